@@ -39,7 +39,9 @@ class FakeTimeModel:
             hist[:, k:] += a[:, :T - k] * (0.5 ** k)
         n = np.arange(N)[None, None, :, None]
         h = np.arange(self.units)[None, None, None, :]
-        return np.tanh(0.3 * hist[:, :, None, None] + 0.1 * n + 0.01 * h).astype(np.float32)
+        out = np.tanh(0.3 * hist[:, :, None, None] + 0.1 * n + 0.01 * h)
+        out[..., 1] = np.sin(2.0 * hist)[:, :, None]          # silence gate, read by FakeNoteModel
+        return out.astype(np.float32)
 
 
 class FakeNoteModel:
@@ -61,7 +63,8 @@ class FakeNoteModel:
         n = np.arange(N)[None, :]
         f0 = feat[:, 0, :, 0]
         sty = (style[:, 0, :] @ np.arange(style.shape[-1]))[:, None]
-        lp = -1.2 + 0.9 * np.sin(0.7 * n + 3.0 * f0 + s + 0.1 * sty)
+        gate = feat[:, 0, :, 1] > 0.3                          # silent steps -> temperature path
+        lp = -1.2 + 0.9 * np.sin(0.7 * n + 3.0 * f0 + s + 0.1 * sty) - 8.0 * gate
         lr = 0.3 * np.cos(0.4 * n + s)
         vol = 0.5 + 0.3 * np.sin(0.2 * n + f0)
         out = np.stack([1 / (1 + np.exp(-lp)), 1 / (1 + np.exp(-lr)), vol], axis=-1)
