@@ -1,0 +1,126 @@
+/* deepj_hip.h -- C ABI of libdeepj_hip.so: the MI355X (gfx950) implementation of the
+ * DeepJ biaxial-LSTM hot path (training step + generation sub-models).
+ *
+ * The reference (calclavia/music-generator) has no FFI on this path: the boundary is
+ * the Keras Model object protocol.  Each entry point below names the reference
+ * interface it replaces (paths relative to /root/reference); the Python duck-types
+ * in music-generator_amd/ (Model.fit / .predict) bind these through ctypes
+ * (see INTEGRATION.md).
+ *
+ * Conventions: every pointer is a DEVICE pointer unless marked "host"; tensors are
+ * dense row-major fp32 in the reference's layouts; no allocation and no implicit
+ * synchronisation inside any call; all work is enqueued on `stream` (a hipStream_t
+ * passed as void*); re-entrant per (stream, workspace).  Return value: 0 = ok,
+ * 1..999 = hipError_t, >= 1000 = argument error.  No exceptions cross the ABI.
+ */
+#ifndef DEEPJ_HIP_H
+#define DEEPJ_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DJ_ABI_VERSION 1
+#define DJ_DTYPE_F32 0  /* fp32 operands, v_mfma_f32_32x32x2_f32 (parity mode)            */
+#define DJ_DTYPE_BF16 1 /* bf16 operands/stash, fp32 accumulate + cell state (throughput) */
+
+/* Hyper-parameters: reference constants.py:42-77 (defaults there), made runtime so the
+ * BASELINE shapes (N=128, B=64) can be expressed. */
+typedef struct dj_config {
+  int32_t batch;            /* B: samples in this call (constants.py:66 BATCH_SIZE)      */
+  int32_t time_steps;       /* T: constants.py:67 SEQ_LEN (1 for note_model.predict)     */
+  int32_t num_notes;        /* N: constants.py:56 NUM_NOTES                              */
+  int32_t num_styles;       /* constants.py:42                                           */
+  int32_t notes_per_bar;    /* constants.py:63 (width of the beat input)                 */
+  int32_t octave;           /* constants.py:51                                           */
+  int32_t octave_units;     /* constants.py:70 (must be 64)                              */
+  int32_t style_units;      /* constants.py:71 (<= 64)                                   */
+  int32_t note_units;       /* constants.py:72 (must be 3)                               */
+  int32_t time_axis_units;  /* constants.py:73 (128 or 256)                              */
+  int32_t note_axis_units;  /* constants.py:74 (128 or 256)                              */
+  int32_t time_axis_layers; /* constants.py:76 (1..4)                                    */
+  int32_t note_axis_layers; /* constants.py:77 (1..4)                                    */
+  int32_t dtype;            /* DJ_DTYPE_*                                                */
+  int32_t recurrent_sigmoid;/* 0: Keras-2 hard_sigmoid gates (default), 1: sigmoid       */
+  float input_dropout;      /* model.py:128 build_models(input_dropout=0.2)              */
+  float dropout;            /* model.py:128 build_models(dropout=0.5)                    */
+} dj_config;
+
+int32_t dj_abi_version(void);
+
+/* Flat fp32 parameter vector in the reference's layer-creation order with Keras tensor
+ * layouts (model.py:128-169).  dj_param_info enumerates the tensors:
+ * returns 0 and fills name/offset/shape for 0 <= index < count, 1000 past the end. */
+int64_t dj_param_count(const dj_config* cfg);
+int32_t dj_param_info(const dj_config* cfg, int32_t index, char* name_host, int32_t name_cap, int64_t* offset_host,
+                      int32_t* shape4_host, int32_t* ndim_host);
+
+/* Caller-owned scratch.  dj_workspace_init must run once (and again after the config
+ * changes) before the first compute call: it zeroes padding rows the kernels rely on. */
+int64_t dj_workspace_bytes(const dj_config* cfg);
+int32_t dj_workspace_init(const dj_config* cfg, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* One teacher-forced forward + BPTT pass = the body of Model.fit on one batch
+ * (train.py:29 -> model.py:151-152; loss = primary_loss, model.py:14-20).
+ * inputs  notes/chosen/target [B,T,N,3], beat [B,T,notes_per_bar], style [B,T,num_styles]
+ * outputs grads[param_count] (overwritten), loss[1] (mean loss), out [B,T,N,3] or NULL.
+ * Dropout masks are a counter hash of (seed, site, element); seed-identical calls are
+ * reproducible and the CPU oracle regenerates the same masks.  dropout == 0 disables. */
+int32_t dj_train_fwd_bwd(const dj_config* cfg, const float* params, float* grads, const float* notes,
+                         const float* chosen, const float* beat, const float* style, const float* target, float* out,
+                         float* loss, void* workspace, int64_t workspace_bytes, uint64_t seed, void* stream);
+
+/* Keras-2 Nadam update (model.py:152 optimizer='nadam'): one fused pass over the flat
+ * vectors.  step_t is 1-based; m_schedule_host is read and updated on the host.
+ * grad_scale pre-multiplies the gradient (1/world_size after an all-reduce(sum)). */
+int32_t dj_nadam_step(float* params, const float* grads, float* m, float* v, int64_t count, int64_t step_t,
+                      double* m_schedule_host, float lr, float beta1, float beta2, float epsilon, float schedule_decay,
+                      float grad_scale, void* stream);
+
+/* Model.predict of the three Keras models built by build_models (model.py:151,155,167),
+ * inference mode (no dropout):
+ *   dj_predict            model       [notes, chosen, beat, style] -> out [B,T,N,3]
+ *   dj_time_model_predict time_model  [notes, beat, style] -> time_out [B,T,N,time_axis_units]
+ *                                      (generate.py:108)
+ *   dj_note_model_predict note_model  [features [B,T,N,time_axis_units], chosen, style] -> out [B,T,N,3]
+ *                                      (generate.py:114; T = 1 there)
+ * target may be passed to dj_predict to also obtain the mean loss (loss may be NULL). */
+int32_t dj_predict(const dj_config* cfg, const float* params, const float* notes, const float* chosen,
+                   const float* beat, const float* style, const float* target, float* out, float* loss,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+int32_t dj_time_model_predict(const dj_config* cfg, const float* params, const float* notes, const float* beat,
+                              const float* style, float* time_out, void* workspace, int64_t workspace_bytes,
+                              void* stream);
+int32_t dj_note_model_predict(const dj_config* cfg, const float* params, const float* features, const float* chosen,
+                              const float* style, float* out, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- single-kernel entry points (unit-tested against the oracle one by one) ---- */
+
+/* C[M,N] = A[M,K] * Bt[N,K]^T + bias[N]; operands in cfg dtype, C in operand dtype
+ * (c_is_f32 = 0) or fp32.  The x*W products of the Keras LSTM layers (model.py:84,122). */
+int32_t dj_gemm_nt(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* Bt,
+                   int32_t ldb, void* C, int32_t ldc, int32_t c_is_f32, const float* bias, void* stream);
+/* C[ka_valid,N] += A[M,Ka]^T * B[M,N] (fp32 atomics).  a_shift = 32 with steps > 0 reads
+ * A one recurrence step earlier (zeros at step 0): the recurrent-kernel gradient. */
+int32_t dj_gemm_tn(int32_t dtype, int64_t M, int32_t Ka, int32_t ka_valid, int32_t N, const void* A, int32_t lda,
+                   const void* B, int32_t ldb, float* C, int32_t ldc, int32_t a_shift, int32_t steps, void* stream);
+/* Pack a Keras recurrent_kernel U[H,4H] (fp32) into MFMA B-fragment order for the
+ * forward (U) and backward (U^T) recurrences; each output holds H*4H operand elements. */
+int32_t dj_lstm_pack(int32_t dtype, int32_t H, const float* U, void* upack_fwd, void* upack_bwd, void* stream);
+/* Recurrent sweep over `steps` for ntiles*32 sequences.  Z [ntiles*steps*32, 4H] holds
+ * x*W+b on entry and the pre-activations on exit; h -> Hout, c -> Cout (may be NULL).
+ * Row order: ((tile*steps + step)*32 + seq_in_tile). */
+int32_t dj_lstm_fwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, void* Z, const void* upack_fwd,
+                    void* Hout, void* Cout, int32_t recurrent_sigmoid, void* stream);
+/* BPTT sweep: Z holds pre-activations on entry, dz on exit; dH = dL/dh per step;
+ * dbias[4H] += column sums of dz. */
+int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, void* Z, const void* upack_bwd,
+                    const void* C, const void* dH, float* dbias, int32_t recurrent_sigmoid, void* stream);
+/* mask[rows, cols] (fp32 0 or 1/(1-p)) of dropout site `site` -- exposes the counter
+ * hash so tests can pin it against the oracle. */
+int32_t dj_dropout_mask(uint64_t seed, int32_t site, float p, int64_t rows, int32_t cols, float* mask, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,91 @@
+"""ctypes binding of libdeepj_hip.so (include/deepj_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails,
+this module raises.  The product never routes through the CPU oracle.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libdeepj_hip.so")
+
+DTYPE_F32, DTYPE_BF16 = 0, 1
+
+
+class DjConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "batch", "time_steps", "num_notes", "num_styles", "notes_per_bar", "octave", "octave_units",
+        "style_units", "note_units", "time_axis_units", "note_axis_units", "time_axis_layers",
+        "note_axis_layers", "dtype", "recurrent_sigmoid")] + [("input_dropout", C.c_float), ("dropout", C.c_float)]
+
+
+class DeepJError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_P = C.c_void_p
+_SIGS = {
+    "dj_abi_version": (C.c_int32, []),
+    "dj_param_count": (C.c_int64, [C.POINTER(DjConfig)]),
+    "dj_param_info": (C.c_int32, [C.POINTER(DjConfig), C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64),
+                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "dj_workspace_bytes": (C.c_int64, [C.POINTER(DjConfig)]),
+    "dj_workspace_init": (C.c_int32, [C.POINTER(DjConfig), _P, C.c_int64, _P]),
+    "dj_train_fwd_bwd": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64,
+                                     C.c_uint64, _P]),
+    "dj_nadam_step": (C.c_int32, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_float, C.c_float,
+                                  C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "dj_predict": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "dj_time_model_predict": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "dj_note_model_predict": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "dj_gemm_nt": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P,
+                               C.c_int32, C.c_int32, _P, _P]),
+    "dj_gemm_tn": (C.c_int32, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32,
+                               _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "dj_lstm_pack": (C.c_int32, [C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "dj_lstm_fwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P]),
+    "dj_lstm_bwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P]),
+    "dj_dropout_mask": (C.c_int32, [C.c_uint64, C.c_int32, C.c_float, C.c_int64, C.c_int32, _P, _P]),
+    "dj_generate_step": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
+}
+OPTIONAL = {"dj_generate_step"}
+
+
+def load():
+    """Load the library (once) and declare every prototype of include/deepj_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DeepJError(
+            f"{LIB_PATH} is missing: build it with `python -m music_generator_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if name in OPTIONAL:
+                continue
+            raise DeepJError(f"{LIB_PATH} does not export {name}")
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dj_abi_version() != 1:
+        raise DeepJError("libdeepj_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = "hipError_t" if rc < 1000 else "argument error"
+        raise DeepJError(f"{what} failed: code {rc} ({kind})")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,513 @@
+// C ABI of libdeepj_hip.so (include/deepj_hip.h): workspace planning and the kernel
+// sequence of one training step / one predict call.  Host code only.
+//
+// Reference graph being executed: model.py:128-169 (build_models), loss model.py:14-20,
+// optimizer model.py:152; driven in the reference by Model.fit (train.py:29) and
+// Model.predict (generate.py:108,114).
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/deepj_hip.h"
+#include "dj_kernels.h"
+
+namespace {
+
+constexpr int MAXL = 4;
+
+struct LstmP {          // parameter offsets (floats) of one LSTM layer + its style Dense
+  int64_t dW, db;       // style Dense kernel [SU, D], bias [D]
+  int64_t W, U, b;      // LSTM kernel [D,4H], recurrent_kernel [H,4H], bias [4H]
+  int D, DP, H;
+};
+
+struct Plan {
+  dj_config c;
+  int B, T, N, S, NB, SU, F, FP, Ht, Hn, Lt, Ln, esz;
+  int64_t BT, seqT, tilesT, Mt, seqN, tilesN, Mn;
+  // parameter offsets
+  int64_t p_style_W, p_style_b, p_conv_W, p_conv_b, p_nd_W, p_nd_b, p_vd_W, p_vd_b, nparams;
+  LstmP tl[MAXL], nl[MAXL];
+  // workspace offsets (bytes)
+  int64_t w_style, w_dstyle, w_bins, w_sp_t[MAXL], w_sp_n[MAXL], w_dpre_t[MAXL], w_dpre_n[MAXL];
+  int64_t w_Wt_t[MAXL], w_Wc_t[MAXL], w_Uf_t[MAXL], w_Ub_t[MAXL];
+  int64_t w_Wt_n[MAXL], w_Wc_n[MAXL], w_Uf_n[MAXL], w_Ub_n[MAXL];
+  int64_t w_X_t[MAXL], w_Z_t[MAXL], w_H_t[MAXL], w_C_t[MAXL];
+  int64_t w_X_n[MAXL], w_Z_n[MAXL], w_H_n[MAXL], w_C_n[MAXL];
+  int64_t w_dH_t, w_dX_t, w_dH_n, w_dX_n, w_featin;
+  int64_t ws_bytes;
+};
+
+inline int64_t up8(int64_t v) { return (v + 7) / 8 * 8; }
+
+int make_plan(const dj_config* cfg, Plan& p) {
+  if (!cfg) return 1100;
+  memset(&p, 0, sizeof(p));
+  p.c = *cfg;
+  p.B = cfg->batch; p.T = cfg->time_steps; p.N = cfg->num_notes; p.S = cfg->num_styles;
+  p.NB = cfg->notes_per_bar; p.SU = cfg->style_units; p.Ht = cfg->time_axis_units; p.Hn = cfg->note_axis_units;
+  p.Lt = cfg->time_axis_layers; p.Ln = cfg->note_axis_layers;
+  if (p.B < 1 || p.T < 1 || p.N < 1 || p.S < 1 || p.NB < 1) return 1101;
+  if (cfg->octave_units != 64 || cfg->note_units != 3 || cfg->octave < 1) return 1102;
+  if (p.SU < 1 || p.SU > 64) return 1103;
+  if ((p.Ht != 128 && p.Ht != 256) || (p.Hn != 128 && p.Hn != 256)) return 1104;
+  if (p.Lt < 1 || p.Lt > MAXL || p.Ln < 1 || p.Ln > MAXL) return 1105;
+  if (cfg->dtype != DJ_F32 && cfg->dtype != DJ_BF16) return 1106;
+  if (cfg->input_dropout < 0 || cfg->input_dropout >= 1 || cfg->dropout < 0 || cfg->dropout >= 1) return 1107;
+  p.esz = cfg->dtype == DJ_F32 ? 4 : 2;
+  p.F = 1 + cfg->octave + 1 + cfg->octave_units + p.NB;    // model.py:61-67
+  p.FP = (int)up8(p.F);
+  if (p.FP - 64 > 64 || p.F > 128) return 1108;
+  p.BT = (int64_t)p.B * p.T;
+  p.seqT = (int64_t)p.B * p.N; p.tilesT = (p.seqT + 31) / 32; p.Mt = p.tilesT * 32 * p.T;
+  p.seqN = p.BT;               p.tilesN = (p.seqN + 31) / 32; p.Mn = p.tilesN * 32 * p.N;
+  if ((int64_t)p.BT * p.N * 264 >= (1LL << 32)) return 1109;   // dropout hash uses 32-bit rows
+  if (p.Mt * 4 * p.Ht >= (1LL << 40) || p.Mt > (1LL << 31) - 256 || p.Mn > (1LL << 31) - 256) return 1110;
+
+  // ---- parameters, reference creation order (model.py:128-169)
+  int64_t o = 0;
+  auto take = [&](int64_t n) { int64_t r = o; o += n; return r; };
+  p.p_style_W = take((int64_t)p.S * p.SU); p.p_style_b = take(p.SU);
+  p.p_conv_W = take(24 * 3 * 64); p.p_conv_b = take(64);
+  for (int l = 0; l < p.Lt; ++l) {
+    LstmP& L = p.tl[l];
+    L.D = l == 0 ? p.F : p.Ht; L.DP = (int)up8(L.D); L.H = p.Ht;
+    L.dW = take((int64_t)p.SU * L.D); L.db = take(L.D);
+    L.W = take((int64_t)L.D * 4 * L.H); L.U = take((int64_t)L.H * 4 * L.H); L.b = take(4 * L.H);
+  }
+  for (int l = 0; l < p.Ln; ++l) {
+    LstmP& L = p.nl[l];
+    L.D = l == 0 ? p.Ht + 3 : p.Hn; L.DP = (int)up8(L.D); L.H = p.Hn;
+    L.dW = take((int64_t)p.SU * L.D); L.db = take(L.D);
+    L.W = take((int64_t)L.D * 4 * L.H); L.U = take((int64_t)L.H * 4 * L.H); L.b = take(4 * L.H);
+  }
+  p.p_nd_W = take(p.Hn * 2); p.p_nd_b = take(2); p.p_vd_W = take(p.Hn); p.p_vd_b = take(1);
+  p.nparams = o;
+
+  // ---- workspace
+  int64_t w = 0;
+  auto wtake = [&](int64_t bytes) { int64_t r = w; w += (bytes + 255) / 256 * 256; return r; };
+  p.w_style = wtake(p.BT * p.SU * 4); p.w_dstyle = wtake(p.BT * p.SU * 4);
+  p.w_bins = wtake((int64_t)cfg->octave * p.BT * 4 + 256);   // + loss scratch not needed; pad only
+  int maxDPt = 0, maxDPn = 0;
+  for (int l = 0; l < p.Lt; ++l) {
+    const LstmP& L = p.tl[l];
+    p.w_sp_t[l] = wtake(p.BT * L.D * 4); p.w_dpre_t[l] = wtake(p.BT * L.D * 4);
+    p.w_Wt_t[l] = wtake((int64_t)4 * L.H * L.DP * p.esz); p.w_Wc_t[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
+    p.w_Uf_t[l] = wtake((int64_t)L.H * 4 * L.H * p.esz); p.w_Ub_t[l] = wtake((int64_t)L.H * 4 * L.H * p.esz);
+    p.w_X_t[l] = wtake(p.Mt * L.DP * p.esz); p.w_Z_t[l] = wtake(p.Mt * 4 * L.H * p.esz);
+    p.w_H_t[l] = wtake(p.Mt * L.H * p.esz); p.w_C_t[l] = wtake(p.Mt * L.H * p.esz);
+    if (L.DP > maxDPt) maxDPt = L.DP;
+  }
+  for (int l = 0; l < p.Ln; ++l) {
+    const LstmP& L = p.nl[l];
+    p.w_sp_n[l] = wtake(p.BT * L.D * 4); p.w_dpre_n[l] = wtake(p.BT * L.D * 4);
+    p.w_Wt_n[l] = wtake((int64_t)4 * L.H * L.DP * p.esz); p.w_Wc_n[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
+    p.w_Uf_n[l] = wtake((int64_t)L.H * 4 * L.H * p.esz); p.w_Ub_n[l] = wtake((int64_t)L.H * 4 * L.H * p.esz);
+    p.w_X_n[l] = wtake(p.Mn * L.DP * p.esz); p.w_Z_n[l] = wtake(p.Mn * 4 * L.H * p.esz);
+    p.w_H_n[l] = wtake(p.Mn * L.H * p.esz); p.w_C_n[l] = wtake(p.Mn * L.H * p.esz);
+    if (L.DP > maxDPn) maxDPn = L.DP;
+  }
+  p.w_dH_t = wtake(p.Mt * p.Ht * p.esz); p.w_dX_t = wtake(p.Mt * maxDPt * p.esz);
+  p.w_dH_n = wtake(p.Mn * p.Hn * p.esz); p.w_dX_n = wtake(p.Mn * maxDPn * p.esz);
+  p.w_featin = wtake(p.Mn * p.Ht * p.esz);   // note_model.predict: features in NA order
+  p.ws_bytes = w;
+  return 0;
+}
+
+DjDrop mkdrop(uint64_t seed, int site, float prob, bool train) {
+  DjDrop d;
+  d.key = (uint32_t)(seed & 0xFFFFFFFFu) ^ ((uint32_t)site * 0x9E3779B9u);
+  d.thr = (train && prob > 0.f) ? (uint32_t)ceil((double)prob * 16777216.0) : 0u;
+  d.scale = (float)(1.0 / (1.0 - (double)prob));
+  return d;
+}
+
+struct Ctx {
+  const Plan& p;
+  const float* P;
+  char* ws;
+  hipStream_t st;
+  bool train;
+  uint64_t seed;
+  template <typename X = void> X* at(int64_t off) const { return (X*)(ws + off); }
+};
+
+#define RUN(x)                 \
+  do {                         \
+    int rc_ = (x);             \
+    if (rc_) return rc_;       \
+  } while (0)
+
+// weight conversion/packing for one LSTM layer
+int prep_layer(const Ctx& c, const LstmP& L, int64_t wWt, int64_t wWc, int64_t wUf, int64_t wUb, bool need_bwd) {
+  const int dt = c.p.c.dtype;
+  RUN(dj_launch_cvt_transpose(dt, c.P + L.W, L.D, 4 * L.H, c.at(wWt), L.DP, c.st));
+  RUN(dj_launch_lstm_pack(dt, L.H, c.P + L.U, c.at(wUf), need_bwd ? c.at(wUb) : nullptr, c.st));
+  if (need_bwd && dt != DJ_F32) RUN(dj_launch_cvt_copy(dt, c.P + L.W, (int64_t)L.D * 4 * L.H, c.at(wWc), c.st));
+  return 0;
+}
+
+int style_forward(const Ctx& c, const float* style_in) {
+  const Plan& p = c.p;
+  RUN(dj_launch_dense_small(style_in, (int)p.BT, p.S, c.P + p.p_style_W, c.P + p.p_style_b, c.at<float>(p.w_style),
+                            p.SU, 0, c.st));                                            // model.py:141-142
+  return 0;
+}
+int style_proj(const Ctx& c, const LstmP& L, int64_t w_sp) {                            // model.py:77,110-113 + tanh
+  return dj_launch_dense_small(c.at<float>(c.p.w_style), (int)c.p.BT, c.p.SU, c.P + L.dW, c.P + L.db,
+                               c.at<float>(w_sp), L.D, 1, c.st);
+}
+
+int lstm_layer_fwd(const Ctx& c, const LstmP& L, int64_t tiles, int steps, int64_t M, int64_t wX, int64_t wWt,
+                   int64_t wUf, int64_t wZ, int64_t wH, int64_t wC) {
+  const int dt = c.p.c.dtype;
+  RUN(dj_launch_gemm_nt(dt, (int)M, 4 * L.H, L.DP, c.at(wX), L.DP, c.at(wWt), L.DP, c.at(wZ), 4 * L.H, 0,
+                        c.P + L.b, c.st));
+  RUN(dj_launch_lstm_fwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUf), c.at(wH), c.train ? c.at(wC) : nullptr,
+                         c.p.c.recurrent_sigmoid, c.train ? 1 : 0, c.st));
+  return 0;
+}
+
+// time axis (model.py:51-89): fills H_t[Lt-1]
+int time_axis_forward(const Ctx& c, const float* notes, const float* beat) {
+  const Plan& p = c.p;
+  const int dt = p.c.dtype;
+  const float pin = p.c.input_dropout, pdr = p.c.dropout;
+  DjDrop d_notes = mkdrop(c.seed, DJ_SITE_NOTES, pin, c.train);
+  RUN(dj_launch_bins(notes, c.at<float>(p.w_bins), p.B, p.T, p.N, p.c.octave, d_notes, c.st));
+  for (int l = 0; l < p.Lt; ++l) RUN(style_proj(c, p.tl[l], p.w_sp_t[l]));
+  FeatArgs fa;
+  fa.notes = notes; fa.beat = beat; fa.bins = c.at<float>(p.w_bins); fa.sp0 = c.at<float>(p.w_sp_t[0]);
+  fa.Wc = c.P + p.p_conv_W; fa.bc = c.P + p.p_conv_b;
+  fa.B = p.B; fa.T = p.T; fa.N = p.N; fa.NB = p.NB; fa.octave = p.c.octave; fa.F = p.F; fa.FP = p.FP;
+  fa.d_notes = d_notes; fa.d_beat = mkdrop(c.seed, DJ_SITE_BEAT, pin, c.train);
+  fa.d_conv = mkdrop(c.seed, DJ_SITE_CONV, pdr, c.train);
+  fa.d_style = mkdrop(c.seed, DJ_SITE_TSTYLE + 0, pdr, c.train);
+  RUN(dj_launch_feature_fwd(dt, &fa, c.at(p.w_X_t[0]), c.st));
+  for (int l = 0; l < p.Lt; ++l) {
+    const LstmP& L = p.tl[l];
+    if (l > 0) {
+      GlueArgs g;
+      g.B = p.B; g.T = p.T; g.N = p.N; g.Hd = p.Ht; g.D = L.D; g.DP = L.DP; g.in_na = 0; g.out_na = 0;
+      g.sp = c.at<float>(p.w_sp_t[l]); g.chosen = nullptr;
+      g.d_out = mkdrop(c.seed, DJ_SITE_TOUT + (l - 1), pdr, c.train);
+      g.d_style = mkdrop(c.seed, DJ_SITE_TSTYLE + l, pdr, c.train);
+      g.d_chosen = mkdrop(c.seed, DJ_SITE_CHOSEN, pin, c.train);
+      RUN(dj_launch_glue_fwd(dt, &g, c.at(p.w_H_t[l - 1]), c.at(p.w_X_t[l]), c.st));
+    }
+    RUN(lstm_layer_fwd(c, L, p.tilesT, p.T, p.Mt, p.w_X_t[l], p.w_Wt_t[l], p.w_Uf_t[l], p.w_Z_t[l], p.w_H_t[l],
+                       p.w_C_t[l]));
+  }
+  return 0;
+}
+
+// note axis (model.py:91-126) from producer buffer `wHin` (TA order if !in_na), then head (+ loss)
+int note_axis_forward(const Ctx& c, int64_t wHin, int in_na, int d_out_site, const float* chosen,
+                      const float* target, float* out, float* loss, float* grads) {
+  const Plan& p = c.p;
+  const int dt = p.c.dtype;
+  const float pin = p.c.input_dropout, pdr = p.c.dropout;
+  for (int l = 0; l < p.Ln; ++l) RUN(style_proj(c, p.nl[l], p.w_sp_n[l]));
+  for (int l = 0; l < p.Ln; ++l) {
+    const LstmP& L = p.nl[l];
+    GlueArgs g;
+    g.B = p.B; g.T = p.T; g.N = p.N; g.D = L.D; g.DP = L.DP; g.out_na = 1;
+    g.sp = c.at<float>(p.w_sp_n[l]);
+    g.d_style = mkdrop(c.seed, DJ_SITE_NSTYLE + l, pdr, c.train);
+    g.d_chosen = mkdrop(c.seed, DJ_SITE_CHOSEN, pin, c.train);
+    if (l == 0) {
+      g.Hd = p.Ht; g.in_na = in_na; g.chosen = chosen;
+      g.d_out = mkdrop(c.seed, d_out_site, pdr, c.train && d_out_site >= 0);
+      RUN(dj_launch_glue_fwd(dt, &g, c.at(wHin), c.at(p.w_X_n[0]), c.st));
+    } else {
+      g.Hd = p.Hn; g.in_na = 1; g.chosen = nullptr;
+      g.d_out = mkdrop(c.seed, DJ_SITE_NOUT + (l - 1), pdr, c.train);
+      RUN(dj_launch_glue_fwd(dt, &g, c.at(p.w_H_n[l - 1]), c.at(p.w_X_n[l]), c.st));
+    }
+    RUN(lstm_layer_fwd(c, L, p.tilesN, p.N, p.Mn, p.w_X_n[l], p.w_Wt_n[l], p.w_Uf_n[l], p.w_Z_n[l], p.w_H_n[l],
+                       p.w_C_n[l]));
+  }
+  HeadArgs h;
+  h.B = p.B; h.T = p.T; h.N = p.N; h.Hd = p.Hn;
+  h.Wn = c.P + p.p_nd_W; h.bn = c.P + p.p_nd_b; h.Wv = c.P + p.p_vd_W; h.bv = c.P + p.p_vd_b;
+  h.target = target; h.out = out; h.loss = loss;
+  h.dWn = grads ? grads + p.p_nd_W : nullptr; h.dbn = grads ? grads + p.p_nd_b : nullptr;
+  h.dWv = grads ? grads + p.p_vd_W : nullptr; h.dbv = grads ? grads + p.p_vd_b : nullptr;
+  h.inv_count = (float)(1.0 / ((double)p.BT * p.N));
+  h.d_out = mkdrop(c.seed, DJ_SITE_NOUT + (p.Ln - 1), pdr, c.train);
+  if (target && !grads) {   // loss only: head gradients land in scratch (dX_n is unused in inference)
+    float* dummy = c.at<float>(p.w_dX_n);
+    h.dWn = dummy; h.dbn = dummy + 2 * p.Hn; h.dWv = dummy + 2 * p.Hn + 2; h.dbv = dummy + 3 * p.Hn + 2;
+  }
+  RUN(dj_launch_head(dt, &h, c.at(p.w_H_n[p.Ln - 1]), (grads && c.train) ? c.at(p.w_dH_n) : nullptr, c.st));
+  return 0;
+}
+
+int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int steps, int64_t M, int64_t wX,
+                   int64_t wWc, int64_t wUb, int64_t wZ, int64_t wH, int64_t wC, int64_t wdH, int64_t wdX) {
+  const int dt = c.p.c.dtype;
+  RUN(dj_launch_lstm_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUb), c.at(wC), c.at(wdH), G + L.b,
+                         c.p.c.recurrent_sigmoid, c.st));
+  RUN(dj_launch_gemm_tn(dt, M, L.DP, L.D, 4 * L.H, c.at(wX), L.DP, c.at(wZ), 4 * L.H, G + L.W, 4 * L.H, 0, 0, c.st));
+  RUN(dj_launch_gemm_tn(dt, M, L.H, L.H, 4 * L.H, c.at(wH), L.H, c.at(wZ), 4 * L.H, G + L.U, 4 * L.H, 32, steps, c.st));
+  const void* Bt = dt == DJ_F32 ? (const void*)(c.P + L.W) : (const void*)c.at(wWc);
+  RUN(dj_launch_gemm_nt(dt, (int)M, L.D, 4 * L.H, c.at(wZ), 4 * L.H, Bt, 4 * L.H, c.at(wdX), L.DP, 0, nullptr, c.st));
+  return 0;
+}
+
+int style_dense_bwd(const Ctx& c, const LstmP& L, float* G, int64_t w_dpre, bool first) {
+  const Plan& p = c.p;
+  RUN(dj_launch_dense_small_bwd_w(c.at<float>(p.w_style), (int)p.BT, p.SU, c.at<float>(w_dpre), L.D, G + L.dW,
+                                  G + L.db, c.st));
+  RUN(dj_launch_dense_small_bwd_x(c.at<float>(w_dpre), (int)p.BT, L.D, c.P + L.dW, p.SU, c.at<float>(p.w_dstyle),
+                                  first ? 0 : 1, c.st));
+  return 0;
+}
+
+int check_ws(const Plan& p, void* ws, int64_t bytes) {
+  if (!ws || bytes < p.ws_bytes) return 1200;
+  if (((uintptr_t)ws) & 255) return 1201;
+  return 0;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+int32_t dj_abi_version(void) { return DJ_ABI_VERSION; }
+
+int64_t dj_param_count(const dj_config* cfg) {
+  Plan p;
+  if (make_plan(cfg, p)) return -1;
+  return p.nparams;
+}
+
+int32_t dj_param_info(const dj_config* cfg, int32_t index, char* name, int32_t cap, int64_t* offset, int32_t* shape,
+                      int32_t* ndim) {
+  Plan p;
+  int rc = make_plan(cfg, p);
+  if (rc) return rc;
+  struct E { char nm[48]; int64_t off; int sh[4]; int nd; };
+  E e[8 + 10 * MAXL];
+  int n = 0;
+  auto add = [&](const char* nm, int64_t off, int nd, int a, int b, int c3) {
+    snprintf(e[n].nm, sizeof(e[n].nm), "%s", nm);
+    e[n].off = off; e[n].nd = nd; e[n].sh[0] = a; e[n].sh[1] = b; e[n].sh[2] = c3; e[n].sh[3] = 0; ++n;
+  };
+  add("style/kernel", p.p_style_W, 2, p.S, p.SU, 0); add("style/bias", p.p_style_b, 1, p.SU, 0, 0);
+  add("conv/kernel", p.p_conv_W, 3, 24, 3, 64); add("conv/bias", p.p_conv_b, 1, 64, 0, 0);
+  char buf[48];
+  for (int ax = 0; ax < 2; ++ax) {
+    int Lc = ax ? p.Ln : p.Lt;
+    for (int l = 0; l < Lc; ++l) {
+      const LstmP& L = ax ? p.nl[l] : p.tl[l];
+      const char* a = ax ? "note" : "time";
+      snprintf(buf, sizeof buf, "%s_dense%d/kernel", a, l); add(buf, L.dW, 2, p.SU, L.D, 0);
+      snprintf(buf, sizeof buf, "%s_dense%d/bias", a, l); add(buf, L.db, 1, L.D, 0, 0);
+      snprintf(buf, sizeof buf, "%s_lstm%d/kernel", a, l); add(buf, L.W, 2, L.D, 4 * L.H, 0);
+      snprintf(buf, sizeof buf, "%s_lstm%d/recurrent_kernel", a, l); add(buf, L.U, 2, L.H, 4 * L.H, 0);
+      snprintf(buf, sizeof buf, "%s_lstm%d/bias", a, l); add(buf, L.b, 1, 4 * L.H, 0, 0);
+    }
+  }
+  add("note_dense/kernel", p.p_nd_W, 2, p.Hn, 2, 0); add("note_dense/bias", p.p_nd_b, 1, 2, 0, 0);
+  add("volume_dense/kernel", p.p_vd_W, 2, p.Hn, 1, 0); add("volume_dense/bias", p.p_vd_b, 1, 1, 0, 0);
+  if (index < 0 || index >= n) return 1000;
+  if (name && cap > 0) snprintf(name, cap, "%s", e[index].nm);
+  if (offset) *offset = e[index].off;
+  if (shape) memcpy(shape, e[index].sh, sizeof(int) * 4);
+  if (ndim) *ndim = e[index].nd;
+  return 0;
+}
+
+int64_t dj_workspace_bytes(const dj_config* cfg) {
+  Plan p;
+  if (make_plan(cfg, p)) return -1;
+  return p.ws_bytes;
+}
+
+int32_t dj_workspace_init(const dj_config* cfg, void* ws, int64_t bytes, void* stream) {
+  Plan p;
+  RUN(make_plan(cfg, p));
+  RUN(check_ws(p, ws, bytes));
+  return (int)hipMemsetAsync(ws, 0, p.ws_bytes, (hipStream_t)stream);
+}
+
+int32_t dj_train_fwd_bwd(const dj_config* cfg, const float* params, float* grads, const float* notes,
+                         const float* chosen, const float* beat, const float* style, const float* target, float* out,
+                         float* loss, void* ws, int64_t ws_bytes, uint64_t seed, void* stream) {
+  Plan p;
+  RUN(make_plan(cfg, p));
+  RUN(check_ws(p, ws, ws_bytes));
+  if (!params || !grads || !notes || !chosen || !beat || !style || !target || !loss) return 1210;
+  Ctx c{p, params, (char*)ws, (hipStream_t)stream, true, seed};
+  const int dt = p.c.dtype;
+  float* G = grads;
+  DJ_CHECK(hipMemsetAsync(G, 0, p.nparams * sizeof(float), c.st));
+  DJ_CHECK(hipMemsetAsync(loss, 0, sizeof(float), c.st));
+  for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], true));
+  for (int l = 0; l < p.Ln; ++l) RUN(prep_layer(c, p.nl[l], p.w_Wt_n[l], p.w_Wc_n[l], p.w_Uf_n[l], p.w_Ub_n[l], true));
+
+  // ---------------- forward
+  RUN(style_forward(c, style));
+  RUN(time_axis_forward(c, notes, beat));
+  RUN(note_axis_forward(c, p.w_H_t[p.Lt - 1], 0, DJ_SITE_TOUT + (p.Lt - 1), chosen, target, out, loss, G));
+
+  // ---------------- backward (BPTT)
+  const float pin = p.c.input_dropout, pdr = p.c.dropout;
+  for (int l = p.Ln - 1; l >= 0; --l) {
+    const LstmP& L = p.nl[l];
+    RUN(lstm_layer_bwd(c, L, G, p.tilesN, p.N, p.Mn, p.w_X_n[l], p.w_Wc_n[l], p.w_Ub_n[l], p.w_Z_n[l], p.w_H_n[l],
+                       p.w_C_n[l], p.w_dH_n, p.w_dX_n));
+    GlueArgs g;
+    g.B = p.B; g.T = p.T; g.N = p.N; g.D = L.D; g.DP = L.DP; g.out_na = 1;
+    g.sp = c.at<float>(p.w_sp_n[l]); g.chosen = nullptr;
+    g.d_style = mkdrop(seed, DJ_SITE_NSTYLE + l, pdr, true);
+    g.d_chosen = mkdrop(seed, DJ_SITE_CHOSEN, pin, true);
+    if (l == 0) {
+      g.Hd = p.Ht; g.in_na = 0;
+      g.d_out = mkdrop(seed, DJ_SITE_TOUT + (p.Lt - 1), pdr, true);
+      RUN(dj_launch_glue_bwd(dt, &g, c.at(p.w_dX_n), c.at(p.w_dH_t), c.at<float>(p.w_dpre_n[l]), c.st));
+    } else {
+      g.Hd = p.Hn; g.in_na = 1;
+      g.d_out = mkdrop(seed, DJ_SITE_NOUT + (l - 1), pdr, true);
+      RUN(dj_launch_glue_bwd(dt, &g, c.at(p.w_dX_n), c.at(p.w_dH_n), c.at<float>(p.w_dpre_n[l]), c.st));
+    }
+  }
+  for (int l = p.Lt - 1; l >= 0; --l) {
+    const LstmP& L = p.tl[l];
+    RUN(lstm_layer_bwd(c, L, G, p.tilesT, p.T, p.Mt, p.w_X_t[l], p.w_Wc_t[l], p.w_Ub_t[l], p.w_Z_t[l], p.w_H_t[l],
+                       p.w_C_t[l], p.w_dH_t, p.w_dX_t));
+    if (l > 0) {
+      GlueArgs g;
+      g.B = p.B; g.T = p.T; g.N = p.N; g.Hd = p.Ht; g.D = L.D; g.DP = L.DP; g.in_na = 0; g.out_na = 0;
+      g.sp = c.at<float>(p.w_sp_t[l]); g.chosen = nullptr;
+      g.d_out = mkdrop(seed, DJ_SITE_TOUT + (l - 1), pdr, true);
+      g.d_style = mkdrop(seed, DJ_SITE_TSTYLE + l, pdr, true);
+      g.d_chosen = mkdrop(seed, DJ_SITE_CHOSEN, pin, true);
+      RUN(dj_launch_glue_bwd(dt, &g, c.at(p.w_dX_t), c.at(p.w_dH_t), c.at<float>(p.w_dpre_t[l]), c.st));
+    } else {
+      FeatArgs fa;
+      fa.notes = notes; fa.beat = beat; fa.bins = c.at<float>(p.w_bins); fa.sp0 = c.at<float>(p.w_sp_t[0]);
+      fa.Wc = c.P + p.p_conv_W; fa.bc = c.P + p.p_conv_b;
+      fa.B = p.B; fa.T = p.T; fa.N = p.N; fa.NB = p.NB; fa.octave = p.c.octave; fa.F = p.F; fa.FP = p.FP;
+      fa.d_notes = mkdrop(seed, DJ_SITE_NOTES, pin, true); fa.d_beat = mkdrop(seed, DJ_SITE_BEAT, pin, true);
+      fa.d_conv = mkdrop(seed, DJ_SITE_CONV, pdr, true); fa.d_style = mkdrop(seed, DJ_SITE_TSTYLE + 0, pdr, true);
+      RUN(dj_launch_feature_bwd(dt, &fa, c.at(p.w_dX_t), G + p.p_conv_W, G + p.p_conv_b,
+                                c.at<float>(p.w_dpre_t[0]), c.st));
+    }
+  }
+  // style Dense layers and the style embedding (model.py:141-142,77,110-113)
+  bool first = true;
+  for (int l = 0; l < p.Lt; ++l) { RUN(style_dense_bwd(c, p.tl[l], G, p.w_dpre_t[l], first)); first = false; }
+  for (int l = 0; l < p.Ln; ++l) { RUN(style_dense_bwd(c, p.nl[l], G, p.w_dpre_n[l], first)); first = false; }
+  RUN(dj_launch_dense_small_bwd_w(style, (int)p.BT, p.S, c.at<float>(p.w_dstyle), p.SU, G + p.p_style_W,
+                                  G + p.p_style_b, c.st));
+  return 0;
+}
+
+int32_t dj_nadam_step(float* params, const float* grads, float* m, float* v, int64_t count, int64_t step_t,
+                      double* m_schedule, float lr, float beta1, float beta2, float epsilon, float schedule_decay,
+                      float grad_scale, void* stream) {
+  if (!params || !grads || !m || !v || !m_schedule || step_t < 1) return 1220;
+  // Keras 2.x Nadam.get_updates
+  double t = (double)step_t;
+  double mu_t = beta1 * (1.0 - 0.5 * pow(0.96, t * schedule_decay));
+  double mu_t1 = beta1 * (1.0 - 0.5 * pow(0.96, (t + 1.0) * schedule_decay));
+  double ms_new = (*m_schedule) * mu_t;
+  double ms_next = ms_new * mu_t1;
+  NadamArgs a;
+  a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = epsilon;
+  a.mu_t = (float)mu_t; a.mu_t1 = (float)mu_t1; a.ms_new = (float)ms_new; a.ms_next = (float)ms_next;
+  a.bc2 = (float)(1.0 - pow((double)beta2, t));
+  a.gscale = grad_scale;
+  *m_schedule = ms_new;
+  return dj_launch_nadam(params, grads, m, v, count, &a, (hipStream_t)stream);
+}
+
+int32_t dj_predict(const dj_config* cfg, const float* params, const float* notes, const float* chosen,
+                   const float* beat, const float* style, const float* target, float* out, float* loss, void* ws,
+                   int64_t ws_bytes, void* stream) {
+  Plan p;
+  RUN(make_plan(cfg, p));
+  RUN(check_ws(p, ws, ws_bytes));
+  if (!params || !notes || !chosen || !beat || !style || !out) return 1210;
+  if (target && !loss) return 1211;
+  Ctx c{p, params, (char*)ws, (hipStream_t)stream, false, 0};
+  for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], false));
+  for (int l = 0; l < p.Ln; ++l) RUN(prep_layer(c, p.nl[l], p.w_Wt_n[l], p.w_Wc_n[l], p.w_Uf_n[l], p.w_Ub_n[l], false));
+  if (target) DJ_CHECK(hipMemsetAsync(loss, 0, sizeof(float), c.st));
+  RUN(style_forward(c, style));
+  RUN(time_axis_forward(c, notes, beat));
+  RUN(note_axis_forward(c, p.w_H_t[p.Lt - 1], 0, -1, chosen, target, out, target ? loss : nullptr, nullptr));
+  return 0;
+}
+
+int32_t dj_time_model_predict(const dj_config* cfg, const float* params, const float* notes, const float* beat,
+                              const float* style, float* time_out, void* ws, int64_t ws_bytes, void* stream) {
+  Plan p;
+  RUN(make_plan(cfg, p));
+  RUN(check_ws(p, ws, ws_bytes));
+  if (!params || !notes || !beat || !style || !time_out) return 1210;
+  Ctx c{p, params, (char*)ws, (hipStream_t)stream, false, 0};
+  for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], false));
+  RUN(style_forward(c, style));
+  RUN(time_axis_forward(c, notes, beat));
+  return dj_launch_ta_to_canonical(p.c.dtype, c.at(p.w_H_t[p.Lt - 1]), time_out, p.B, p.T, p.N, p.Ht, c.st);
+}
+
+int32_t dj_note_model_predict(const dj_config* cfg, const float* params, const float* features, const float* chosen,
+                              const float* style, float* out, void* ws, int64_t ws_bytes, void* stream) {
+  Plan p;
+  RUN(make_plan(cfg, p));
+  RUN(check_ws(p, ws, ws_bytes));
+  if (!params || !features || !chosen || !style || !out) return 1210;
+  Ctx c{p, params, (char*)ws, (hipStream_t)stream, false, 0};
+  for (int l = 0; l < p.Ln; ++l) RUN(prep_layer(c, p.nl[l], p.w_Wt_n[l], p.w_Wc_n[l], p.w_Uf_n[l], p.w_Ub_n[l], false));
+  RUN(style_forward(c, style));
+  RUN(dj_launch_canonical_to_na(p.c.dtype, features, c.at(p.w_featin), p.B, p.T, p.N, p.Ht, c.st));
+  RUN(note_axis_forward(c, p.w_featin, 1, -1, chosen, nullptr, out, nullptr, nullptr));
+  return 0;
+}
+
+// ------------------------------------------------------------------ single-kernel entry points
+int32_t dj_gemm_nt(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* Bt,
+                   int32_t ldb, void* C, int32_t ldc, int32_t c_is_f32, const float* bias, void* stream) {
+  if (dtype != DJ_F32 && dtype != DJ_BF16) return 1106;
+  return dj_launch_gemm_nt(dtype, M, N, K, A, lda, Bt, ldb, C, ldc, c_is_f32, bias, (hipStream_t)stream);
+}
+int32_t dj_gemm_tn(int32_t dtype, int64_t M, int32_t Ka, int32_t ka_valid, int32_t N, const void* A, int32_t lda,
+                   const void* B, int32_t ldb, float* C, int32_t ldc, int32_t a_shift, int32_t steps, void* stream) {
+  if (dtype != DJ_F32 && dtype != DJ_BF16) return 1106;
+  if (M % 32) return 1230;
+  return dj_launch_gemm_tn(dtype, M, Ka, ka_valid, N, A, lda, B, ldb, C, ldc, a_shift, steps, (hipStream_t)stream);
+}
+int32_t dj_lstm_pack(int32_t dtype, int32_t H, const float* U, void* f, void* b, void* stream) {
+  return dj_launch_lstm_pack(dtype, H, U, f, b, (hipStream_t)stream);
+}
+int32_t dj_lstm_fwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, void* Z, const void* upack, void* Hout,
+                    void* Cout, int32_t sigm, void* stream) {
+  return dj_launch_lstm_fwd(dtype, H, ntiles, steps, Z, upack, Hout, Cout, sigm, 1, (hipStream_t)stream);
+}
+int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, void* Z, const void* upack,
+                    const void* C, const void* dH, float* dbias, int32_t sigm, void* stream) {
+  return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dbias, sigm, (hipStream_t)stream);
+}
+
+__global__ void dropout_mask_kernel(DjDrop d, int64_t rows, int cols, float* mask) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  uint32_t r = (uint32_t)(idx / cols), c = (uint32_t)(idx % cols);
+  mask[idx] = dj_keep(d, dj_rowkey(d, r), c);
+}
+int32_t dj_dropout_mask(uint64_t seed, int32_t site, float prob, int64_t rows, int32_t cols, float* mask,
+                        void* stream) {
+  DjDrop d = mkdrop(seed, site, prob, true);
+  int64_t n = rows * cols;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d, rows,
+                     cols, mask);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+// DeepJ biaxial-LSTM hot path for MI355X (gfx950 / CDNA4) -- shared device helpers.
+//
+// Conventions used by every kernel in this directory:
+//  * "operand type" T is float (parity mode) or __bf16 (throughput mode); all
+//    accumulation, cell state and gate math is fp32.
+//  * MFMA tiles are 32x32 (v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16);
+//    C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+//  * Row orders.  A "sequence tile" is 32 independent sequences.  Activations of
+//    a recurrent layer are stored [tile][step][32 seqs][cols] so that one step of
+//    one tile is a contiguous 32-row block:
+//       TA (time axis, reference model.py:72 Permute): seq = b*N + n, step = t
+//       NA (note axis, model.py:119-122):              seq = b*T + t, step = n
+//    row = ((seq>>5)*steps + step)*32 + (seq&31).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define DJ_F32 0
+#define DJ_BF16 1
+
+#define DJ_CHECK(x)                                \
+  do {                                             \
+    hipError_t e_ = (x);                           \
+    if (e_ != hipSuccess) return (int)e_;          \
+  } while (0)
+
+// ---------------------------------------------------------------- conversions
+__device__ __forceinline__ float dj_to_f32(float v) { return v; }
+__device__ __forceinline__ float dj_to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T dj_from_f32(float v);
+template <> __device__ __forceinline__ float dj_from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t dj_from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// ---------------------------------------------------------------- row orders
+__device__ __forceinline__ int64_t dj_row(int seq, int step, int steps) {
+  return ((int64_t)(seq >> 5) * steps + step) * 32 + (seq & 31);
+}
+__device__ __forceinline__ int64_t dj_row_ta(int b, int t, int n, int T, int N) { return dj_row(b * N + n, t, T); }
+__device__ __forceinline__ int64_t dj_row_na(int b, int t, int n, int T, int N) { return dj_row(b * T + t, n, N); }
+
+// C/D fragment row of register r for this lane (32x32 MFMA)
+__device__ __forceinline__ int dj_crow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ---------------------------------------------------------------- dropout hash
+// Counter-based masks, regenerated in backward instead of stored.  Bit-for-bit
+// the same function as oracle/deepj_oracle.py:keep_mask().  Replaces Keras'
+// Dropout layers (reference model.py:58,80,85,116,123,136-138).
+#define DJ_SITE_NOTES 1
+#define DJ_SITE_BEAT 2
+#define DJ_SITE_CHOSEN 3
+#define DJ_SITE_CONV 4
+#define DJ_SITE_TSTYLE 16
+#define DJ_SITE_TOUT 32
+#define DJ_SITE_NSTYLE 48
+#define DJ_SITE_NOUT 64
+
+__host__ __device__ __forceinline__ uint32_t dj_lowbias32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+struct DjDrop {
+  uint32_t key;     // seed ^ site*golden
+  uint32_t thr;     // ceil(p * 2^24); 0 => dropout disabled
+  float scale;      // 1/(1-p)
+};
+__host__ __device__ __forceinline__ uint32_t dj_rowkey(const DjDrop& d, uint32_t row) {
+  return dj_lowbias32(row + d.key);
+}
+// returns the multiplier (0 or 1/(1-p)) for element (row, c)
+__host__ __device__ __forceinline__ float dj_keep(const DjDrop& d, uint32_t rowkey, uint32_t c) {
+  if (d.thr == 0) return 1.0f;
+  uint32_t h = dj_lowbias32(rowkey + c * 0x9E3779B9u);
+  return ((h >> 8) >= d.thr) ? d.scale : 0.0f;
+}
+
+// ---------------------------------------------------------------- activations
+__device__ __forceinline__ float dj_tanh(float x) {
+  // |x| small: odd polynomial (rel err < 1e-8 below 0.04); else 1 - 2/(e^{2x}+1)
+  float ax = fabsf(x);
+  if (ax < 0.04f) {
+    float x2 = x * x;
+    return x * (1.0f + x2 * (-0.33333334f + x2 * 0.13333334f));
+  }
+  float e = __expf(2.0f * ax);
+  float r = 1.0f - 2.0f / (e + 1.0f);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float dj_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// Keras hard_sigmoid = clip(0.2x + 0.5, 0, 1)
+__device__ __forceinline__ float dj_hsig(float x) { return fminf(fmaxf(0.2f * x + 0.5f, 0.0f), 1.0f); }
+__device__ __forceinline__ float dj_hsig_grad(float x) { return (x > -2.5f && x < 2.5f) ? 0.2f : 0.0f; }
+__device__ __forceinline__ float dj_ract(float x, int sigm) { return sigm ? dj_sigmoid(x) : dj_hsig(x); }
+__device__ __forceinline__ float dj_ract_grad(float x, float y, int sigm) {
+  return sigm ? y * (1.0f - y) : dj_hsig_grad(x);
+}
+
+// ---------------------------------------------------------------- MFMA wrappers
+// One "k-chunk" of operand fragments per lane:
+//   float : 4 consecutive k-steps of the 32x32x2 op  -> f32x4  (k = 8 per chunk)
+//   bf16  : one 32x32x16 op                          -> bf16x8 (k = 16 per chunk)
+template <typename T> struct DjFrag;
+template <> struct DjFrag<float> {
+  typedef f32x4 type;
+  static constexpr int KCHUNK = 8;
+};
+template <> struct DjFrag<bf16_t> {
+  typedef bf16x8 type;
+  static constexpr int KCHUNK = 16;
+};
+
+__device__ __forceinline__ void dj_mfma(f32x16& acc, const f32x4& a, const f32x4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+}
+__device__ __forceinline__ void dj_mfma(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+
+// Fragment element -> k index inside a chunk, for lane half h = lane>>5:
+//   float : element e (0..3)  -> k = 4h + e   (the hardware sums over (e, h); which
+//   bf16  : element e (0..7)  -> k = 8h + e    logical k a slot carries is ours to
+//                                              choose as long as A and B agree)
+template <typename T> __device__ __forceinline__ int dj_frag_k(int e, int h);
+template <> __device__ __forceinline__ int dj_frag_k<float>(int e, int h) { return 4 * h + e; }
+template <> __device__ __forceinline__ int dj_frag_k<bf16_t>(int e, int h) { return 8 * h + e; }
+
+// Read an operand fragment from a k-contiguous LDS row: p points at element
+// [row][k0] of a tile whose rows hold k contiguously.
+__device__ __forceinline__ f32x4 dj_lds_frag(const float* p, int h) { return *(const f32x4*)(p + 4 * h); }
+__device__ __forceinline__ bf16x8 dj_lds_frag(const bf16_t* p, int h) { return *(const bf16x8*)(p + 8 * h); }

@@ -1,0 +1,627 @@
+// Non-GEMM kernels of the DeepJ hot path: feature assembly (octave conv + positional
+// features), style projections, inter-layer glue (dropout + style add + axis swap),
+// play/replay/volume head with the masked loss, and the Nadam update.
+// All HBM-bound; every kernel reads each activation once with coalesced rows.
+#include "dj_kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------ small dense (fp32)
+// C[m, n] = act(A[m,:K] . W[:K, n] + b[n])      (reference model.py:141-142 style
+// embedding; model.py:77,110-113 per-layer style Dense followed by tanh)
+__global__ void dense_small_kernel(const float* __restrict__ A, int M, int K, const float* __restrict__ W,
+                                   const float* __restrict__ b, float* __restrict__ C, int N, int act_tanh) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)M * N) return;
+  int m = idx / N, n = idx % N;
+  float s = b ? b[n] : 0.f;
+  for (int k = 0; k < K; ++k) s += A[(int64_t)m * K + k] * W[(int64_t)k * N + n];
+  C[idx] = act_tanh ? dj_tanh(s) : s;
+}
+// dA[m,k] (+)= sum_n dC[m,n] * W[k,n]
+__global__ void dense_small_bwd_x_kernel(const float* __restrict__ dC, int M, int N, const float* __restrict__ W, int K,
+                                         float* __restrict__ dA, int accumulate) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)M * K) return;
+  int m = idx / K, k = idx % K;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += dC[(int64_t)m * N + n] * W[(int64_t)k * N + n];
+  dA[idx] = accumulate ? dA[idx] + s : s;
+}
+// dW[k,n] += sum_m A[m,k] dC[m,n];  db[n] += sum_m dC[m,n].  One block per
+// (row chunk, 64-col strip); thread (kq, n) owns K/4 rows of dW for its column.
+__global__ __launch_bounds__(256) void dense_small_bwd_w_kernel(const float* __restrict__ A, int M, int K,
+                                                                const float* __restrict__ dC, int N,
+                                                                float* __restrict__ dW, float* __restrict__ db,
+                                                                int rows_per_block) {
+  extern __shared__ float sm[];   // As[rows][K]
+  const int tid = threadIdx.x, nl = tid & 63, kq = tid >> 6;
+  const int n = blockIdx.y * 64 + nl;
+  const int m0 = blockIdx.x * rows_per_block;
+  int m1 = m0 + rows_per_block;
+  if (m1 > M) m1 = M;
+  for (int i = tid; i < (m1 - m0) * K; i += 256) sm[i] = A[(int64_t)m0 * K + i];
+  __syncthreads();
+  if (n >= N) return;
+  // K <= 64 in this model (style units); each thread handles k = kq, kq+4, ...
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float bsum = 0.f;
+  for (int m = m0; m < m1; ++m) {
+    float d = dC[(int64_t)m * N + n];
+    bsum += d;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int k = kq + 4 * i;
+      if (k < K) acc[i] += sm[(m - m0) * K + k] * d;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int k = kq + 4 * i;
+    if (k < K) atomicAdd(dW + (int64_t)k * N + n, acc[i]);
+  }
+  if (db && kq == 0) atomicAdd(db + n, bsum);
+}
+
+// ------------------------------------------------------------------ pitch bins (model.py:43-49)
+// bins[i, b, t] = sum_k dropped_notes[b, t, i + 12k, 0]
+__global__ void bins_kernel(const float* __restrict__ notes, float* __restrict__ bins, int B, int T, int N, int octave,
+                            DjDrop dn) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= octave * B * T) return;
+  int i = idx / (B * T), bt = idx % (B * T);
+  float s = 0.f;
+  for (int n = i; n < N; n += octave) {
+    uint32_t r = (uint32_t)bt * N + n;
+    s += notes[(int64_t)r * 3] * dj_keep(dn, dj_rowkey(dn, r), 0);
+  }
+  bins[idx] = s;
+}
+
+// ------------------------------------------------------------------ feature assembly
+
+constexpr int CONV_K = 24, CONV_C = 3, CONV_O = 64, CONV_L = 11;   // 'same': pad 11 left / 12 right
+
+// x0[b,n,t,:] = concat[pos, class, bins, drop(tanh(conv)), drop(beat)] + drop(tanh-style)  (model.py:56-82)
+template <typename T>
+__global__ __launch_bounds__(256) void feature_fwd_kernel(FeatArgs a, T* __restrict__ X) {
+  extern __shared__ float sm[];
+  const int NQ = ((a.N + 3) / 4 + 3) / 4 * 4;   // notes per thread-group, multiple of 4
+  const int XR = NQ * 4 + CONV_K + 3;           // padded note rows in LDS
+  float* xin = sm;                              // [XR][3]
+  const int tid = threadIdx.x, o = tid & 63, ng = tid >> 6;
+  float wreg[CONV_K * CONV_C];
+#pragma unroll
+  for (int i = 0; i < CONV_K * CONV_C; ++i) wreg[i] = a.Wc[i * CONV_O + o];
+  const float bo = a.bc[o];
+  const int conv_col0 = 2 + a.octave;           // 14
+
+  for (int bt = blockIdx.x; bt < a.B * a.T; bt += gridDim.x) {
+    const int b = bt / a.T, t = bt % a.T;
+    __syncthreads();
+    for (int i = tid; i < XR * 3; i += 256) {
+      int n = i / 3 - CONV_L, c = i % 3;
+      float v = 0.f;
+      if (n >= 0 && n < a.N) {
+        uint32_t r = (uint32_t)bt * a.N + n;
+        v = a.notes[(int64_t)r * 3 + c] * dj_keep(a.d_notes, dj_rowkey(a.d_notes, r), c);
+      }
+      xin[i] = v;
+    }
+    __syncthreads();
+    // octave conv: thread (o, ng) -> notes [ng*NQ, (ng+1)*NQ) in groups of 4
+    for (int nb = ng * NQ; nb < (ng + 1) * NQ && nb < a.N; nb += 4) {
+      float acc[4] = {bo, bo, bo, bo};
+#pragma unroll
+      for (int kk = 0; kk < CONV_K + 3; ++kk)
+#pragma unroll
+        for (int c = 0; c < CONV_C; ++c) {
+          float xv = xin[(nb + kk) * 3 + c];
+#pragma unroll
+          for (int dn = 0; dn < 4; ++dn) {
+            int k = kk - dn;
+            if (k >= 0 && k < CONV_K) acc[dn] += xv * wreg[k * CONV_C + c];
+          }
+        }
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) {
+        int n = nb + dn;
+        if (n < a.N) {
+          uint32_t r = (uint32_t)bt * a.N + n;
+          int col = conv_col0 + o;
+          float v = dj_tanh(acc[dn]) * dj_keep(a.d_conv, dj_rowkey(a.d_conv, r), o);
+          v += a.sp0[(int64_t)bt * a.F + col] * dj_keep(a.d_style, dj_rowkey(a.d_style, r), col);
+          X[dj_row_ta(b, t, n, a.T, a.N) * a.FP + col] = dj_from_f32<T>(v);
+        }
+      }
+    }
+    // the remaining columns: [0, 14) and [14+64, FP)
+    const int nrest = a.FP - CONV_O;
+    for (int i = tid; i < a.N * nrest; i += 256) {
+      int n = i / nrest, q = i % nrest;
+      int col = q < conv_col0 ? q : q + CONV_O;
+      uint32_t r = (uint32_t)bt * a.N + n;
+      float v = 0.f;
+      if (col == 0) {
+        v = (float)n / (float)a.N;                               // model.py:22-30
+      } else if (col <= a.octave) {
+        v = ((n % a.octave) == col - 1) ? 1.f : 0.f;             // model.py:32-41
+      } else if (col == a.octave + 1) {                          // model.py:43-49 raw-reshape quirk
+        int64_t f = (int64_t)r, bT = (int64_t)a.B * a.T;
+        v = a.bins[((f / bT) % a.octave) * bT + (f % bT)];
+      } else if (col < a.F) {                                    // beat, model.py:66
+        int j = col - conv_col0 - CONV_O;
+        v = a.beat[(int64_t)bt * a.NB + j] * dj_keep(a.d_beat, dj_rowkey(a.d_beat, bt), j);
+      }
+      if (col < a.F) v += a.sp0[(int64_t)bt * a.F + col] * dj_keep(a.d_style, dj_rowkey(a.d_style, r), col);
+      X[dj_row_ta(b, t, n, a.T, a.N) * a.FP + col] = dj_from_f32<T>(v);
+    }
+  }
+}
+
+// backward of the above: conv kernel/bias gradients and the style-projection gradient
+template <typename T>
+__global__ __launch_bounds__(256) void feature_bwd_kernel(FeatArgs a, const T* __restrict__ dX,
+                                                          float* __restrict__ dWc, float* __restrict__ dbc,
+                                                          float* __restrict__ dpre0) {
+  extern __shared__ float sm[];
+  const int NQ = ((a.N + 3) / 4 + 3) / 4 * 4;
+  const int XR = NQ * 4 + CONV_K + 3;
+  float* xin = sm;                 // [XR][3]
+  float* red = sm + XR * 3;        // [2][FP] partial style sums, later [4][64] reduction scratch
+  const int tid = threadIdx.x, o = tid & 63, ng = tid >> 6;
+  float wreg[CONV_K * CONV_C], dwreg[CONV_K * CONV_C];
+#pragma unroll
+  for (int i = 0; i < CONV_K * CONV_C; ++i) {
+    wreg[i] = a.Wc[i * CONV_O + o];
+    dwreg[i] = 0.f;
+  }
+  const float bo = a.bc[o];
+  float dbo = 0.f;
+  const int conv_col0 = 2 + a.octave;
+
+  for (int bt = blockIdx.x; bt < a.B * a.T; bt += gridDim.x) {
+    const int b = bt / a.T, t = bt % a.T;
+    __syncthreads();
+    for (int i = tid; i < XR * 3; i += 256) {
+      int n = i / 3 - CONV_L, c = i % 3;
+      float v = 0.f;
+      if (n >= 0 && n < a.N) {
+        uint32_t r = (uint32_t)bt * a.N + n;
+        v = a.notes[(int64_t)r * 3 + c] * dj_keep(a.d_notes, dj_rowkey(a.d_notes, r), c);
+      }
+      xin[i] = v;
+    }
+    __syncthreads();
+    // style gradient: dpre0[bt, d] = (sum_n dX[b,n,t,d] * keep) * (1 - sp^2); two n-halves
+    {
+      int d = tid % 128, part = tid / 128;
+      float s = 0.f;
+      if (d < a.F) {
+        int nh = (a.N + 1) / 2;
+        for (int n = part * nh; n < (part + 1) * nh && n < a.N; ++n) {
+          uint32_t r = (uint32_t)bt * a.N + n;
+          s += dj_to_f32(dX[dj_row_ta(b, t, n, a.T, a.N) * a.FP + d]) * dj_keep(a.d_style, dj_rowkey(a.d_style, r), d);
+        }
+        red[part * 128 + d] = s;
+      }
+    }
+    __syncthreads();
+    if (tid < a.F) {
+      float sp = a.sp0[(int64_t)bt * a.F + tid];
+      dpre0[(int64_t)bt * a.F + tid] = (red[tid] + red[128 + tid]) * (1.f - sp * sp);
+    }
+    // conv gradients
+    for (int nb = ng * NQ; nb < (ng + 1) * NQ && nb < a.N; nb += 4) {
+      float acc[4] = {bo, bo, bo, bo};
+#pragma unroll
+      for (int kk = 0; kk < CONV_K + 3; ++kk)
+#pragma unroll
+        for (int c = 0; c < CONV_C; ++c) {
+          float xv = xin[(nb + kk) * 3 + c];
+#pragma unroll
+          for (int dn = 0; dn < 4; ++dn) {
+            int k = kk - dn;
+            if (k >= 0 && k < CONV_K) acc[dn] += xv * wreg[k * CONV_C + c];
+          }
+        }
+      float g[4];
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) {
+        int n = nb + dn;
+        g[dn] = 0.f;
+        if (n < a.N) {
+          uint32_t r = (uint32_t)bt * a.N + n;
+          float y = dj_tanh(acc[dn]);
+          float up = dj_to_f32(dX[dj_row_ta(b, t, n, a.T, a.N) * a.FP + conv_col0 + o]);
+          g[dn] = up * dj_keep(a.d_conv, dj_rowkey(a.d_conv, r), o) * (1.f - y * y);
+        }
+        dbo += g[dn];
+      }
+#pragma unroll
+      for (int kk = 0; kk < CONV_K + 3; ++kk)
+#pragma unroll
+        for (int c = 0; c < CONV_C; ++c) {
+          float xv = xin[(nb + kk) * 3 + c];
+#pragma unroll
+          for (int dn = 0; dn < 4; ++dn) {
+            int k = kk - dn;
+            if (k >= 0 && k < CONV_K) dwreg[k * CONV_C + c] += xv * g[dn];
+          }
+        }
+    }
+  }
+  // reduce the 4 note-groups through LDS, then one atomic per (k,c,o) per workgroup
+  __syncthreads();
+  float* r4 = sm;   // [4][64] reuse
+  for (int i = 0; i <= CONV_K * CONV_C; ++i) {
+    float v = (i < CONV_K * CONV_C) ? dwreg[0] : dbo;
+    // rotate registers so that dwreg[0] is always the next one (keeps indexing static)
+#pragma unroll
+    for (int q = 0; q + 1 < CONV_K * CONV_C; ++q) dwreg[q] = dwreg[q + 1];
+    r4[ng * 64 + o] = v;
+    __syncthreads();
+    if (ng == 0) {
+      float s = r4[o] + r4[64 + o] + r4[128 + o] + r4[192 + o];
+      if (i < CONV_K * CONV_C)
+        atomicAdd(dWc + i * CONV_O + o, s);
+      else
+        atomicAdd(dbc + o, s);
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ inter-layer glue
+
+// x_next = concat[drop(h), shift(drop(chosen))] + drop(tanh-style)   (model.py:85,77-82 / 101-117)
+template <typename T>
+__global__ void glue_fwd_kernel(GlueArgs a, const T* __restrict__ Hin, T* __restrict__ X) {
+  const int chunks = a.DP / 8;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)a.B * a.T * a.N * chunks) return;
+  const int ch = idx % chunks;
+  const uint32_t r = (uint32_t)(idx / chunks);
+  const int n = r % a.N, bt = r / a.N, t = bt % a.T, b = bt / a.T;
+  const int64_t rin = a.in_na ? dj_row_na(b, t, n, a.T, a.N) : dj_row_ta(b, t, n, a.T, a.N);
+  const int64_t rout = a.out_na ? dj_row_na(b, t, n, a.T, a.N) : dj_row_ta(b, t, n, a.T, a.N);
+  const uint32_t ko = dj_rowkey(a.d_out, r), ks = dj_rowkey(a.d_style, r);
+  T outv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int d = ch * 8 + e;
+    float v = 0.f;
+    if (d < a.Hd) {
+      v = dj_to_f32(Hin[rin * a.Hd + d]) * dj_keep(a.d_out, ko, d);
+    } else if (a.chosen && d < a.Hd + 3 && n > 0) {
+      v = a.chosen[(int64_t)(r - 1) * 3 + (d - a.Hd)] * dj_keep(a.d_chosen, dj_rowkey(a.d_chosen, r - 1), d - a.Hd);
+    }
+    if (a.sp && d < a.D) v += a.sp[(int64_t)bt * a.D + d] * dj_keep(a.d_style, ks, d);
+    if (d >= a.D) v = 0.f;
+    outv[e] = dj_from_f32<T>(v);
+  }
+  T* dst = X + rout * a.DP + ch * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dst[e] = outv[e];
+}
+
+// backward: dH = dX * keep_out ; dpre[bt,d] = (sum_n dX * keep_style) * (1 - sp^2)
+template <typename T>
+__global__ void glue_bwd_kernel(GlueArgs a, const T* __restrict__ dX, T* __restrict__ dH, float* __restrict__ dpre) {
+  const int bt = blockIdx.x, t = bt % a.T, b = bt / a.T;
+  for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
+    float s = 0.f;
+    for (int n = 0; n < a.N; ++n) {
+      const uint32_t r = (uint32_t)bt * a.N + n;
+      const int64_t rin = a.in_na ? dj_row_na(b, t, n, a.T, a.N) : dj_row_ta(b, t, n, a.T, a.N);
+      const int64_t rout = a.out_na ? dj_row_na(b, t, n, a.T, a.N) : dj_row_ta(b, t, n, a.T, a.N);
+      float v = dj_to_f32(dX[rout * a.DP + d]);
+      if (a.sp) s += v * dj_keep(a.d_style, dj_rowkey(a.d_style, r), d);
+      if (d < a.Hd) dH[rin * a.Hd + d] = dj_from_f32<T>(v * dj_keep(a.d_out, dj_rowkey(a.d_out, r), d));
+    }
+    if (a.sp) {
+      float sp = a.sp[(int64_t)bt * a.D + d];
+      dpre[(int64_t)bt * a.D + d] = s * (1.f - sp * sp);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ head + loss
+
+__device__ __forceinline__ float bce_clip(float t, float p, float& pc, bool& inr) {
+  // Keras/TF1 binary_crossentropy on probabilities
+  const float eps = 1e-7f;
+  inr = (p >= eps) && (p <= 1.f - eps);
+  pc = fminf(fmaxf(p, eps), 1.f - eps);
+  float l = logf(pc / (1.f - pc));
+  return fmaxf(l, 0.f) - l * t + log1pf(expf(-fabsf(l)));
+}
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void head_loss_kernel(HeadArgs a, const T* __restrict__ Hn, T* __restrict__ dH) {
+  constexpr int PER = HD / 64;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  float w0[PER], w1[PER], w2[PER], g0[PER], g1[PER], g2[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    int d = lane + 64 * i;
+    w0[i] = a.Wn[d * 2];
+    w1[i] = a.Wn[d * 2 + 1];
+    w2[i] = a.Wv[d];
+    g0[i] = g1[i] = g2[i] = 0.f;
+  }
+  const float b0 = a.bn[0], b1 = a.bn[1], b2 = a.bv[0];
+  float gb0 = 0.f, gb1 = 0.f, gb2 = 0.f, lsum = 0.f;
+  const int64_t rows = (int64_t)a.B * a.T * a.N;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const int n = r % a.N, bt = r / a.N, t = bt % a.T, b = bt / a.T;
+    const int64_t row = dj_row_na(b, t, n, a.T, a.N);
+    const uint32_t rk = dj_rowkey(a.d_out, (uint32_t)r);
+    float x[PER], kp[PER];
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int d = lane + 64 * i;
+      kp[i] = dj_keep(a.d_out, rk, d);
+      x[i] = dj_to_f32(Hn[row * HD + d]) * kp[i];
+      l0 += x[i] * w0[i];
+      l1 += x[i] * w1[i];
+      l2 += x[i] * w2[i];
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+      l0 += __shfl_xor(l0, s);
+      l1 += __shfl_xor(l1, s);
+      l2 += __shfl_xor(l2, s);
+    }
+    l0 += b0;
+    l1 += b1;
+    l2 += b2;
+    const float p0 = dj_sigmoid(l0), p1 = dj_sigmoid(l1);
+    if (a.out && lane == 0) {
+      a.out[r * 3] = p0;
+      a.out[r * 3 + 1] = p1;
+      a.out[r * 3 + 2] = l2;
+    }
+    if (!a.target) continue;
+    const float t0 = a.target[r * 3], t1 = a.target[r * 3 + 1], t2 = a.target[r * 3 + 2];
+    const float played = t0;
+    float pc;
+    bool inr;
+    float L = bce_clip(t0, p0, pc, inr);
+    float d0 = inr ? (p0 - t0) : 0.f;
+    const float pe = played * p1 + (1.f - played) * t1;
+    L += bce_clip(t1, pe, pc, inr);
+    float d1 = inr ? (pc - t1) / (pc * (1.f - pc)) * played * p1 * (1.f - p1) : 0.f;
+    const float ve = played * l2 + (1.f - played) * t2;
+    const float diff = t2 - ve;
+    L += diff * diff;
+    float d2 = -2.f * diff * played;
+    d0 *= a.inv_count;
+    d1 *= a.inv_count;
+    d2 *= a.inv_count;
+    lsum += L;
+    gb0 += d0;
+    gb1 += d1;
+    gb2 += d2;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int d = lane + 64 * i;
+      g0[i] += x[i] * d0;
+      g1[i] += x[i] * d1;
+      g2[i] += x[i] * d2;
+      if (dH) dH[row * HD + d] = dj_from_f32<T>((d0 * w0[i] + d1 * w1[i] + d2 * w2[i]) * kp[i]);
+    }
+  }
+  if (!a.target) return;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    int d = lane + 64 * i;
+    atomicAdd(a.dWn + d * 2, g0[i]);
+    atomicAdd(a.dWn + d * 2 + 1, g1[i]);
+    atomicAdd(a.dWv + d, g2[i]);
+  }
+  if (lane == 0) {
+    atomicAdd(a.dbn, gb0);
+    atomicAdd(a.dbn + 1, gb1);
+    atomicAdd(a.dbv, gb2);
+    if (a.loss) atomicAdd(a.loss, lsum * a.inv_count);
+  }
+}
+
+// ------------------------------------------------------------------ weight conversion
+// out[n*ld + k] = (k < K) ? W[k*N + n] : 0     (Keras [in,out] -> k-contiguous Bt for dj_gemm_nt)
+template <typename T>
+__global__ void cvt_transpose_kernel(const float* __restrict__ W, int K, int N, T* __restrict__ out, int ld) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * ld) return;
+  int n = idx / ld, k = idx % ld;
+  out[idx] = dj_from_f32<T>(k < K ? W[(int64_t)k * N + n] : 0.f);
+}
+template <typename T> __global__ void cvt_copy_kernel(const float* __restrict__ W, int64_t n, T* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) out[idx] = dj_from_f32<T>(W[idx]);
+}
+template <typename T> __global__ void cvt_to_f32_kernel(const T* __restrict__ in, int64_t n, float* __restrict__ out) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) out[idx] = dj_to_f32(in[idx]);
+}
+
+// ------------------------------------------------------------------ Nadam (Keras 2.x, model.py:152)
+__global__ void nadam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n, NadamArgs a) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float gi = g[i] * a.gscale;
+  float gp = gi / (1.f - a.ms_new);
+  float mt = a.beta1 * m[i] + (1.f - a.beta1) * gi;
+  float mp = mt / (1.f - a.ms_next);
+  float vt = a.beta2 * v[i] + (1.f - a.beta2) * gi * gi;
+  float vp = vt / a.bc2;
+  float mbar = (1.f - a.mu_t) * gp + a.mu_t1 * mp;
+  m[i] = mt;
+  v[i] = vt;
+  p[i] = p[i] - a.lr * mbar / (sqrtf(vp) + a.eps);
+}
+
+// scatter h from TA row order to the canonical [B,T,N,H] fp32 layout (time_model.predict output)
+template <typename T>
+__global__ void ta_to_canonical_kernel(const T* __restrict__ Hin, float* __restrict__ out, int B, int T_, int N,
+                                       int Hd) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * T_ * N * Hd) return;
+  int d = idx % Hd;
+  int64_t r = idx / Hd;
+  int n = r % N, bt = r / N, t = bt % T_, b = bt / T_;
+  out[idx] = dj_to_f32(Hin[dj_row_ta(b, t, n, T_, N) * Hd + d]);
+}
+// canonical fp32 [B,T,N,Hd] features -> NA row order operand buffer (note_model.predict input)
+template <typename T>
+__global__ void canonical_to_na_kernel(const float* __restrict__ in, T* __restrict__ out, int B, int T_, int N,
+                                       int Hd) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * T_ * N * Hd) return;
+  int d = idx % Hd;
+  int64_t r = idx / Hd;
+  int n = r % N, bt = r / N, t = bt % T_, b = bt / T_;
+  out[dj_row_na(b, t, n, T_, N) * Hd + d] = dj_from_f32<T>(in[idx]);
+}
+
+inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+}  // namespace
+
+// ------------------------------------------------------------------ launchers
+#define DJ_T_DISPATCH(expr_f32, expr_bf16) \
+  if (dtype == DJ_F32) { expr_f32; } else { expr_bf16; }
+
+int dj_launch_dense_small(const float* A, int M, int K, const float* W, const float* b, float* C, int N, int act_tanh,
+                          hipStream_t st) {
+  hipLaunchKernelGGL(dense_small_kernel, dim3(nblk((int64_t)M * N)), dim3(256), 0, st, A, M, K, W, b, C, N, act_tanh);
+  return (int)hipGetLastError();
+}
+int dj_launch_dense_small_bwd_x(const float* dC, int M, int N, const float* W, int K, float* dA, int accumulate,
+                                hipStream_t st) {
+  hipLaunchKernelGGL(dense_small_bwd_x_kernel, dim3(nblk((int64_t)M * K)), dim3(256), 0, st, dC, M, N, W, K, dA,
+                     accumulate);
+  return (int)hipGetLastError();
+}
+int dj_launch_dense_small_bwd_w(const float* A, int M, int K, const float* dC, int N, float* dW, float* db,
+                                hipStream_t st) {
+  if (K > 64) return 1020;
+  const int rpb = 128;
+  dim3 grid((M + rpb - 1) / rpb, (N + 63) / 64);
+  hipLaunchKernelGGL(dense_small_bwd_w_kernel, grid, dim3(256), (size_t)rpb * K * sizeof(float), st, A, M, K, dC, N, dW,
+                     db, rpb);
+  return (int)hipGetLastError();
+}
+int dj_launch_bins(const float* notes, float* bins, int B, int T, int N, int octave, DjDrop dn, hipStream_t st) {
+  hipLaunchKernelGGL(bins_kernel, dim3(nblk((int64_t)octave * B * T)), dim3(256), 0, st, notes, bins, B, T, N, octave,
+                     dn);
+  return (int)hipGetLastError();
+}
+static size_t feat_smem(int N) {
+  int NQ = ((N + 3) / 4 + 3) / 4 * 4;
+  int XR = NQ * 4 + CONV_K + 3;
+  return (size_t)(XR * 3 + 256) * sizeof(float);
+}
+int dj_launch_feature_fwd(int dtype, const void* fa, void* X, hipStream_t st) {
+  const FeatArgs& a = *(const FeatArgs*)fa;
+  if (a.FP - CONV_O > 64 || a.FP % 8) return 1021;
+  int grid = a.B * a.T < 2048 ? a.B * a.T : 2048;
+  DJ_T_DISPATCH(hipLaunchKernelGGL(feature_fwd_kernel<float>, dim3(grid), dim3(256), feat_smem(a.N), st, a, (float*)X),
+                hipLaunchKernelGGL(feature_fwd_kernel<bf16_t>, dim3(grid), dim3(256), feat_smem(a.N), st, a,
+                                   (bf16_t*)X))
+  return (int)hipGetLastError();
+}
+int dj_launch_feature_bwd(int dtype, const void* fa, const void* dX, float* dWc, float* dbc, float* dpre0,
+                          hipStream_t st) {
+  const FeatArgs& a = *(const FeatArgs*)fa;
+  if (a.F > 128) return 1022;
+  int grid = a.B * a.T < 512 ? a.B * a.T : 512;
+  DJ_T_DISPATCH(hipLaunchKernelGGL(feature_bwd_kernel<float>, dim3(grid), dim3(256), feat_smem(a.N), st, a,
+                                   (const float*)dX, dWc, dbc, dpre0),
+                hipLaunchKernelGGL(feature_bwd_kernel<bf16_t>, dim3(grid), dim3(256), feat_smem(a.N), st, a,
+                                   (const bf16_t*)dX, dWc, dbc, dpre0))
+  return (int)hipGetLastError();
+}
+int dj_launch_glue_fwd(int dtype, const void* ga, const void* Hin, void* X, hipStream_t st) {
+  const GlueArgs& a = *(const GlueArgs*)ga;
+  if (a.DP % 8) return 1023;
+  int64_t n = (int64_t)a.B * a.T * a.N * (a.DP / 8);
+  DJ_T_DISPATCH(hipLaunchKernelGGL(glue_fwd_kernel<float>, dim3(nblk(n)), dim3(256), 0, st, a, (const float*)Hin,
+                                   (float*)X),
+                hipLaunchKernelGGL(glue_fwd_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, st, a, (const bf16_t*)Hin,
+                                   (bf16_t*)X))
+  return (int)hipGetLastError();
+}
+int dj_launch_glue_bwd(int dtype, const void* ga, const void* dX, void* dH, float* dpre, hipStream_t st) {
+  const GlueArgs& a = *(const GlueArgs*)ga;
+  DJ_T_DISPATCH(hipLaunchKernelGGL(glue_bwd_kernel<float>, dim3(a.B * a.T), dim3(256), 0, st, a, (const float*)dX,
+                                   (float*)dH, dpre),
+                hipLaunchKernelGGL(glue_bwd_kernel<bf16_t>, dim3(a.B * a.T), dim3(256), 0, st, a, (const bf16_t*)dX,
+                                   (bf16_t*)dH, dpre))
+  return (int)hipGetLastError();
+}
+int dj_launch_head(int dtype, const void* ha, const void* Hn, void* dH, hipStream_t st) {
+  const HeadArgs& a = *(const HeadArgs*)ha;
+  int64_t rows = (int64_t)a.B * a.T * a.N;
+  int grid = (int)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
+  if (a.Hd == 128) {
+    DJ_T_DISPATCH(hipLaunchKernelGGL((head_loss_kernel<float, 128>), dim3(grid), dim3(256), 0, st, a, (const float*)Hn,
+                                     (float*)dH),
+                  hipLaunchKernelGGL((head_loss_kernel<bf16_t, 128>), dim3(grid), dim3(256), 0, st, a,
+                                     (const bf16_t*)Hn, (bf16_t*)dH))
+  } else if (a.Hd == 256) {
+    DJ_T_DISPATCH(hipLaunchKernelGGL((head_loss_kernel<float, 256>), dim3(grid), dim3(256), 0, st, a, (const float*)Hn,
+                                     (float*)dH),
+                  hipLaunchKernelGGL((head_loss_kernel<bf16_t, 256>), dim3(grid), dim3(256), 0, st, a,
+                                     (const bf16_t*)Hn, (bf16_t*)dH))
+  } else {
+    return 1024;
+  }
+  return (int)hipGetLastError();
+}
+int dj_launch_cvt_transpose(int dtype, const float* W, int K, int N, void* out, int ld, hipStream_t st) {
+  int64_t n = (int64_t)N * ld;
+  DJ_T_DISPATCH(hipLaunchKernelGGL(cvt_transpose_kernel<float>, dim3(nblk(n)), dim3(256), 0, st, W, K, N, (float*)out,
+                                   ld),
+                hipLaunchKernelGGL(cvt_transpose_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, st, W, K, N,
+                                   (bf16_t*)out, ld))
+  return (int)hipGetLastError();
+}
+int dj_launch_cvt_copy(int dtype, const float* W, int64_t n, void* out, hipStream_t st) {
+  DJ_T_DISPATCH(hipLaunchKernelGGL(cvt_copy_kernel<float>, dim3(nblk(n)), dim3(256), 0, st, W, n, (float*)out),
+                hipLaunchKernelGGL(cvt_copy_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, st, W, n, (bf16_t*)out))
+  return (int)hipGetLastError();
+}
+int dj_launch_cvt_to_f32(int dtype, const void* in, int64_t n, float* out, hipStream_t st) {
+  DJ_T_DISPATCH(hipLaunchKernelGGL(cvt_to_f32_kernel<float>, dim3(nblk(n)), dim3(256), 0, st, (const float*)in, n, out),
+                hipLaunchKernelGGL(cvt_to_f32_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, st, (const bf16_t*)in, n,
+                                   out))
+  return (int)hipGetLastError();
+}
+int dj_launch_nadam(float* p, const float* g, float* m, float* v, int64_t n, const void* na, hipStream_t st) {
+  hipLaunchKernelGGL(nadam_kernel, dim3(nblk(n)), dim3(256), 0, st, p, g, m, v, n, *(const NadamArgs*)na);
+  return (int)hipGetLastError();
+}
+int dj_launch_ta_to_canonical(int dtype, const void* Hin, float* out, int B, int T, int N, int Hd, hipStream_t st) {
+  int64_t n = (int64_t)B * T * N * Hd;
+  DJ_T_DISPATCH(hipLaunchKernelGGL(ta_to_canonical_kernel<float>, dim3(nblk(n)), dim3(256), 0, st, (const float*)Hin,
+                                   out, B, T, N, Hd),
+                hipLaunchKernelGGL(ta_to_canonical_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, st, (const bf16_t*)Hin,
+                                   out, B, T, N, Hd))
+  return (int)hipGetLastError();
+}
+int dj_launch_canonical_to_na(int dtype, const float* in, void* out, int B, int T, int N, int Hd, hipStream_t st) {
+  int64_t n = (int64_t)B * T * N * Hd;
+  DJ_T_DISPATCH(hipLaunchKernelGGL(canonical_to_na_kernel<float>, dim3(nblk(n)), dim3(256), 0, st, in, (float*)out, B,
+                                   T, N, Hd),
+                hipLaunchKernelGGL(canonical_to_na_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, st, in, (bf16_t*)out,
+                                   B, T, N, Hd))
+  return (int)hipGetLastError();
+}

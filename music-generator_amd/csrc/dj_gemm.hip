@@ -1,0 +1,361 @@
+// Dense contractions of the DeepJ hot path on the MI355X matrix cores.
+//
+//  dj_gemm_nt : C[M,N]  = A[M,K] * Bt[N,K]^T (+ bias)     -- input-to-hidden projections
+//               x*W of every LSTM layer (reference model.py:84,122, Keras LSTM kernel) and
+//               the input gradient dX = dZ * W^T of BPTT.
+//  dj_gemm_tn : C[Ka,N] += A[M,Ka]^T * B[M,N]  (fp32 atomics, split over M)
+//               -- weight gradients dW = X^T dZ, dU = Hprev^T dZ of BPTT (TF autodiff
+//               of model.py:84,122 in the reference).
+//
+// 128x128 output tile per 256-thread workgroup, 2x2 waves, each wave 2x2 MFMA
+// 32x32 tiles.  Operand tiles are staged global -> registers -> LDS with the next
+// tile's global loads in flight during the MFMAs (register-staged pipeline).
+// LDS rows hold k contiguously with a 16-byte pad: 144-byte row stride makes the
+// ds_read_b128 fragment reads bank-conflict free (MI355X_MICROARCH LDS table).
+#include "dj_kernels.h"
+
+namespace {
+
+template <typename T> struct Vec16 { uint4 v; };
+
+template <typename T> struct GemmCfg {
+  static constexpr int EPL = 16 / sizeof(T);   // elements per 16-byte lane vector
+  static constexpr int BK = 8 * EPL;           // k elements per LDS tile (f32: 32, bf16: 64)
+  static constexpr int LDT = BK + EPL;         // padded LDS row stride in elements (144 B)
+  static constexpr int KC = 2 * EPL;           // k per MFMA chunk
+  static constexpr int NCH = BK / KC;          // chunks per tile (4)
+};
+
+__device__ __forceinline__ uint4 ldg16(const void* p) { return *(const uint4*)p; }
+
+template <typename T>
+__device__ __forceinline__ void mma_tile(const T* As, const T* Bs, f32x16 (&acc)[2][2], int wr, int wc, int lane) {
+  using G = GemmCfg<T>;
+  using Frag = typename DjFrag<T>::type;
+  const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int kc = 0; kc < G::NCH; ++kc) {
+    Frag a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      a[i] = dj_lds_frag(As + (wr * 64 + i * 32 + l31) * G::LDT + kc * G::KC, h);
+      b[i] = dj_lds_frag(Bs + (wc * 64 + i * 32 + l31) * G::LDT + kc * G::KC, h);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) dj_mfma(acc[i][j], a[i], b[j]);
+  }
+}
+
+// ------------------------------------------------------------------ NT
+template <typename T, typename TC>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const T* __restrict__ A, int lda,
+                                                      const T* __restrict__ Bt, int ldb, TC* __restrict__ C, int ldc,
+                                                      const float* __restrict__ bias, int ntn) {
+  using G = GemmCfg<T>;
+  __shared__ __attribute__((aligned(16))) T As[128 * G::LDT];
+  __shared__ __attribute__((aligned(16))) T Bs[128 * G::LDT];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+  const int n0 = (blockIdx.x % ntn) * 128;
+  const int m0 = (blockIdx.x / ntn) * 128;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 ra[4], rb[4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int vid = tid + 256 * i;
+      int row = vid >> 3, kv = (vid & 7) * G::EPL;
+      uint4 z = make_uint4(0, 0, 0, 0);
+      bool kin = (k0 + kv) < K;
+      ra[i] = (kin && (m0 + row) < M) ? ldg16(A + (int64_t)(m0 + row) * lda + k0 + kv) : z;
+      rb[i] = (kin && (n0 + row) < N) ? ldg16(Bt + (int64_t)(n0 + row) * ldb + k0 + kv) : z;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int vid = tid + 256 * i;
+      int row = vid >> 3, kv = (vid & 7) * G::EPL;
+      *(uint4*)(As + row * G::LDT + kv) = ra[i];
+      *(uint4*)(Bs + row * G::LDT + kv) = rb[i];
+    }
+  };
+
+  const int nk = (K + G::BK - 1) / G::BK;
+  gload(0);
+  lstore();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload((kt + 1) * G::BK);
+    mma_tile<T>(As, Bs, acc, wr, wc, lane);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      lstore();
+      __syncthreads();
+    }
+  }
+
+  const int l31 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int col = n0 + wc * 64 + j * 32 + l31;
+      if (col >= N) continue;
+      float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = m0 + wr * 64 + i * 32 + dj_crow(r, lane);
+        if (row < M) C[(int64_t)row * ldc + col] = dj_from_f32<TC>(acc[i][j][r] + bv);
+      }
+    }
+}
+
+// ------------------------------------------------------------------ TN
+// A row remap for the recurrent-weight gradient: a_shift = 32 makes row m read
+// row m-32 (the previous step of the same sequence tile), zeros at step 0.
+__device__ __forceinline__ bool tn_a_row(int64_t m, int a_shift, int steps, int64_t& src) {
+  if (a_shift == 0) {
+    src = m;
+    return true;
+  }
+  if (((m >> 5) % steps) == 0) return false;
+  src = m - a_shift;
+  return true;
+}
+
+// fp32: LDS tiles are k-major [BK][128] (no transpose on the way in); a fragment is
+// four conflict-free ds_read_b32.
+__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(int64_t M, int Ka, int N, const float* __restrict__ A, int lda,
+                                                          const float* __restrict__ B, int ldb, float* __restrict__ C,
+                                                          int ldc, int ntn, int ntiles, int64_t rows_per_split,
+                                                          int a_shift, int steps, int ka_valid) {
+  constexpr int BK = 32, LD = 128;
+  __shared__ __attribute__((aligned(16))) float As[BK * LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+  const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+  const int n0 = (tile % ntn) * 128, i0 = (tile / ntn) * 128;
+  const int64_t ms = (int64_t)split * rows_per_split;
+  int64_t me = ms + rows_per_split;
+  if (me > M) me = M;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  uint4 ra[4], rb[4];
+  auto gload = [&](int64_t mt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int vid = tid + 256 * i;
+      int kr = vid >> 5, cv = (vid & 31) * 4;
+      int64_t m = mt + kr, src;
+      uint4 z = make_uint4(0, 0, 0, 0);
+      bool min = m < me;
+      ra[i] = (min && (i0 + cv) < Ka && tn_a_row(m, a_shift, steps, src)) ? ldg16(A + src * lda + i0 + cv) : z;
+      rb[i] = (min && (n0 + cv) < N) ? ldg16(B + m * ldb + n0 + cv) : z;
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int vid = tid + 256 * i;
+      int kr = vid >> 5, cv = (vid & 31) * 4;
+      *(uint4*)(As + kr * LD + cv) = ra[i];
+      *(uint4*)(Bs + kr * LD + cv) = rb[i];
+    }
+  };
+  const int h = lane >> 5, l31 = lane & 31;
+  if (ms < me) {
+    gload(ms);
+    lstore();
+    __syncthreads();
+    for (int64_t mt = ms; mt < me; mt += BK) {
+      bool more = (mt + BK) < me;
+      if (more) gload(mt + BK);
+#pragma unroll
+      for (int kc = 0; kc < BK / 8; ++kc) {
+        f32x4 a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            int k = kc * 8 + 4 * h + e;
+            a[i][e] = As[k * LD + wr * 64 + i * 32 + l31];
+            b[i][e] = Bs[k * LD + wc * 64 + i * 32 + l31];
+          }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) dj_mfma(acc[i][j], a[i], b[j]);
+      }
+      __syncthreads();
+      if (more) {
+        lstore();
+        __syncthreads();
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int col = n0 + wc * 64 + j * 32 + l31;
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = i0 + wr * 64 + i * 32 + dj_crow(r, lane);
+        if (row < ka_valid) atomicAdd(C + (int64_t)row * ldc + col, acc[i][j][r]);
+      }
+    }
+}
+
+// bf16: each thread transposes an 8(k) x 8(col) block in registers so the LDS tiles
+// are k-contiguous and fragments are single ds_read_b128.
+__device__ __forceinline__ void transpose8x8_b16(const uint4 (&r)[8], uint4 (&o)[8]) {
+  const uint32_t* rin = (const uint32_t*)&r[0];   // rin[row*4 + d]
+  uint32_t* out = (uint32_t*)&o[0];               // out[col*4 + q]
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t lo = rin[(2 * q) * 4 + (c >> 1)], hi = rin[(2 * q + 1) * 4 + (c >> 1)];
+      out[c * 4 + q] = (c & 1) ? ((lo >> 16) | (hi & 0xFFFF0000u)) : ((lo & 0xFFFFu) | (hi << 16));
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(int64_t M, int Ka, int N, const bf16_t* __restrict__ A,
+                                                           int lda, const bf16_t* __restrict__ B, int ldb,
+                                                           float* __restrict__ C, int ldc, int ntn, int ntiles,
+                                                           int64_t rows_per_split, int a_shift, int steps,
+                                                           int ka_valid) {
+  using G = GemmCfg<bf16_t>;   // BK = 64 rows of M per tile
+  __shared__ __attribute__((aligned(16))) bf16_t As[128 * G::LDT];
+  __shared__ __attribute__((aligned(16))) bf16_t Bs[128 * G::LDT];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+  const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+  const int n0 = (tile % ntn) * 128, i0 = (tile / ntn) * 128;
+  const int64_t ms = (int64_t)split * rows_per_split;
+  int64_t me = ms + rows_per_split;
+  if (me > M) me = M;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // threads 0..127 stage A blocks, 128..255 stage B blocks; block = 8 k-rows x 8 cols
+  const bool isA = tid < 128;
+  const int q = tid & 127, kb = q >> 4, cb = q & 15;
+  uint4 rg[8];
+  auto gload = [&](int64_t mt) {
+    const int c0 = (isA ? i0 : n0) + cb * 8;
+    const bool cin = c0 < (isA ? Ka : N);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      int64_t m = mt + kb * 8 + r, src = m;
+      bool ok = cin && m < me;
+      if (isA) ok = ok && tn_a_row(m, a_shift, steps, src);
+      const bf16_t* p = isA ? (A + src * lda + c0) : (B + m * ldb + c0);
+      rg[r] = ok ? ldg16(p) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&]() {
+    uint4 o[8];
+    transpose8x8_b16(rg, o);
+    bf16_t* dst = isA ? As : Bs;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) *(uint4*)(dst + (cb * 8 + c) * G::LDT + kb * 8) = o[c];
+  };
+
+  if (ms < me) {
+    gload(ms);
+    lstore();
+    __syncthreads();
+    for (int64_t mt = ms; mt < me; mt += G::BK) {
+      bool more = (mt + G::BK) < me;
+      if (more) gload(mt + G::BK);
+      mma_tile<bf16_t>(As, Bs, acc, wr, wc, lane);
+      __syncthreads();
+      if (more) {
+        lstore();
+        __syncthreads();
+      }
+    }
+  }
+  const int l31 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int col = n0 + wc * 64 + j * 32 + l31;
+      if (col >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = i0 + wr * 64 + i * 32 + dj_crow(r, lane);
+        if (row < ka_valid) atomicAdd(C + (int64_t)row * ldc + col, acc[i][j][r]);
+      }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ launchers (internal C++ API)
+int dj_launch_gemm_nt(int dtype, int M, int N, int K, const void* A, int lda, const void* Bt, int ldb, void* C, int ldc,
+                      int c_is_f32, const float* bias, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int epl = dtype == DJ_F32 ? 4 : 8;
+  if ((K % epl) || (lda % epl) || (ldb % epl)) return 1001;
+  int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
+  dim3 grid((unsigned)(ntn * (int64_t)ntm)), block(256);
+  if (dtype == DJ_F32) {
+    hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, block, 0, st, M, N, K, (const float*)A, lda,
+                       (const float*)Bt, ldb, (float*)C, ldc, bias, ntn);
+  } else if (c_is_f32) {
+    hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, block, 0, st, M, N, K, (const bf16_t*)A, lda,
+                       (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn);
+  } else {
+    hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, block, 0, st, M, N, K, (const bf16_t*)A, lda,
+                       (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn);
+  }
+  return (int)hipGetLastError();
+}
+
+int dj_launch_gemm_tn(int dtype, int64_t M, int Ka, int ka_valid, int N, const void* A, int lda, const void* B, int ldb, float* C,
+                      int ldc, int a_shift, int steps, hipStream_t st) {
+  if (M <= 0 || N <= 0 || Ka <= 0) return 0;
+  const int epl = dtype == DJ_F32 ? 4 : 8;
+  if ((Ka % epl) || (N % epl) || (lda % epl) || (ldb % epl)) return 1002;
+  if (a_shift && (a_shift != 32 || steps <= 0)) return 1003;
+  int ntn = (N + 127) / 128, nta = (Ka + 127) / 128, ntiles = ntn * nta;
+  // split the reduction so that ~1024 workgroups are in flight; chunks are multiples of 64 rows
+  int64_t target = (1024 + ntiles - 1) / ntiles;
+  int64_t rps = (M + target - 1) / target;
+  rps = ((rps + 63) / 64) * 64;
+  int splits = (int)((M + rps - 1) / rps);
+  dim3 grid((unsigned)(ntiles * splits)), block(256);
+  if (dtype == DJ_F32)
+    hipLaunchKernelGGL(gemm_tn_f32_kernel, grid, block, 0, st, M, Ka, N, (const float*)A, lda, (const float*)B, ldb, C,
+                       ldc, ntn, ntiles, rps, a_shift, steps, ka_valid);
+  else
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, block, 0, st, M, Ka, N, (const bf16_t*)A, lda, (const bf16_t*)B, ldb,
+                       C, ldc, ntn, ntiles, rps, a_shift, steps, ka_valid);
+  return (int)hipGetLastError();
+}

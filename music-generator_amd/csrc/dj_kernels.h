@@ -1,0 +1,82 @@
+// Internal C++ interface between the kernel translation units and dj_api.hip.
+#pragma once
+#include "dj_common.h"
+
+struct FeatArgs {
+  const float* notes;   // [B,T,N,3]
+  const float* beat;    // [B,T,NB]
+  const float* bins;    // [12,B,T]
+  const float* sp0;     // [B*T, F] tanh'd style projection of time layer 0
+  const float* Wc;      // [24,3,64] conv kernel (Keras layout)
+  const float* bc;      // [64]
+  int B, T, N, NB, octave;
+  int F, FP;            // logical / padded feature width (94 / 96)
+  DjDrop d_notes, d_beat, d_conv, d_style;
+};
+
+struct GlueArgs {
+  int B, T, N;
+  int Hd;          // width of the producing layer's h
+  int D, DP;       // logical / padded width of the consuming layer's input
+  int in_na, out_na;   // row order of producer / consumer (0 = TA, 1 = NA)
+  const float* sp;     // [B*T, D] tanh'd style projection of the consuming layer (nullable)
+  const float* chosen; // [B,T,N,3] or null: append shifted chosen after the Hd columns (model.py:101-106)
+  DjDrop d_out, d_style, d_chosen;
+};
+
+struct HeadArgs {
+  int B, T, N, Hd;
+  const float* Wn;   // note_dense kernel [Hd,2]   (model.py:94)
+  const float* bn;   // [2]
+  const float* Wv;   // volume_dense kernel [Hd,1] (model.py:95)
+  const float* bv;   // [1]
+  const float* target;   // [B,T,N,3] or null (inference)
+  float* out;            // [B,T,N,3] or null
+  float* loss;           // scalar accumulator (+=) or null
+  float* dWn;
+  float* dbn;
+  float* dWv;
+  float* dbv;
+  float inv_count;
+  DjDrop d_out;
+};
+
+struct NadamArgs {
+  float lr, beta1, beta2, eps;
+  float mu_t, mu_t1;          // momentum_cache_t, momentum_cache_t_1
+  float ms_new, ms_next;      // m_schedule_new, m_schedule_next
+  float bc2;                  // 1 - beta2^t
+  float gscale;               // gradient pre-scale (1/world_size for data parallel)
+};
+
+// dj_gemm.hip
+int dj_launch_gemm_nt(int dtype, int M, int N, int K, const void* A, int lda, const void* Bt, int ldb, void* C, int ldc,
+                      int c_is_f32, const float* bias, hipStream_t st);
+int dj_launch_gemm_tn(int dtype, int64_t M, int Ka, int ka_valid, int N, const void* A, int lda, const void* B, int ldb, float* C,
+                      int ldc, int a_shift, int steps, hipStream_t st);
+// dj_lstm.hip
+int dj_launch_lstm_pack(int dtype, int H, const float* U, void* fwd, void* bwd, hipStream_t st);
+int dj_launch_lstm_fwd(int dtype, int H, int ntiles, int steps, void* Z, const void* Upack, void* Hout, void* Cout,
+                       int sigm, int store_z, hipStream_t st);
+int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, void* Z, const void* UTpack, const void* C,
+                       const void* dH, float* dbias, int sigm, hipStream_t st);
+// dj_elem.hip
+int dj_launch_dense_small(const float* A, int M, int K, const float* W, const float* b, float* C, int N, int act_tanh,
+                          hipStream_t st);
+int dj_launch_dense_small_bwd_x(const float* dC, int M, int N, const float* W, int K, float* dA, int accumulate,
+                                hipStream_t st);
+int dj_launch_dense_small_bwd_w(const float* A, int M, int K, const float* dC, int N, float* dW, float* db,
+                                hipStream_t st);
+int dj_launch_bins(const float* notes, float* bins, int B, int T, int N, int octave, DjDrop dn, hipStream_t st);
+int dj_launch_feature_fwd(int dtype, const void* fa, void* X, hipStream_t st);
+int dj_launch_feature_bwd(int dtype, const void* fa, const void* dX, float* dWc, float* dbc, float* dpre0,
+                          hipStream_t st);
+int dj_launch_glue_fwd(int dtype, const void* ga, const void* Hin, void* X, hipStream_t st);
+int dj_launch_glue_bwd(int dtype, const void* ga, const void* dX, void* dH, float* dpre, hipStream_t st);
+int dj_launch_head(int dtype, const void* ha, const void* Hn, void* dH, hipStream_t st);
+int dj_launch_cvt_transpose(int dtype, const float* W, int K, int N, void* out, int ld, hipStream_t st);
+int dj_launch_cvt_copy(int dtype, const float* W, int64_t n, void* out, hipStream_t st);
+int dj_launch_cvt_to_f32(int dtype, const void* in, int64_t n, float* out, hipStream_t st);
+int dj_launch_nadam(float* p, const float* g, float* m, float* v, int64_t n, const void* na, hipStream_t st);
+int dj_launch_ta_to_canonical(int dtype, const void* Hin, float* out, int B, int T, int N, int Hd, hipStream_t st);
+int dj_launch_canonical_to_na(int dtype, const float* in, void* out, int B, int T, int N, int Hd, hipStream_t st);

@@ -1,0 +1,231 @@
+"""Host-side engine: owns device memory (through torch) and calls the C ABI.
+
+PyTorch is plumbing here -- tensor allocation, streams, torch.distributed -- every
+arithmetic op of the hot path runs inside libdeepj_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import constants as K
+
+
+@dataclass(frozen=True)
+class DeepJConfig:
+    """Model hyper-parameters; defaults = reference constants.py:42-77."""
+    num_notes: int = K.NUM_NOTES
+    time_steps: int = K.SEQ_LEN
+    num_styles: int = K.NUM_STYLES
+    notes_per_bar: int = K.NOTES_PER_BAR
+    octave: int = K.OCTAVE
+    octave_units: int = K.OCTAVE_UNITS
+    style_units: int = K.STYLE_UNITS
+    note_units: int = K.NOTE_UNITS
+    time_axis_units: int = K.TIME_AXIS_UNITS
+    note_axis_units: int = K.NOTE_AXIS_UNITS
+    time_axis_layers: int = K.TIME_AXIS_LAYERS
+    note_axis_layers: int = K.NOTE_AXIS_LAYERS
+    recurrent_activation: str = "hard_sigmoid"     # Keras 2.x LSTM default
+    dtype: str = "f32"                             # "f32" (parity) | "bf16" (throughput)
+
+    def cstruct(self, batch, time_steps=None, input_dropout=0.0, dropout=0.0):
+        c = _lib.DjConfig()
+        c.batch = int(batch)
+        c.time_steps = int(self.time_steps if time_steps is None else time_steps)
+        c.num_notes = self.num_notes
+        c.num_styles = self.num_styles
+        c.notes_per_bar = self.notes_per_bar
+        c.octave = self.octave
+        c.octave_units = self.octave_units
+        c.style_units = self.style_units
+        c.note_units = self.note_units
+        c.time_axis_units = self.time_axis_units
+        c.note_axis_units = self.note_axis_units
+        c.time_axis_layers = self.time_axis_layers
+        c.note_axis_layers = self.note_axis_layers
+        c.dtype = {"f32": _lib.DTYPE_F32, "bf16": _lib.DTYPE_BF16}[self.dtype]
+        c.recurrent_sigmoid = {"hard_sigmoid": 0, "sigmoid": 1}[self.recurrent_activation]
+        c.input_dropout = float(input_dropout)
+        c.dropout = float(dropout)
+        return c
+
+
+def param_layout(cfg: DeepJConfig):
+    """[(name, offset, shape)] straight from the library (dj_param_info)."""
+    lib = _lib.load()
+    c = cfg.cstruct(1)
+    out = []
+    name = C.create_string_buffer(64)
+    off = C.c_int64()
+    shape = (C.c_int32 * 4)()
+    nd = C.c_int32()
+    i = 0
+    while True:
+        rc = lib.dj_param_info(C.byref(c), i, name, 64, C.byref(off), shape, C.byref(nd))
+        if rc == 1000:
+            break
+        _lib.check(rc, "dj_param_info")
+        out.append((name.value.decode(), int(off.value), tuple(int(shape[k]) for k in range(nd.value))))
+        i += 1
+    return out
+
+
+def param_count(cfg: DeepJConfig) -> int:
+    n = _lib.load().dj_param_count(C.byref(cfg.cstruct(1)))
+    if n < 0:
+        raise _lib.DeepJError("dj_param_count: invalid configuration")
+    return int(n)
+
+
+def init_params_numpy(cfg: DeepJConfig, seed: int = 1234) -> np.ndarray:
+    """Keras default initialisers: glorot-uniform kernels, orthogonal
+    recurrent kernels, zero biases with unit forget-gate bias.  Flat fp32 vector."""
+    rs = np.random.RandomState(seed)
+    flat = np.zeros(param_count(cfg), np.float32)
+    for name, off, shape in param_layout(cfg):
+        n = int(np.prod(shape))
+        if name.endswith("/bias"):
+            w = np.zeros(shape, np.float32)
+            if "lstm" in name:
+                h = shape[0] // 4
+                w[h:2 * h] = 1.0
+        elif name.endswith("recurrent_kernel"):
+            a = rs.normal(0.0, 1.0, shape)
+            u, _, v = np.linalg.svd(a, full_matrices=False)
+            w = (u if u.shape == shape else v).reshape(shape).astype(np.float32)
+        else:
+            if len(shape) == 3:
+                fan_in, fan_out = shape[0] * shape[1], shape[0] * shape[2]
+            else:
+                fan_in, fan_out = shape[0], shape[1]
+            lim = math.sqrt(6.0 / (fan_in + fan_out))
+            w = rs.uniform(-lim, lim, shape).astype(np.float32)
+        flat[off:off + n] = w.ravel()
+    return flat
+
+
+def _dev_f32(a, device):
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=torch.float32).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """One (config, batch, time_steps) instance = one workspace in HBM."""
+
+    def __init__(self, cfg: DeepJConfig, batch: int, time_steps: int | None = None, device="cuda:0",
+                 input_dropout: float = 0.0, dropout: float = 0.0):
+        if not torch.cuda.is_available():
+            raise _lib.DeepJError("no HIP device visible: the DeepJ engine has no CPU path")
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.batch = int(batch)
+        self.time_steps = int(cfg.time_steps if time_steps is None else time_steps)
+        self.c = cfg.cstruct(batch, self.time_steps, input_dropout, dropout)
+        self.nparams = int(self.lib.dj_param_count(C.byref(self.c)))
+        nbytes = int(self.lib.dj_workspace_bytes(C.byref(self.c)))
+        if self.nparams < 0 or nbytes < 0:
+            raise _lib.DeepJError("invalid DeepJ configuration for the HIP engine")
+        self.ws_bytes = nbytes
+        with torch.cuda.device(self.device):
+            self.ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            pad = (-self.ws.data_ptr()) % 256
+            self.ws_ptr = C.c_void_p(self.ws.data_ptr() + pad)
+            _lib.check(self.lib.dj_workspace_init(C.byref(self.c), self.ws_ptr, nbytes, _stream_ptr()),
+                       "dj_workspace_init")
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    # -- shapes
+    def _shapes(self):
+        B, T, N = self.batch, self.time_steps, self.cfg.num_notes
+        return (B, T, N, 3), (B, T, self.cfg.notes_per_bar), (B, T, self.cfg.num_styles)
+
+    def _check(self, t, shape, what):
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{what}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+
+    def train_fwd_bwd(self, params, grads, notes, chosen, beat, style, target, seed=0, out=None):
+        """Forward + BPTT.  All arguments are device fp32 tensors; returns the loss
+        tensor (device, shape [1]); grads is overwritten."""
+        s3, sb, ss = self._shapes()
+        for t, sh, nm in ((notes, s3, "notes"), (chosen, s3, "chosen"), (target, s3, "target"),
+                          (beat, sb, "beat"), (style, ss, "style")):
+            self._check(t, sh, nm)
+        assert params.numel() == self.nparams and grads.numel() == self.nparams
+        with torch.cuda.device(self.device):
+            rc = self.lib.dj_train_fwd_bwd(C.byref(self.c), _lib.ptr(params), _lib.ptr(grads), _lib.ptr(notes),
+                                           _lib.ptr(chosen), _lib.ptr(beat), _lib.ptr(style), _lib.ptr(target),
+                                           _lib.ptr(out), _lib.ptr(self.loss), self.ws_ptr, self.ws_bytes,
+                                           C.c_uint64(int(seed) & (2 ** 64 - 1)), _stream_ptr())
+        _lib.check(rc, "dj_train_fwd_bwd")
+        return self.loss
+
+    def predict(self, params, notes, chosen, beat, style, target=None):
+        s3, sb, ss = self._shapes()
+        for t, sh, nm in ((notes, s3, "notes"), (chosen, s3, "chosen"), (beat, sb, "beat"), (style, ss, "style")):
+            self._check(t, sh, nm)
+        out = torch.empty(s3, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.dj_predict(C.byref(self.c), _lib.ptr(params), _lib.ptr(notes), _lib.ptr(chosen),
+                                     _lib.ptr(beat), _lib.ptr(style), _lib.ptr(target),
+                                     _lib.ptr(out), _lib.ptr(self.loss) if target is not None else None,
+                                     self.ws_ptr, self.ws_bytes, _stream_ptr())
+        _lib.check(rc, "dj_predict")
+        return (out, self.loss) if target is not None else out
+
+    def time_model_predict(self, params, notes, beat, style):
+        s3, sb, ss = self._shapes()
+        self._check(notes, s3, "notes"); self._check(beat, sb, "beat"); self._check(style, ss, "style")
+        B, T, N = self.batch, self.time_steps, self.cfg.num_notes
+        out = torch.empty((B, T, N, self.cfg.time_axis_units), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.dj_time_model_predict(C.byref(self.c), _lib.ptr(params), _lib.ptr(notes), _lib.ptr(beat),
+                                                _lib.ptr(style), _lib.ptr(out), self.ws_ptr, self.ws_bytes,
+                                                _stream_ptr())
+        _lib.check(rc, "dj_time_model_predict")
+        return out
+
+    def note_model_predict(self, params, features, chosen, style):
+        s3, _, ss = self._shapes()
+        B, T, N = self.batch, self.time_steps, self.cfg.num_notes
+        self._check(features, (B, T, N, self.cfg.time_axis_units), "features")
+        self._check(chosen, s3, "chosen"); self._check(style, ss, "style")
+        out = torch.empty(s3, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.dj_note_model_predict(C.byref(self.c), _lib.ptr(params), _lib.ptr(features),
+                                                _lib.ptr(chosen), _lib.ptr(style), _lib.ptr(out), self.ws_ptr,
+                                                self.ws_bytes, _stream_ptr())
+        _lib.check(rc, "dj_note_model_predict")
+        return out
+
+
+class Nadam:
+    """Keras-2 Nadam state (model.py:152) around dj_nadam_step."""
+
+    def __init__(self, nparams, device, lr=0.002, beta_1=0.9, beta_2=0.999, epsilon=1e-8, schedule_decay=0.004):
+        self.lib = _lib.load()
+        self.lr, self.beta_1, self.beta_2, self.epsilon, self.schedule_decay = lr, beta_1, beta_2, epsilon, schedule_decay
+        self.m = torch.zeros(nparams, dtype=torch.float32, device=device)
+        self.v = torch.zeros(nparams, dtype=torch.float32, device=device)
+        self.iterations = 0
+        self.m_schedule = C.c_double(1.0)
+
+    def step(self, params, grads, grad_scale=1.0):
+        self.iterations += 1
+        with torch.cuda.device(params.device):
+            rc = self.lib.dj_nadam_step(_lib.ptr(params), _lib.ptr(grads), _lib.ptr(self.m), _lib.ptr(self.v),
+                                        params.numel(), self.iterations, C.byref(self.m_schedule), self.lr,
+                                        self.beta_1, self.beta_2, self.epsilon, self.schedule_decay,
+                                        float(grad_scale), _stream_ptr())
+        _lib.check(rc, "dj_nadam_step")

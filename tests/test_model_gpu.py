@@ -1,0 +1,136 @@
+"""Whole-path parity: the HIP training step / predict calls (through the C ABI) against
+the CPU oracle on the same seeded inputs.  north_star tolerance: 1e-3 relative on the
+outputs ("logits") in fp32 mode; gradients are checked at 2e-3 relative to the
+per-tensor max (fp32 atomics reorder sums).  bf16 mode is checked at bf16 tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import deepj_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfgs(**kw):
+    from music_generator_amd.engine import DeepJConfig
+    o = O.OracleConfig(**{k: v for k, v in kw.items() if k != "dtype"})
+    d = DeepJConfig(**kw)
+    return o, d
+
+
+def _run_train(dcfg, B, T, flat, batch, seed, pin, pdr, dev):
+    from music_generator_amd.engine import Engine
+    eng = Engine(dcfg, B, T, device=dev, input_dropout=pin, dropout=pdr)
+    P = torch.from_numpy(flat).to(dev)
+    G = torch.empty_like(P)
+    dn = [torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev) for a in batch]
+    out = torch.empty((B, T, dcfg.num_notes, 3), dtype=torch.float32, device=dev)
+    loss = eng.train_fwd_bwd(P, G, dn[0], dn[1], dn[2], dn[3], dn[4], seed=seed, out=out)
+    torch.cuda.synchronize()
+    return float(loss.cpu()[0]), out.cpu().numpy(), G.cpu().numpy(), eng
+
+
+def _grad_report(ocfg, g_hip, g_ref):
+    rows = []
+    o = 0
+    worst = 0.0
+    for name, shape in O.param_layout(ocfg):
+        n = int(np.prod(shape))
+        a, b = g_hip[o:o + n], g_ref[name].ravel()
+        scale = max(float(np.abs(b).max()), 1e-12)
+        err = float(np.abs(a - b).max()) / scale
+        rows.append((name, err, scale))
+        worst = max(worst, err)
+        o += n
+    return worst, rows
+
+
+CASES = [
+    # name, cfg kwargs, B, T, input_dropout, dropout
+    ("ref_dims_nodrop", dict(), 2, 8, 0.0, 0.0),
+    ("ref_dims_dropout", dict(), 2, 8, 0.2, 0.5),
+    ("ragged_n20", dict(num_notes=20), 3, 5, 0.2, 0.5),
+    ("n128_baseline_shape", dict(num_notes=128), 1, 6, 0.0, 0.0),
+    ("sigmoid_gates", dict(recurrent_activation="sigmoid", time_axis_units=128), 2, 4, 0.0, 0.0),
+    ("three_layers", dict(time_axis_layers=3, note_axis_layers=1, time_axis_units=128, note_axis_units=256), 2, 4,
+     0.0, 0.5),
+]
+
+
+@pytest.mark.parametrize("name,kw,B,T,pin,pdr", CASES, ids=[c[0] for c in CASES])
+def test_train_step_fp32_parity(gpu_device, name, kw, B, T, pin, pdr):
+    ocfg, dcfg = _cfgs(time_steps=T, **kw)
+    params = O.init_params(ocfg, seed=11)
+    # perturb biases so that every bias gradient path is exercised with non-trivial values
+    rs = np.random.RandomState(2)
+    for k in params:
+        if k.endswith("bias"):
+            params[k] = params[k] + rs.uniform(-0.1, 0.1, params[k].shape).astype(np.float32)
+    flat = O.flatten_params(ocfg, params)
+    batch = O.synthetic_batch(ocfg, B, seed=3, T=T)
+    seed = 99
+    masks = O.make_masks(ocfg, B, seed, pin, pdr, T=T) if (pin > 0 or pdr > 0) else None
+    loss_ref, out_ref, g_ref = O.loss_and_grads(ocfg, params, batch, masks)
+    loss, out, g, _ = _run_train(dcfg, B, T, flat, batch, seed, pin, pdr, gpu_device)
+    # outputs: 1e-3 relative (north_star), tiny atol for values near zero
+    np.testing.assert_allclose(out, out_ref, rtol=1e-3, atol=1e-5)
+    assert abs(loss - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref)), (loss, loss_ref)
+    worst, rows = _grad_report(ocfg, g, g_ref)
+    assert worst < 2e-3, sorted(rows, key=lambda r: -r[1])[:6]
+
+
+def test_train_step_bf16_close(gpu_device):
+    T, B = 8, 2
+    ocfg, dcfg = _cfgs(time_steps=T, dtype="bf16")
+    params = O.init_params(ocfg, seed=11)
+    flat = O.flatten_params(ocfg, params)
+    batch = O.synthetic_batch(ocfg, B, seed=3, T=T)
+    loss_ref, out_ref, g_ref = O.loss_and_grads(ocfg, params, batch, None)
+    loss, out, g, _ = _run_train(dcfg, B, T, flat, batch, 1, 0.0, 0.0, gpu_device)
+    np.testing.assert_allclose(out, out_ref, rtol=3e-2, atol=3e-3)     # bf16 operands: ~2^-8 relative
+    assert abs(loss - loss_ref) <= 2e-2 * max(1.0, abs(loss_ref))
+    worst, rows = _grad_report(ocfg, g, g_ref)
+    assert worst < 8e-2, sorted(rows, key=lambda r: -r[1])[:6]
+
+
+def test_predict_models_fp32(gpu_device):
+    from music_generator_amd.engine import Engine
+    T, G = 16, 3
+    ocfg, dcfg = _cfgs(time_steps=T)
+    params = O.init_params(ocfg, seed=5)
+    flat = torch.from_numpy(O.flatten_params(ocfg, params)).to(gpu_device)
+    notes, chosen, beat, style, target = O.synthetic_batch(ocfg, G, seed=8, T=T)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(gpu_device)
+    eng = Engine(dcfg, G, T, device=gpu_device)
+    # full model, inference mode, with loss
+    out, loss = eng.predict(flat, d(notes), d(chosen), d(beat), d(style), d(target))
+    p = O.to_torch(params)
+    with torch.no_grad():
+        ref = O.forward(ocfg, p, *[torch.from_numpy(a) for a in (notes, chosen, beat, style)])
+        lref = float(O.primary_loss(torch.from_numpy(target), ref))
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-5)
+    assert abs(float(loss.cpu()[0]) - lref) < 1e-4 * max(1.0, lref)
+    # time_model (generate.py:108)
+    tout = eng.time_model_predict(flat, d(notes), d(beat), d(style)).cpu().numpy()
+    tref = O.time_model_predict(ocfg, params, notes, beat, style)
+    np.testing.assert_allclose(tout, tref, rtol=1e-3, atol=2e-5)
+    # note_model on one time step (generate.py:114)
+    eng1 = Engine(dcfg, G, 1, device=gpu_device)
+    feat = tref[:, -1:, :, :]
+    ch = chosen[:, -1:, :, :]
+    st = style[:, -1:, :]
+    nout = eng1.note_model_predict(flat, d(feat), d(ch), d(st)).cpu().numpy()
+    nref = O.note_model_predict(ocfg, params, feat, ch, st)
+    np.testing.assert_allclose(nout, nref, rtol=1e-3, atol=1e-5)
+
+
+def test_seed_reproducible_and_mask_sensitive(gpu_device):
+    T, B = 4, 2
+    ocfg, dcfg = _cfgs(time_steps=T)
+    flat = O.flatten_params(ocfg, O.init_params(ocfg, seed=1))
+    batch = O.synthetic_batch(ocfg, B, seed=0, T=T)
+    l1, o1, _, _ = _run_train(dcfg, B, T, flat, batch, 5, 0.2, 0.5, gpu_device)
+    l2, o2, _, _ = _run_train(dcfg, B, T, flat, batch, 5, 0.2, 0.5, gpu_device)
+    l3, o3, _, _ = _run_train(dcfg, B, T, flat, batch, 6, 0.2, 0.5, gpu_device)
+    np.testing.assert_array_equal(o1, o2)
+    assert np.abs(o1 - o3).max() > 1e-4
