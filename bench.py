@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DeepJ biaxial-LSTM training throughput in note-steps/sec.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full training step (teacher-forced forward + BPTT + Nadam, dropout on,
+plus the RCCL gradient all-reduce when N > 1) over one synthetic batch of
+B=64 x T=128 x N=128 per GPU (BASELINE.json configs[1]; weak scaling: global batch
+64*N).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON
+line.  `roofline` is measured live with HIP events recorded by the library around
+every launch (dj_profile_*); `cpu_baseline` times the CPU oracle on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def category_flops(cfg, B, T, N):
+    """ALGORITHMIC FLOPs (2*MAC) per training step of each MFMA kernel category
+    (SURVEY.md 8d formulas, generalised to the config)."""
+    Ht, Hn = cfg.time_axis_units, cfg.note_axis_units
+    rows = B * T * N
+    F = 1 + cfg.octave + 1 + cfg.octave_units + cfg.notes_per_bar
+    t_in = [F] + [Ht] * (cfg.time_axis_layers - 1)
+    n_in = [Ht + cfg.note_units] + [Hn] * (cfg.note_axis_layers - 1)
+    xw = sum(2 * rows * d * 4 * Ht for d in t_in) + sum(2 * rows * d * 4 * Hn for d in n_in)
+    rec_t = cfg.time_axis_layers * 2 * rows * Ht * 4 * Ht
+    rec_n = cfg.note_axis_layers * 2 * rows * Hn * 4 * Hn
+    return {
+        "gemm_xw": xw, "gemm_dx": xw, "gemm_dw": xw + rec_t + rec_n,
+        "lstm_fwd_time": rec_t, "lstm_bwd_time": rec_t, "lstm_fwd_note": rec_n, "lstm_bwd_note": rec_n,
+    }
+
+
+def launches_per_step(cfg):
+    Lt, Ln = cfg.time_axis_layers, cfg.note_axis_layers
+    return {"gemm_xw": Lt + Ln, "gemm_dx": Lt + Ln, "gemm_dw": 2 * (Lt + Ln), "lstm_fwd_time": Lt,
+            "lstm_bwd_time": Lt, "lstm_fwd_note": Ln, "lstm_bwd_note": Ln}
+
+
+def cpu_baseline(cfg, T, N, sample_b, pin, pdr):
+    """CPU oracle (torch-CPU fp32 restatement of the reference) on a bounded sample of the
+    same workload: sample_b sequences of the B=64 batch, one forward + BPTT + Nadam step."""
+    from oracle import deepj_oracle as O
+    from music_generator_amd.data import synthetic_batch
+    ocfg = O.OracleConfig(num_notes=N, time_steps=T, time_axis_units=cfg.time_axis_units,
+                          note_axis_units=cfg.note_axis_units, time_axis_layers=cfg.time_axis_layers,
+                          note_axis_layers=cfg.note_axis_layers)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    params = O.init_params(ocfg, seed=1234)
+    batch = synthetic_batch(N, T, sample_b, seed=0)
+    masks = O.make_masks(ocfg, sample_b, 0, pin, pdr, T=T)
+    st = O.NadamState()
+    t0 = time.time()
+    loss, _, grads = O.loss_and_grads(ocfg, params, batch, masks)
+    flat = O.flatten_params(ocfg, params)
+    O.nadam_step(flat, O.flatten_params(ocfg, grads), st)
+    dt = time.time() - t0
+    return {"value": sample_b * T * N / dt, "unit": "note-steps/sec", "cores": cores, "kind": "port",
+            "sample": f"CPU oracle (torch-CPU fp32), 1 train step (fwd+BPTT+Nadam, dropout on) on {sample_b} of the "
+                      f"64 sequences, T={T}, N={N}: {dt:.1f} s",
+            "loss": loss}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
+    ap.add_argument("--time-steps", type=int, default=128)
+    ap.add_argument("--notes", type=int, default=128)
+    ap.add_argument("--cpu-sample", type=int, default=4, help="sequences in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the DeepJ engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from music_generator_amd import _lib
+    from music_generator_amd.data import synthetic_batch
+    from music_generator_amd.engine import DeepJConfig, Engine, Nadam, init_params_numpy
+
+    B, T, N = args.batch, args.time_steps, args.notes
+    pin, pdr = 0.2, 0.5                                  # model.py:128 defaults
+    cfg = DeepJConfig(num_notes=N, time_steps=T, dtype=args.dtype)
+    eng = Engine(cfg, B, T, device=dev, input_dropout=pin, dropout=pdr)
+    P = torch.from_numpy(init_params_numpy(cfg, seed=1234)).to(dev)     # replicated weights
+    G = torch.zeros_like(P)
+    opt = Nadam(P.numel(), dev)
+    notes, chosen, beat, style, target = [torch.from_numpy(a).to(dev)
+                                          for a in synthetic_batch(N, T, B, seed=rank)]
+    lib = _lib.load()
+
+    def step(i):
+        loss = eng.train_fwd_bwd(P, G, notes, chosen, beat, style, target, seed=i * world + rank)
+        if world > 1:
+            dist.all_reduce(G)                           # one flat fp32 buffer, RCCL over xGMI
+        opt.step(P, G, grad_scale=1.0 / world)
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_profile:
+        lib.dj_profile_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    final_loss = float(loss.cpu()[0])
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.cpu()[0])
+
+    kernels = {}
+    roof = None
+    if not args.no_profile:
+        ncat = lib.dj_profile_category_count()
+        for c in range(ncat):
+            ms, n = C.c_double(), C.c_int64()
+            _lib.check(lib.dj_profile_read(c, C.byref(ms), C.byref(n)), "dj_profile_read")
+            kernels[lib.dj_profile_category_name(c).decode()] = round(ms.value / args.steps, 4)
+        lib.dj_profile_enable(0)
+        fl = category_flops(cfg, B, T, N)
+        lps = launches_per_step(cfg)
+        dom = max(fl, key=lambda k: kernels.get(k, 0.0))
+        ms = kernels[dom]
+        achieved = fl[dom] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype],
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                "launches_per_step": lps[dom], "avg_launch_ms": round(ms / lps[dom], 4),
+                "flops_per_launch": fl[dom] / lps[dom]}
+
+    if rank == 0:
+        value = world * B * T * N * args.steps / elapsed
+        flops_step = 3 * (category_flops(cfg, B, T, N)["gemm_xw"] + category_flops(cfg, B, T, N)["lstm_fwd_time"]
+                          + category_flops(cfg, B, T, N)["lstm_fwd_note"])
+        out = {
+            "metric": "note-steps/sec (train)", "value": round(value, 1), "unit": "note-steps/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"biaxial-LSTM train step, batch {B}/GPU x {T} steps x {N} notes "
+                                   f"(BASELINE configs[1]), 2x256 time-axis + 2x128 note-axis LSTM, dropout 0.2/0.5, "
+                                   f"Nadam; random-init weights",
+                       "global_batch": B * world, "seq_len": T, "num_notes": N, "parallelism": f"dp{world}"},
+            "model_tflops_per_s": round(flops_step * world * args.steps / elapsed / 1e12, 2),
+            "final_loss": round(final_loss, 5),
+            "roofline": roof, "kernel_ms_per_step": kernels,
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(cfg, T, N, args.cpu_sample, pin, pdr)
+            out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

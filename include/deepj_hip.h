@@ -120,6 +120,15 @@ int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, voi
  * hash so tests can pin it against the oracle. */
 int32_t dj_dropout_mask(uint64_t seed, int32_t site, float p, int64_t rows, int32_t cols, float* mask, void* stream);
 
+/* ---- live kernel timing (bench.py roofline): when enabled, HIP events are recorded on
+ * the caller's stream around every launch, grouped by category.  dj_profile_read waits
+ * for the category's events and returns the summed milliseconds and the scope count.
+ * Process-global and not thread-safe: a measurement aid, not part of the data path. */
+int32_t dj_profile_enable(int32_t on);
+int32_t dj_profile_category_count(void);
+const char* dj_profile_category_name(int32_t category);
+int32_t dj_profile_read(int32_t category, double* total_ms_host, int64_t* scopes_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,10 @@ _SIGS = {
     "dj_lstm_fwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P]),
     "dj_lstm_bwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "dj_dropout_mask": (C.c_int32, [C.c_uint64, C.c_int32, C.c_float, C.c_int64, C.c_int32, _P, _P]),
+    "dj_profile_enable": (C.c_int32, [C.c_int32]),
+    "dj_profile_category_count": (C.c_int32, []),
+    "dj_profile_category_name": (C.c_char_p, [C.c_int32]),
+    "dj_profile_read": (C.c_int32, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dj_generate_step": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
 }
 OPTIONAL = {"dj_generate_step"}

@@ -8,12 +8,45 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/deepj_hip.h"
 #include "dj_kernels.h"
 
 namespace {
 
 constexpr int MAXL = 4;
+
+// ---- optional per-category HIP-event timing (dj_profile_*): events are recorded on the
+// caller's stream around each launch, so bench.py can report live kernel durations.
+enum ProfCat {
+  PC_PREP, PC_STYLE_FWD, PC_FEATURE_FWD, PC_GLUE_FWD, PC_GEMM_XW, PC_LSTM_FWD_TIME, PC_LSTM_FWD_NOTE, PC_HEAD,
+  PC_LSTM_BWD_TIME, PC_LSTM_BWD_NOTE, PC_GEMM_DW, PC_GEMM_DX, PC_GLUE_BWD, PC_FEATURE_BWD, PC_STYLE_BWD, PC_NADAM,
+  PC_COUNT
+};
+const char* const kProfNames[PC_COUNT] = {
+    "prep_weights", "style_fwd", "feature_fwd", "glue_fwd", "gemm_xw", "lstm_fwd_time", "lstm_fwd_note", "head_loss",
+    "lstm_bwd_time", "lstm_bwd_note", "gemm_dw", "gemm_dx", "glue_bwd", "feature_bwd", "style_bwd", "nadam"};
+struct ProfRec { int cat; hipEvent_t a, b; };
+struct Prof {
+  bool on = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+  }
+} g_prof;
+struct ProfScope {
+  bool act; hipStream_t st; hipEvent_t b;
+  ProfScope(int cat, hipStream_t s) : act(g_prof.on), st(s) {
+    if (!act) return;
+    hipEvent_t a = g_prof.get(); b = g_prof.get();
+    hipEventRecord(a, st);
+    g_prof.recs.push_back({cat, a, b});
+  }
+  ~ProfScope() { if (act) hipEventRecord(b, st); }
+};
 
 struct LstmP {          // parameter offsets (floats) of one LSTM layer + its style Dense
   int64_t dW, db;       // style Dense kernel [SU, D], bias [D]
@@ -142,6 +175,7 @@ struct Ctx {
 // weight conversion/packing for one LSTM layer
 int prep_layer(const Ctx& c, const LstmP& L, int64_t wWt, int64_t wWc, int64_t wUf, int64_t wUb, bool need_bwd) {
   const int dt = c.p.c.dtype;
+  ProfScope ps(PC_PREP, c.st);
   RUN(dj_launch_cvt_transpose(dt, c.P + L.W, L.D, 4 * L.H, c.at(wWt), L.DP, c.st));
   RUN(dj_launch_lstm_pack(dt, L.H, c.P + L.U, c.at(wUf), need_bwd ? c.at(wUb) : nullptr, c.st));
   if (need_bwd && dt != DJ_F32) RUN(dj_launch_cvt_copy(dt, c.P + L.W, (int64_t)L.D * 4 * L.H, c.at(wWc), c.st));
@@ -150,20 +184,26 @@ int prep_layer(const Ctx& c, const LstmP& L, int64_t wWt, int64_t wWc, int64_t w
 
 int style_forward(const Ctx& c, const float* style_in) {
   const Plan& p = c.p;
+  ProfScope ps(PC_STYLE_FWD, c.st);
   RUN(dj_launch_dense_small(style_in, (int)p.BT, p.S, c.P + p.p_style_W, c.P + p.p_style_b, c.at<float>(p.w_style),
                             p.SU, 0, c.st));                                            // model.py:141-142
   return 0;
 }
 int style_proj(const Ctx& c, const LstmP& L, int64_t w_sp) {                            // model.py:77,110-113 + tanh
+  ProfScope ps(PC_STYLE_FWD, c.st);
   return dj_launch_dense_small(c.at<float>(c.p.w_style), (int)c.p.BT, c.p.SU, c.P + L.dW, c.P + L.db,
                                c.at<float>(w_sp), L.D, 1, c.st);
 }
 
 int lstm_layer_fwd(const Ctx& c, const LstmP& L, int64_t tiles, int steps, int64_t M, int64_t wX, int64_t wWt,
-                   int64_t wUf, int64_t wZ, int64_t wH, int64_t wC) {
+                   int64_t wUf, int64_t wZ, int64_t wH, int64_t wC, bool is_note) {
   const int dt = c.p.c.dtype;
-  RUN(dj_launch_gemm_nt(dt, (int)M, 4 * L.H, L.DP, c.at(wX), L.DP, c.at(wWt), L.DP, c.at(wZ), 4 * L.H, 0,
-                        c.P + L.b, c.st));
+  {
+    ProfScope ps(PC_GEMM_XW, c.st);
+    RUN(dj_launch_gemm_nt(dt, (int)M, 4 * L.H, L.DP, c.at(wX), L.DP, c.at(wWt), L.DP, c.at(wZ), 4 * L.H, 0,
+                          c.P + L.b, c.st));
+  }
+  ProfScope ps(is_note ? PC_LSTM_FWD_NOTE : PC_LSTM_FWD_TIME, c.st);
   RUN(dj_launch_lstm_fwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUf), c.at(wH), c.train ? c.at(wC) : nullptr,
                          c.p.c.recurrent_sigmoid, c.train ? 1 : 0, c.st));
   return 0;
@@ -184,7 +224,10 @@ int time_axis_forward(const Ctx& c, const float* notes, const float* beat) {
   fa.d_notes = d_notes; fa.d_beat = mkdrop(c.seed, DJ_SITE_BEAT, pin, c.train);
   fa.d_conv = mkdrop(c.seed, DJ_SITE_CONV, pdr, c.train);
   fa.d_style = mkdrop(c.seed, DJ_SITE_TSTYLE + 0, pdr, c.train);
-  RUN(dj_launch_feature_fwd(dt, &fa, c.at(p.w_X_t[0]), c.st));
+  {
+    ProfScope ps(PC_FEATURE_FWD, c.st);
+    RUN(dj_launch_feature_fwd(dt, &fa, c.at(p.w_X_t[0]), c.st));
+  }
   for (int l = 0; l < p.Lt; ++l) {
     const LstmP& L = p.tl[l];
     if (l > 0) {
@@ -194,10 +237,11 @@ int time_axis_forward(const Ctx& c, const float* notes, const float* beat) {
       g.d_out = mkdrop(c.seed, DJ_SITE_TOUT + (l - 1), pdr, c.train);
       g.d_style = mkdrop(c.seed, DJ_SITE_TSTYLE + l, pdr, c.train);
       g.d_chosen = mkdrop(c.seed, DJ_SITE_CHOSEN, pin, c.train);
+      ProfScope ps(PC_GLUE_FWD, c.st);
       RUN(dj_launch_glue_fwd(dt, &g, c.at(p.w_H_t[l - 1]), c.at(p.w_X_t[l]), c.st));
     }
     RUN(lstm_layer_fwd(c, L, p.tilesT, p.T, p.Mt, p.w_X_t[l], p.w_Wt_t[l], p.w_Uf_t[l], p.w_Z_t[l], p.w_H_t[l],
-                       p.w_C_t[l]));
+                       p.w_C_t[l], false));
   }
   return 0;
 }
@@ -219,14 +263,16 @@ int note_axis_forward(const Ctx& c, int64_t wHin, int in_na, int d_out_site, con
     if (l == 0) {
       g.Hd = p.Ht; g.in_na = in_na; g.chosen = chosen;
       g.d_out = mkdrop(c.seed, d_out_site, pdr, c.train && d_out_site >= 0);
+      ProfScope ps(PC_GLUE_FWD, c.st);
       RUN(dj_launch_glue_fwd(dt, &g, c.at(wHin), c.at(p.w_X_n[0]), c.st));
     } else {
       g.Hd = p.Hn; g.in_na = 1; g.chosen = nullptr;
       g.d_out = mkdrop(c.seed, DJ_SITE_NOUT + (l - 1), pdr, c.train);
+      ProfScope ps(PC_GLUE_FWD, c.st);
       RUN(dj_launch_glue_fwd(dt, &g, c.at(p.w_H_n[l - 1]), c.at(p.w_X_n[l]), c.st));
     }
     RUN(lstm_layer_fwd(c, L, p.tilesN, p.N, p.Mn, p.w_X_n[l], p.w_Wt_n[l], p.w_Uf_n[l], p.w_Z_n[l], p.w_H_n[l],
-                       p.w_C_n[l]));
+                       p.w_C_n[l], true));
   }
   HeadArgs h;
   h.B = p.B; h.T = p.T; h.N = p.N; h.Hd = p.Hn;
@@ -240,24 +286,34 @@ int note_axis_forward(const Ctx& c, int64_t wHin, int in_na, int d_out_site, con
     float* dummy = c.at<float>(p.w_dX_n);
     h.dWn = dummy; h.dbn = dummy + 2 * p.Hn; h.dWv = dummy + 2 * p.Hn + 2; h.dbv = dummy + 3 * p.Hn + 2;
   }
+  ProfScope ps(PC_HEAD, c.st);
   RUN(dj_launch_head(dt, &h, c.at(p.w_H_n[p.Ln - 1]), (grads && c.train) ? c.at(p.w_dH_n) : nullptr, c.st));
   return 0;
 }
 
 int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int steps, int64_t M, int64_t wX,
-                   int64_t wWc, int64_t wUb, int64_t wZ, int64_t wH, int64_t wC, int64_t wdH, int64_t wdX) {
+                   int64_t wWc, int64_t wUb, int64_t wZ, int64_t wH, int64_t wC, int64_t wdH, int64_t wdX, bool is_note) {
   const int dt = c.p.c.dtype;
-  RUN(dj_launch_lstm_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUb), c.at(wC), c.at(wdH), G + L.b,
-                         c.p.c.recurrent_sigmoid, c.st));
-  RUN(dj_launch_gemm_tn(dt, M, L.DP, L.D, 4 * L.H, c.at(wX), L.DP, c.at(wZ), 4 * L.H, G + L.W, 4 * L.H, 0, 0, c.st));
-  RUN(dj_launch_gemm_tn(dt, M, L.H, L.H, 4 * L.H, c.at(wH), L.H, c.at(wZ), 4 * L.H, G + L.U, 4 * L.H, 32, steps, c.st));
+  {
+    ProfScope ps(is_note ? PC_LSTM_BWD_NOTE : PC_LSTM_BWD_TIME, c.st);
+    RUN(dj_launch_lstm_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUb), c.at(wC), c.at(wdH), G + L.b,
+                           c.p.c.recurrent_sigmoid, c.st));
+  }
+  {
+    ProfScope ps(PC_GEMM_DW, c.st);
+    RUN(dj_launch_gemm_tn(dt, M, L.DP, L.D, 4 * L.H, c.at(wX), L.DP, c.at(wZ), 4 * L.H, G + L.W, 4 * L.H, 0, 0, c.st));
+    RUN(dj_launch_gemm_tn(dt, M, L.H, L.H, 4 * L.H, c.at(wH), L.H, c.at(wZ), 4 * L.H, G + L.U, 4 * L.H, 32, steps,
+                          c.st));
+  }
   const void* Bt = dt == DJ_F32 ? (const void*)(c.P + L.W) : (const void*)c.at(wWc);
+  ProfScope ps(PC_GEMM_DX, c.st);
   RUN(dj_launch_gemm_nt(dt, (int)M, L.D, 4 * L.H, c.at(wZ), 4 * L.H, Bt, 4 * L.H, c.at(wdX), L.DP, 0, nullptr, c.st));
   return 0;
 }
 
 int style_dense_bwd(const Ctx& c, const LstmP& L, float* G, int64_t w_dpre, bool first) {
   const Plan& p = c.p;
+  ProfScope ps(PC_STYLE_BWD, c.st);
   RUN(dj_launch_dense_small_bwd_w(c.at<float>(p.w_style), (int)p.BT, p.SU, c.at<float>(w_dpre), L.D, G + L.dW,
                                   G + L.db, c.st));
   RUN(dj_launch_dense_small_bwd_x(c.at<float>(w_dpre), (int)p.BT, L.D, c.P + L.dW, p.SU, c.at<float>(p.w_dstyle),
@@ -359,7 +415,7 @@ int32_t dj_train_fwd_bwd(const dj_config* cfg, const float* params, float* grads
   for (int l = p.Ln - 1; l >= 0; --l) {
     const LstmP& L = p.nl[l];
     RUN(lstm_layer_bwd(c, L, G, p.tilesN, p.N, p.Mn, p.w_X_n[l], p.w_Wc_n[l], p.w_Ub_n[l], p.w_Z_n[l], p.w_H_n[l],
-                       p.w_C_n[l], p.w_dH_n, p.w_dX_n));
+                       p.w_C_n[l], p.w_dH_n, p.w_dX_n, true));
     GlueArgs g;
     g.B = p.B; g.T = p.T; g.N = p.N; g.D = L.D; g.DP = L.DP; g.out_na = 1;
     g.sp = c.at<float>(p.w_sp_n[l]); g.chosen = nullptr;
@@ -368,17 +424,19 @@ int32_t dj_train_fwd_bwd(const dj_config* cfg, const float* params, float* grads
     if (l == 0) {
       g.Hd = p.Ht; g.in_na = 0;
       g.d_out = mkdrop(seed, DJ_SITE_TOUT + (p.Lt - 1), pdr, true);
+      ProfScope ps(PC_GLUE_BWD, c.st);
       RUN(dj_launch_glue_bwd(dt, &g, c.at(p.w_dX_n), c.at(p.w_dH_t), c.at<float>(p.w_dpre_n[l]), c.st));
     } else {
       g.Hd = p.Hn; g.in_na = 1;
       g.d_out = mkdrop(seed, DJ_SITE_NOUT + (l - 1), pdr, true);
+      ProfScope ps(PC_GLUE_BWD, c.st);
       RUN(dj_launch_glue_bwd(dt, &g, c.at(p.w_dX_n), c.at(p.w_dH_n), c.at<float>(p.w_dpre_n[l]), c.st));
     }
   }
   for (int l = p.Lt - 1; l >= 0; --l) {
     const LstmP& L = p.tl[l];
     RUN(lstm_layer_bwd(c, L, G, p.tilesT, p.T, p.Mt, p.w_X_t[l], p.w_Wc_t[l], p.w_Ub_t[l], p.w_Z_t[l], p.w_H_t[l],
-                       p.w_C_t[l], p.w_dH_t, p.w_dX_t));
+                       p.w_C_t[l], p.w_dH_t, p.w_dX_t, false));
     if (l > 0) {
       GlueArgs g;
       g.B = p.B; g.T = p.T; g.N = p.N; g.Hd = p.Ht; g.D = L.D; g.DP = L.DP; g.in_na = 0; g.out_na = 0;
@@ -386,6 +444,7 @@ int32_t dj_train_fwd_bwd(const dj_config* cfg, const float* params, float* grads
       g.d_out = mkdrop(seed, DJ_SITE_TOUT + (l - 1), pdr, true);
       g.d_style = mkdrop(seed, DJ_SITE_TSTYLE + l, pdr, true);
       g.d_chosen = mkdrop(seed, DJ_SITE_CHOSEN, pin, true);
+      ProfScope ps(PC_GLUE_BWD, c.st);
       RUN(dj_launch_glue_bwd(dt, &g, c.at(p.w_dX_t), c.at(p.w_dH_t), c.at<float>(p.w_dpre_t[l]), c.st));
     } else {
       FeatArgs fa;
@@ -394,6 +453,7 @@ int32_t dj_train_fwd_bwd(const dj_config* cfg, const float* params, float* grads
       fa.B = p.B; fa.T = p.T; fa.N = p.N; fa.NB = p.NB; fa.octave = p.c.octave; fa.F = p.F; fa.FP = p.FP;
       fa.d_notes = mkdrop(seed, DJ_SITE_NOTES, pin, true); fa.d_beat = mkdrop(seed, DJ_SITE_BEAT, pin, true);
       fa.d_conv = mkdrop(seed, DJ_SITE_CONV, pdr, true); fa.d_style = mkdrop(seed, DJ_SITE_TSTYLE + 0, pdr, true);
+      ProfScope ps(PC_FEATURE_BWD, c.st);
       RUN(dj_launch_feature_bwd(dt, &fa, c.at(p.w_dX_t), G + p.p_conv_W, G + p.p_conv_b,
                                 c.at<float>(p.w_dpre_t[0]), c.st));
     }
@@ -402,6 +462,7 @@ int32_t dj_train_fwd_bwd(const dj_config* cfg, const float* params, float* grads
   bool first = true;
   for (int l = 0; l < p.Lt; ++l) { RUN(style_dense_bwd(c, p.tl[l], G, p.w_dpre_t[l], first)); first = false; }
   for (int l = 0; l < p.Ln; ++l) { RUN(style_dense_bwd(c, p.nl[l], G, p.w_dpre_n[l], first)); first = false; }
+  ProfScope ps(PC_STYLE_BWD, c.st);
   RUN(dj_launch_dense_small_bwd_w(style, (int)p.BT, p.S, c.at<float>(p.w_dstyle), p.SU, G + p.p_style_W,
                                   G + p.p_style_b, c.st));
   return 0;
@@ -423,6 +484,7 @@ int32_t dj_nadam_step(float* params, const float* grads, float* m, float* v, int
   a.bc2 = (float)(1.0 - pow((double)beta2, t));
   a.gscale = grad_scale;
   *m_schedule = ms_new;
+  ProfScope ps(PC_NADAM, (hipStream_t)stream);
   return dj_launch_nadam(params, grads, m, v, count, &a, (hipStream_t)stream);
 }
 
@@ -468,6 +530,32 @@ int32_t dj_note_model_predict(const dj_config* cfg, const float* params, const f
   RUN(style_forward(c, style));
   RUN(dj_launch_canonical_to_na(p.c.dtype, features, c.at(p.w_featin), p.B, p.T, p.N, p.Ht, c.st));
   RUN(note_axis_forward(c, p.w_featin, 1, -1, chosen, nullptr, out, nullptr, nullptr));
+  return 0;
+}
+
+// ------------------------------------------------------------------ live kernel timing
+int32_t dj_profile_enable(int32_t on) {
+  for (auto& r : g_prof.recs) { g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b); }
+  g_prof.recs.clear();
+  g_prof.on = on != 0;
+  return 0;
+}
+int32_t dj_profile_category_count(void) { return PC_COUNT; }
+const char* dj_profile_category_name(int32_t cat) { return (cat >= 0 && cat < PC_COUNT) ? kProfNames[cat] : ""; }
+int32_t dj_profile_read(int32_t cat, double* total_ms, int64_t* scopes) {
+  if (cat < 0 || cat >= PC_COUNT || !total_ms || !scopes) return 1240;
+  double tot = 0;
+  int64_t n = 0;
+  for (auto& r : g_prof.recs) {
+    if (r.cat != cat) continue;
+    DJ_CHECK(hipEventSynchronize(r.b));
+    float ms = 0;
+    DJ_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+    tot += ms;
+    ++n;
+  }
+  *total_ms = tot;
+  *scopes = n;
   return 0;
 }
 
