@@ -50,6 +50,22 @@ def launches_per_step(cfg):
             "lstm_bwd_time": Lt, "lstm_fwd_note": Ln, "lstm_bwd_note": Ln}
 
 
+def cpu_share():
+    """CPU cores this process may really use: affinity mask capped by the cgroup quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(cfg, T, N, sample_b, pin, pdr):
     """CPU oracle (torch-CPU fp32 restatement of the reference) on a bounded sample of the
     same workload: sample_b sequences of the B=64 batch, one forward + BPTT + Nadam step."""
@@ -58,11 +74,7 @@ def cpu_baseline(cfg, T, N, sample_b, pin, pdr):
     ocfg = O.OracleConfig(num_notes=N, time_steps=T, time_axis_units=cfg.time_axis_units,
                           note_axis_units=cfg.note_axis_units, time_axis_layers=cfg.time_axis_layers,
                           note_axis_layers=cfg.note_axis_layers)
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = cpu_share()
     torch.set_num_threads(cores)
     params = O.init_params(ocfg, seed=1234)
     batch = synthetic_batch(N, T, sample_b, seed=0)
@@ -88,7 +100,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
     ap.add_argument("--time-steps", type=int, default=128)
     ap.add_argument("--notes", type=int, default=128)
-    ap.add_argument("--cpu-sample", type=int, default=4, help="sequences in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2, help="sequences in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
 

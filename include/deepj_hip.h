@@ -96,10 +96,14 @@ int32_t dj_note_model_predict(const dj_config* cfg, const float* params, const f
 
 /* ---- single-kernel entry points (unit-tested against the oracle one by one) ---- */
 
-/* C[M,N] = A[M,K] * Bt[N,K]^T + bias[N]; operands in cfg dtype, C in operand dtype
- * (c_is_f32 = 0) or fp32.  The x*W products of the Keras LSTM layers (model.py:84,122). */
+/* C[M,N] = A[M,K] * Bt[N,K]^T + bias[N]; operands in `dtype`.  c_mode: 0 = row-major C in the
+ * operand dtype, 1 = row-major fp32, 2 = FRAGMENT-TILED C in the operand dtype (the layout
+ * dj_lstm_fwd consumes: 32x32 block (rb, cb) stored as [64 lanes][16 accumulator registers];
+ * element (s, c) of the block at ((rb*(N/32) + cb)*64 + 32*((s>>2)&1) + c)*16 + (s&3) + 4*(s>>3);
+ * needs M % 32 == 0 and N % 32 == 0).  The x*W products of the Keras LSTM layers
+ * (model.py:84,122) and the BPTT input gradient dX = dZ * W^T. */
 int32_t dj_gemm_nt(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* Bt,
-                   int32_t ldb, void* C, int32_t ldc, int32_t c_is_f32, const float* bias, void* stream);
+                   int32_t ldb, void* C, int32_t ldc, int32_t c_mode, const float* bias, void* stream);
 /* C[ka_valid,N] += A[M,Ka]^T * B[M,N] (fp32 atomics).  a_shift = 32 with steps > 0 reads
  * A one recurrence step earlier (zeros at step 0): the recurrent-kernel gradient. */
 int32_t dj_gemm_tn(int32_t dtype, int64_t M, int32_t Ka, int32_t ka_valid, int32_t N, const void* A, int32_t lda,
@@ -107,15 +111,17 @@ int32_t dj_gemm_tn(int32_t dtype, int64_t M, int32_t Ka, int32_t ka_valid, int32
 /* Pack a Keras recurrent_kernel U[H,4H] (fp32) into MFMA B-fragment order for the
  * forward (U) and backward (U^T) recurrences; each output holds H*4H operand elements. */
 int32_t dj_lstm_pack(int32_t dtype, int32_t H, const float* U, void* upack_fwd, void* upack_bwd, void* stream);
-/* Recurrent sweep over `steps` for ntiles*32 sequences.  Z [ntiles*steps*32, 4H] holds
- * x*W+b on entry and the pre-activations on exit; h -> Hout, c -> Cout (may be NULL).
+/* Recurrent sweep over `steps` for ntiles*32 sequences.  Z (fragment-tiled, see dj_gemm_nt
+ * c_mode 2; [ntiles*steps*32, 4H] logical) holds x*W+b on entry and the pre-activations on
+ * exit; h -> Hout (row-major [rows, H]); c -> Cout (fragment-tiled [rows, H], may be NULL).
  * Row order: ((tile*steps + step)*32 + seq_in_tile). */
 int32_t dj_lstm_fwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, void* Z, const void* upack_fwd,
                     void* Hout, void* Cout, int32_t recurrent_sigmoid, void* stream);
-/* BPTT sweep: Z holds pre-activations on entry, dz on exit; dH = dL/dh per step;
+/* BPTT sweep: Z / C = the forward's fragment-tiled pre-activations / cell states; dH = dL/dh
+ * per step (row-major [rows, H]); dZ (row-major [rows, 4H]) receives dL/dz;
  * dbias[4H] += column sums of dz. */
-int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, void* Z, const void* upack_bwd,
-                    const void* C, const void* dH, float* dbias, int32_t recurrent_sigmoid, void* stream);
+int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack_bwd,
+                    const void* C, const void* dH, void* dZ, float* dbias, int32_t recurrent_sigmoid, void* stream);
 /* mask[rows, cols] (fp32 0 or 1/(1-p)) of dropout site `site` -- exposes the counter
  * hash so tests can pin it against the oracle. */
 int32_t dj_dropout_mask(uint64_t seed, int32_t site, float p, int64_t rows, int32_t cols, float* mask, void* stream);

@@ -46,7 +46,7 @@ _SIGS = {
                                _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "dj_lstm_pack": (C.c_int32, [C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "dj_lstm_fwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P]),
-    "dj_lstm_bwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P]),
+    "dj_lstm_bwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "dj_dropout_mask": (C.c_int32, [C.c_uint64, C.c_int32, C.c_float, C.c_int64, C.c_int32, _P, _P]),
     "dj_profile_enable": (C.c_int32, [C.c_int32]),
     "dj_profile_category_count": (C.c_int32, []),
@@ -62,6 +62,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so (same SONAME as /opt/rocm's).  Import torch first
+    # so that our library binds to the HIP runtime torch's tensors/streams live in; loaded the
+    # other way round the process ends up with two runtimes (hipErrorNoDevice on first use).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise DeepJError(
             f"{LIB_PATH} is missing: build it with `python -m music_generator_amd.build` "

@@ -67,7 +67,7 @@ struct Plan {
   int64_t w_Wt_n[MAXL], w_Wc_n[MAXL], w_Uf_n[MAXL], w_Ub_n[MAXL];
   int64_t w_X_t[MAXL], w_Z_t[MAXL], w_H_t[MAXL], w_C_t[MAXL];
   int64_t w_X_n[MAXL], w_Z_n[MAXL], w_H_n[MAXL], w_C_n[MAXL];
-  int64_t w_dH_t, w_dX_t, w_dH_n, w_dX_n, w_featin;
+  int64_t w_dH_t, w_dX_t, w_dH_n, w_dX_n, w_featin, w_dZ_t, w_dZ_n;
   int64_t ws_bytes;
 };
 
@@ -144,6 +144,8 @@ int make_plan(const dj_config* cfg, Plan& p) {
   p.w_dH_t = wtake(p.Mt * p.Ht * p.esz); p.w_dX_t = wtake(p.Mt * maxDPt * p.esz);
   p.w_dH_n = wtake(p.Mn * p.Hn * p.esz); p.w_dX_n = wtake(p.Mn * maxDPn * p.esz);
   p.w_featin = wtake(p.Mn * p.Ht * p.esz);   // note_model.predict: features in NA order
+  p.w_dZ_t = wtake(p.Mt * 4 * p.Ht * p.esz);  // row-major dz of the layer in flight (BPTT)
+  p.w_dZ_n = wtake(p.Mn * 4 * p.Hn * p.esz);
   p.ws_bytes = w;
   return 0;
 }
@@ -200,7 +202,7 @@ int lstm_layer_fwd(const Ctx& c, const LstmP& L, int64_t tiles, int steps, int64
   const int dt = c.p.c.dtype;
   {
     ProfScope ps(PC_GEMM_XW, c.st);
-    RUN(dj_launch_gemm_nt(dt, (int)M, 4 * L.H, L.DP, c.at(wX), L.DP, c.at(wWt), L.DP, c.at(wZ), 4 * L.H, 0,
+    RUN(dj_launch_gemm_nt(dt, (int)M, 4 * L.H, L.DP, c.at(wX), L.DP, c.at(wWt), L.DP, c.at(wZ), 4 * L.H, 2,
                           c.P + L.b, c.st));
   }
   ProfScope ps(is_note ? PC_LSTM_FWD_NOTE : PC_LSTM_FWD_TIME, c.st);
@@ -292,22 +294,22 @@ int note_axis_forward(const Ctx& c, int64_t wHin, int in_na, int d_out_site, con
 }
 
 int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int steps, int64_t M, int64_t wX,
-                   int64_t wWc, int64_t wUb, int64_t wZ, int64_t wH, int64_t wC, int64_t wdH, int64_t wdX, bool is_note) {
+                   int64_t wWc, int64_t wUb, int64_t wZ, int64_t wH, int64_t wC, int64_t wdH, int64_t wdX, int64_t wdZ, bool is_note) {
   const int dt = c.p.c.dtype;
   {
     ProfScope ps(is_note ? PC_LSTM_BWD_NOTE : PC_LSTM_BWD_TIME, c.st);
-    RUN(dj_launch_lstm_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUb), c.at(wC), c.at(wdH), G + L.b,
+    RUN(dj_launch_lstm_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUb), c.at(wC), c.at(wdH), c.at(wdZ), G + L.b,
                            c.p.c.recurrent_sigmoid, c.st));
   }
   {
     ProfScope ps(PC_GEMM_DW, c.st);
-    RUN(dj_launch_gemm_tn(dt, M, L.DP, L.D, 4 * L.H, c.at(wX), L.DP, c.at(wZ), 4 * L.H, G + L.W, 4 * L.H, 0, 0, c.st));
-    RUN(dj_launch_gemm_tn(dt, M, L.H, L.H, 4 * L.H, c.at(wH), L.H, c.at(wZ), 4 * L.H, G + L.U, 4 * L.H, 32, steps,
+    RUN(dj_launch_gemm_tn(dt, M, L.DP, L.D, 4 * L.H, c.at(wX), L.DP, c.at(wdZ), 4 * L.H, G + L.W, 4 * L.H, 0, 0, c.st));
+    RUN(dj_launch_gemm_tn(dt, M, L.H, L.H, 4 * L.H, c.at(wH), L.H, c.at(wdZ), 4 * L.H, G + L.U, 4 * L.H, 32, steps,
                           c.st));
   }
   const void* Bt = dt == DJ_F32 ? (const void*)(c.P + L.W) : (const void*)c.at(wWc);
   ProfScope ps(PC_GEMM_DX, c.st);
-  RUN(dj_launch_gemm_nt(dt, (int)M, L.D, 4 * L.H, c.at(wZ), 4 * L.H, Bt, 4 * L.H, c.at(wdX), L.DP, 0, nullptr, c.st));
+  RUN(dj_launch_gemm_nt(dt, (int)M, L.D, 4 * L.H, c.at(wdZ), 4 * L.H, Bt, 4 * L.H, c.at(wdX), L.DP, 0, nullptr, c.st));
   return 0;
 }
 
@@ -415,7 +417,7 @@ int32_t dj_train_fwd_bwd(const dj_config* cfg, const float* params, float* grads
   for (int l = p.Ln - 1; l >= 0; --l) {
     const LstmP& L = p.nl[l];
     RUN(lstm_layer_bwd(c, L, G, p.tilesN, p.N, p.Mn, p.w_X_n[l], p.w_Wc_n[l], p.w_Ub_n[l], p.w_Z_n[l], p.w_H_n[l],
-                       p.w_C_n[l], p.w_dH_n, p.w_dX_n, true));
+                       p.w_C_n[l], p.w_dH_n, p.w_dX_n, p.w_dZ_n, true));
     GlueArgs g;
     g.B = p.B; g.T = p.T; g.N = p.N; g.D = L.D; g.DP = L.DP; g.out_na = 1;
     g.sp = c.at<float>(p.w_sp_n[l]); g.chosen = nullptr;
@@ -436,7 +438,7 @@ int32_t dj_train_fwd_bwd(const dj_config* cfg, const float* params, float* grads
   for (int l = p.Lt - 1; l >= 0; --l) {
     const LstmP& L = p.tl[l];
     RUN(lstm_layer_bwd(c, L, G, p.tilesT, p.T, p.Mt, p.w_X_t[l], p.w_Wc_t[l], p.w_Ub_t[l], p.w_Z_t[l], p.w_H_t[l],
-                       p.w_C_t[l], p.w_dH_t, p.w_dX_t, false));
+                       p.w_C_t[l], p.w_dH_t, p.w_dX_t, p.w_dZ_t, false));
     if (l > 0) {
       GlueArgs g;
       g.B = p.B; g.T = p.T; g.N = p.N; g.Hd = p.Ht; g.D = L.D; g.DP = L.DP; g.in_na = 0; g.out_na = 0;
@@ -561,9 +563,10 @@ int32_t dj_profile_read(int32_t cat, double* total_ms, int64_t* scopes) {
 
 // ------------------------------------------------------------------ single-kernel entry points
 int32_t dj_gemm_nt(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* Bt,
-                   int32_t ldb, void* C, int32_t ldc, int32_t c_is_f32, const float* bias, void* stream) {
+                   int32_t ldb, void* C, int32_t ldc, int32_t c_mode, const float* bias, void* stream) {
   if (dtype != DJ_F32 && dtype != DJ_BF16) return 1106;
-  return dj_launch_gemm_nt(dtype, M, N, K, A, lda, Bt, ldb, C, ldc, c_is_f32, bias, (hipStream_t)stream);
+  if (c_mode < 0 || c_mode > 2) return 1005;
+  return dj_launch_gemm_nt(dtype, M, N, K, A, lda, Bt, ldb, C, ldc, c_mode, bias, (hipStream_t)stream);
 }
 int32_t dj_gemm_tn(int32_t dtype, int64_t M, int32_t Ka, int32_t ka_valid, int32_t N, const void* A, int32_t lda,
                    const void* B, int32_t ldb, float* C, int32_t ldc, int32_t a_shift, int32_t steps, void* stream) {
@@ -578,9 +581,9 @@ int32_t dj_lstm_fwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, voi
                     void* Cout, int32_t sigm, void* stream) {
   return dj_launch_lstm_fwd(dtype, H, ntiles, steps, Z, upack, Hout, Cout, sigm, 1, (hipStream_t)stream);
 }
-int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, void* Z, const void* upack,
-                    const void* C, const void* dH, float* dbias, int32_t sigm, void* stream) {
-  return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dbias, sigm, (hipStream_t)stream);
+int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack,
+                    const void* C, const void* dH, void* dZ, float* dbias, int32_t sigm, void* stream) {
+  return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dbias, sigm, (hipStream_t)stream);
 }
 
 __global__ void dropout_mask_kernel(DjDrop d, int64_t rows, int cols, float* mask) {

@@ -52,7 +52,7 @@ __device__ __forceinline__ void mma_tile(const T* As, const T* Bs, f32x16 (&acc)
 template <typename T, typename TC>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const T* __restrict__ A, int lda,
                                                       const T* __restrict__ Bt, int ldb, TC* __restrict__ C, int ldc,
-                                                      const float* __restrict__ bias, int ntn) {
+                                                      const float* __restrict__ bias, int ntn, int c_frag) {
   using G = GemmCfg<T>;
   __shared__ __attribute__((aligned(16))) T As[128 * G::LDT];
   __shared__ __attribute__((aligned(16))) T Bs[128 * G::LDT];
@@ -112,6 +112,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const
       int col = n0 + wc * 64 + j * 32 + l31;
       if (col >= N) continue;
       float bv = bias ? bias[col] : 0.f;
+      if (c_frag) {
+        // fragment-tiled output for the recurrent kernels (dj_lstm.hip): block (rb, cb) as [lane][16]
+        int rowb = m0 + wr * 64 + i * 32;
+        if (rowb < M) {
+          float x[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x[r] = acc[i][j][r] + bv;
+          int64_t rb = rowb >> 5, cb = (n0 + wc * 64 + j * 32) >> 5;
+          store_frag(C + ((rb * (N >> 5) + cb) * 64 + lane) * 16, x);
+        }
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int row = m0 + wr * 64 + i * 32 + dj_crow(r, lane);
@@ -319,21 +331,23 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(int64_t M, int Ka, in
 
 // ------------------------------------------------------------------ launchers (internal C++ API)
 int dj_launch_gemm_nt(int dtype, int M, int N, int K, const void* A, int lda, const void* Bt, int ldb, void* C, int ldc,
-                      int c_is_f32, const float* bias, hipStream_t st) {
+                      int c_mode, const float* bias, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int epl = dtype == DJ_F32 ? 4 : 8;
   if ((K % epl) || (lda % epl) || (ldb % epl)) return 1001;
+  const int c_is_f32 = c_mode == 1, c_frag = c_mode == 2;
+  if (c_frag && ((M % 32) || (N % 32))) return 1004;
   int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
   dim3 grid((unsigned)(ntn * (int64_t)ntm)), block(256);
   if (dtype == DJ_F32) {
     hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, block, 0, st, M, N, K, (const float*)A, lda,
-                       (const float*)Bt, ldb, (float*)C, ldc, bias, ntn);
+                       (const float*)Bt, ldb, (float*)C, ldc, bias, ntn, c_frag);
   } else if (c_is_f32) {
     hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, block, 0, st, M, N, K, (const bf16_t*)A, lda,
-                       (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn);
+                       (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn, c_frag);
   } else {
     hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, block, 0, st, M, N, K, (const bf16_t*)A, lda,
-                       (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn);
+                       (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn, c_frag);
   }
   return (int)hipGetLastError();
 }

@@ -51,15 +51,15 @@ struct NadamArgs {
 
 // dj_gemm.hip
 int dj_launch_gemm_nt(int dtype, int M, int N, int K, const void* A, int lda, const void* Bt, int ldb, void* C, int ldc,
-                      int c_is_f32, const float* bias, hipStream_t st);
+                      int c_mode, const float* bias, hipStream_t st);
 int dj_launch_gemm_tn(int dtype, int64_t M, int Ka, int ka_valid, int N, const void* A, int lda, const void* B, int ldb, float* C,
                       int ldc, int a_shift, int steps, hipStream_t st);
 // dj_lstm.hip
 int dj_launch_lstm_pack(int dtype, int H, const float* U, void* fwd, void* bwd, hipStream_t st);
 int dj_launch_lstm_fwd(int dtype, int H, int ntiles, int steps, void* Z, const void* Upack, void* Hout, void* Cout,
                        int sigm, int store_z, hipStream_t st);
-int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, void* Z, const void* UTpack, const void* C,
-                       const void* dH, float* dbias, int sigm, hipStream_t st);
+int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* UTpack, const void* C,
+                       const void* dH, void* dZ, float* dbias, int sigm, hipStream_t st);
 // dj_elem.hip
 int dj_launch_dense_small(const float* A, int M, int K, const float* W, const float* b, float* C, int N, int act_tanh,
                           hipStream_t st);

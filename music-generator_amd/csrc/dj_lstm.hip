@@ -6,14 +6,23 @@
 // i,f,o = hard_sigmoid (switchable to sigmoid), g = tanh; c' = f c + i g;
 // h' = o tanh(c'); zero initial state.
 //
-// One 256-thread workgroup owns a tile of 32 independent sequences for ALL steps
-// (no inter-workgroup traffic).  Wave w owns hidden units [w*H/4, (w+1)*H/4) and
+// One workgroup of H/32 waves owns a tile of 32 independent sequences for ALL steps
+// (no inter-workgroup traffic).  Wave w owns hidden units [32w, 32w+32) and
 // all four gate columns of those units, so the cell update is lane-local in the
 // MFMA accumulator layout.  h_{t-1} lives in LDS (A operand); the recurrent
 // kernel U is streamed every step from L2 as pre-packed MFMA B fragments (one
-// coalesced 1 KiB wave-load per fragment).  x_t W + b arrives precomputed in Z
-// (dj_gemm_nt) and is overwritten in place by the pre-activations z_t (the BPTT
-// stash), which backward overwrites in place again with dz_t.
+// coalesced 1 KiB wave-load per fragment, software-pipelined PD chunks ahead).
+//
+// Data layouts in HBM:
+//  * Z  (x_t W + b in, pre-activations z_t out, in place) and the cell stash C are
+//    FRAGMENT-TILED: for 32-row block rb (= tile*steps + step) and 32-col block cb,
+//    the 32x32 block is stored as [lane 0..63][16 accumulator registers], i.e.
+//    element (s, c) of the block sits at ((rb*NCB + cb)*64 + 32*((s>>2)&1) + c)*16
+//    + (s&3) + 4*(s>>3).  dj_gemm_nt writes this layout from its accumulators, and
+//    both recurrent kernels read/write it with 16-byte per-lane accesses that are
+//    perfectly coalesced -- no scalar loads, no partial-line writes.
+//  * h (Hout), dH and dz are ROW-MAJOR [rows, cols] (they feed the GEMMs and the
+//    glue kernels) and go through LDS for wide coalesced rows.
 #include "dj_kernels.h"
 
 namespace {
@@ -21,14 +30,69 @@ namespace {
 template <typename T, int H> struct RecCfg {
   static constexpr int EPL = 16 / sizeof(T);
   static constexpr int KC = 2 * EPL;
-  static constexpr int UW = H / 4;        // units per wave
-  static constexpr int NJ = UW / 32;      // 32-col tiles per gate per wave
+  static constexpr int UW = 32;           // hidden units per wave (one 32-col MFMA tile per gate)
+  static constexpr int NJ = 1;            // 32-col tiles per gate per wave
+  static constexpr int NW = H / UW;       // waves per workgroup (H=128: 4, H=256: 8 = 2 per SIMD)
+  static constexpr int NT = 64 * NW;      // threads per workgroup
   static constexpr int NKC = H / KC;      // k-chunks of the forward product (K = H)
   static constexpr int NKCB = 4 * H / KC; // k-chunks of the backward product (K = 4H)
   static constexpr int LDH = H + EPL;     // LDS row stride of the h tile
   static constexpr int LDZ = 4 * H + EPL; // LDS row stride of the dz tile
+  static constexpr int NCB = 4 * H / 32;  // 32-col blocks of Z
+  static constexpr int NCBH = H / 32;     // 32-col blocks of C
+  static constexpr int VPT = 16 / EPL;    // 16-byte vectors per 16-register fragment (bf16: 2, f32: 4)
+  static constexpr int PD = 2;            // U prefetch depth in k-chunks
+  static constexpr int UNR = 4;           // k-chunks per unrolled body (multiple of PD)
+  static constexpr bool HOIST = sizeof(T) == 2;   // prefetch Z fragments a step ahead (register budget)
 };
 
+// raw workgroup barrier: waits for this wave's LDS traffic only, so global prefetches
+// and stores stay in flight across it (cdna_hip_programming.md "Pipelining across barriers")
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// 16 accumulator values <-> fragment-tiled memory
+template <typename T> struct Frag16;
+template <> struct Frag16<float> {
+  uint4 v[4];
+  __device__ __forceinline__ void load(const float* p) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = ((const uint4*)p)[i];
+  }
+  __device__ __forceinline__ void store(float* p) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ((uint4*)p)[i] = v[i];
+  }
+  __device__ __forceinline__ float get(int r) const {
+    const uint4& q = v[r >> 2];
+    uint32_t w = (r & 3) == 0 ? q.x : (r & 3) == 1 ? q.y : (r & 3) == 2 ? q.z : q.w;
+    return __uint_as_float(w);
+  }
+  __device__ __forceinline__ void copy_from(const Frag16& o) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = o.v[i];
+  }
+};
+template <> struct Frag16<bf16_t> {
+  uint4 v[2];
+  __device__ __forceinline__ void load(const bf16_t* p) {
+    v[0] = ((const uint4*)p)[0];
+    v[1] = ((const uint4*)p)[1];
+  }
+  __device__ __forceinline__ void store(bf16_t* p) const {
+    ((uint4*)p)[0] = v[0];
+    ((uint4*)p)[1] = v[1];
+  }
+  __device__ __forceinline__ float get(int r) const {
+    const uint4& q = v[r >> 3];
+    const int d = (r >> 1) & 3;
+    uint32_t w = d == 0 ? q.x : d == 1 ? q.y : d == 2 ? q.z : q.w;
+    return __uint_as_float((r & 1) ? (w & 0xFFFF0000u) : (w << 16));
+  }
+  __device__ __forceinline__ void copy_from(const Frag16& o) {
+    v[0] = o.v[0];
+    v[1] = o.v[1];
+  }
+};
 // ---------------------------------------------------------------- weight packing
 // Upack[(((w*4+g)*NJ+j)*NKC + kc)*64 + lane][e] = U[kc*KC + EPL*h + e][g*H + w*UW + j*32 + l31]
 template <typename T, int H>
@@ -62,9 +126,9 @@ __global__ void pack_u_bwd_kernel(const float* __restrict__ U, T* __restrict__ o
 }
 
 // ---------------------------------------------------------------- forward
-template <typename T, int H>
-__global__ __launch_bounds__(256) void lstm_fwd_kernel(T* __restrict__ Z, const T* __restrict__ Upack,
-                                                       T* __restrict__ Hout, T* __restrict__ Cout, int steps, int sigm,
+template <typename T, int H, bool SIGM>
+__global__ __launch_bounds__(2 * H) void lstm_fwd_kernel(T* __restrict__ Z, const T* __restrict__ Upack,
+                                                       T* __restrict__ Hout, T* __restrict__ Cout, int steps,
                                                        int store_z) {
   using R = RecCfg<T, H>;
   using Frag = typename DjFrag<T>::type;
@@ -79,77 +143,114 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(T* __restrict__ Z, const 
     for (int r = 0; r < 16; ++r) c[j][r] = 0.f;
 
   const Frag* up = (const Frag*)Upack + (int64_t)w * 4 * R::NJ * R::NKC * 64 + lane;
+  // fragment addresses of this lane: Z block (g, j) and C block j of row-block rb
+  auto zaddr = [&](int64_t rb, int g, int j) {
+    return Z + ((rb * R::NCB + (g * H + w * R::UW + j * 32) / 32) * 64 + lane) * 16;
+  };
+  auto caddr = [&](int64_t rb, int j) { return Cout + ((rb * R::NCBH + (w * R::UW + j * 32) / 32) * 64 + lane) * 16; };
+
+  Frag16<T> zin[4][R::NJ];
+  if constexpr (R::HOIST) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < R::NJ; ++j) zin[g][j].load(zaddr(tile * steps, g, j));
+  }
+
   int cur = 0;
   for (int t = 0; t < steps; ++t) {
-    const int64_t rowbase = (tile * steps + t) * 32;
+    const int64_t rb = tile * steps + t;
+    if constexpr (!R::HOIST) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < R::NJ; ++j) zin[g][j].load(zaddr(rb, g, j));
+    }
     f32x16 acc[4][R::NJ];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int j = 0; j < R::NJ; ++j) {
-        const T* zp = Z + rowbase * (4 * H) + g * H + w * R::UW + j * 32 + l31;
+      for (int j = 0; j < R::NJ; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[g][j][r] = dj_to_f32(zp[(int64_t)dj_crow(r, lane) * (4 * H)]);
-      }
-    if (t > 0) {
-      const T* hp = hs[cur] + l31 * R::LDH;
-#pragma unroll 4
-      for (int kc = 0; kc < R::NKC; ++kc) {
-        Frag a = dj_lds_frag(hp + kc * R::KC, h);
+        for (int r = 0; r < 16; ++r) acc[g][j][r] = zin[g][j].get(r);
+    // prefetch next step's x*W+b fragments (land during the MFMA phase)
+    if constexpr (R::HOIST) {
+      if (t + 1 < steps) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int j = 0; j < R::NJ; ++j) {
-            Frag b = up[((g * R::NJ + j) * R::NKC + kc) * 64];
-            dj_mfma(acc[g][j], a, b);
-          }
+          for (int j = 0; j < R::NJ; ++j) zin[g][j].load(zaddr(rb + 1, g, j));
+      }
+    }
+    if (t > 0) {
+      const T* hp = hs[cur] + l31 * R::LDH;
+      Frag bq[R::PD][4 * R::NJ];
+#pragma unroll
+      for (int p = 0; p < R::PD; ++p)
+#pragma unroll
+        for (int q = 0; q < 4 * R::NJ; ++q) bq[p][q] = up[(q * R::NKC + p) * 64];
+#pragma unroll 1
+      for (int kc0 = 0; kc0 < R::NKC; kc0 += R::UNR) {
+#pragma unroll
+        for (int u = 0; u < R::UNR; ++u) {
+          const int kc = kc0 + u;
+          Frag a = dj_lds_frag(hp + kc * R::KC, h);
+#pragma unroll
+          for (int q = 0; q < 4 * R::NJ; ++q) dj_mfma(acc[q / R::NJ][q % R::NJ], a, bq[u % R::PD][q]);
+          const int kn = (kc + R::PD < R::NKC) ? kc + R::PD : R::NKC - 1;   // clamped: tail reloads are harmless
+#pragma unroll
+          for (int q = 0; q < 4 * R::NJ; ++q) bq[u % R::PD][q] = up[(q * R::NKC + kn) * 64];
+        }
       }
     }
     T* hn = hs[cur ^ 1];
 #pragma unroll
     for (int j = 0; j < R::NJ; ++j) {
       const int u = w * R::UW + j * 32 + l31;
+      float cv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = dj_crow(r, lane);
         float zi = acc[0][j][r], zf = acc[1][j][r], zg = acc[2][j][r], zo = acc[3][j][r];
-        float ig = dj_ract(zi, sigm), fg = dj_ract(zf, sigm), gg = dj_tanh(zg), og = dj_ract(zo, sigm);
+        float ig = dj_ract<SIGM>(zi), fg = dj_ract<SIGM>(zf), gg = dj_tanh(zg), og = dj_ract<SIGM>(zo);
         float cn = fg * c[j][r] + ig * gg;
         c[j][r] = cn;
-        float hv = og * dj_tanh(cn);
-        hn[row * R::LDH + u] = dj_from_f32<T>(hv);
-        const int64_t grow = rowbase + row;
-        if (store_z) {
-          T* zp = Z + grow * (4 * H) + u;
-          zp[0] = dj_from_f32<T>(zi);
-          zp[H] = dj_from_f32<T>(zf);
-          zp[2 * H] = dj_from_f32<T>(zg);
-          zp[3 * H] = dj_from_f32<T>(zo);
+        cv[r] = cn;
+        hn[row * R::LDH + u] = dj_from_f32<T>(og * dj_tanh(cn));
+      }
+      if (Cout) store_frag(caddr(rb, j), cv);
+      if (store_z) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float zv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) zv[r] = acc[g][j][r];
+          store_frag(zaddr(rb, g, j), zv);
         }
-        if (Cout) Cout[grow * H + u] = dj_from_f32<T>(cn);
       }
     }
-    __syncthreads();
+    lds_barrier();
     // cooperative, coalesced copy of h_t (32 x H) to global
     constexpr int VPR = H / R::EPL;
 #pragma unroll
-    for (int v = tid; v < 32 * VPR; v += 256) {
+    for (int v = tid; v < 32 * VPR; v += R::NT) {
       int row = v / VPR, cv = (v % VPR) * R::EPL;
-      *(uint4*)(Hout + (rowbase + row) * H + cv) = *(const uint4*)(hn + row * R::LDH + cv);
+      *(uint4*)(Hout + (rb * 32 + row) * H + cv) = *(const uint4*)(hn + row * R::LDH + cv);
     }
     cur ^= 1;
   }
 }
 
 // ---------------------------------------------------------------- backward (BPTT)
-template <typename T, int H>
-__global__ __launch_bounds__(256) void lstm_bwd_kernel(T* __restrict__ Z, const T* __restrict__ UTpack,
+// Z: fragment-tiled pre-activations (read only); dZ: row-major [M,4H] output.
+template <typename T, int H, bool SIGM>
+__global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z, const T* __restrict__ UTpack,
                                                        const T* __restrict__ C, const T* __restrict__ dH,
-                                                       float* __restrict__ dbias, int steps, int sigm) {
+                                                       T* __restrict__ dZ, float* __restrict__ dbias, int steps) {
   using R = RecCfg<T, H>;
   using Frag = typename DjFrag<T>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* dzs = (T*)smem_raw;   // [32][LDZ]
+  T* dzs = (T*)smem_raw;   // [32][LDZ]; its first 32*LDH elements double as the dH staging tile
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
   const int64_t tile = blockIdx.x;
 
@@ -167,27 +268,72 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(T* __restrict__ Z, const 
     for (int g = 0; g < 4; ++g) dbs[g][j] = 0.f;
   }
   const Frag* up = (const Frag*)UTpack + (int64_t)w * R::NJ * R::NKCB * 64 + lane;
+  auto zaddr = [&](int64_t rb, int g, int j) {
+    return Z + ((rb * R::NCB + (g * H + w * R::UW + j * 32) / 32) * 64 + lane) * 16;
+  };
+  auto caddr = [&](int64_t rb, int j) { return C + ((rb * R::NCBH + (w * R::UW + j * 32) / 32) * 64 + lane) * 16; };
+
+  // dH tile (32 x H, row-major): each thread stages NV 16-byte vectors
+  constexpr int VPR = H / R::EPL, NV = 32 * VPR / R::NT;
+  uint4 dhreg[NV];
+  auto dh_load = [&](int64_t rb) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int v = tid + R::NT * i, row = v / VPR, cv = (v % VPR) * R::EPL;
+      dhreg[i] = *(const uint4*)(dH + (rb * 32 + row) * H + cv);
+    }
+  };
+  Frag16<T> cnext[R::NJ];   // c_t of the step being processed (loaded as c_{t-1} one step earlier)
+  dh_load(tile * steps + steps - 1);
+#pragma unroll
+  for (int j = 0; j < R::NJ; ++j) cnext[j].load(caddr(tile * steps + steps - 1, j));
 
   for (int t = steps - 1; t >= 0; --t) {
-    const int64_t rowbase = (tile * steps + t) * 32;
+    const int64_t rb = tile * steps + t;
+    // stage dH_t into LDS, then pick it up in accumulator layout
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int v = tid + R::NT * i, row = v / VPR, cv = (v % VPR) * R::EPL;
+      *(uint4*)(dzs + row * R::LDH + cv) = dhreg[i];
+    }
+    Frag16<T> zf[4][R::NJ], cprev[R::NJ];
+#pragma unroll
+    for (int j = 0; j < R::NJ; ++j) {
+      if constexpr (R::HOIST) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) zf[g][j].load(zaddr(rb, g, j));
+      }
+      if (t > 0) cprev[j].load(caddr(rb - 1, j));
+    }
+    if (t > 0) dh_load(rb - 1);
+    lds_barrier();
+    float dhv[R::NJ][16];
+#pragma unroll
+    for (int j = 0; j < R::NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        dhv[j][r] = dj_to_f32(dzs[dj_crow(r, lane) * R::LDH + w * R::UW + j * 32 + l31]) + acc[j][r];
+    lds_barrier();
 #pragma unroll
     for (int j = 0; j < R::NJ; ++j) {
       const int u = w * R::UW + j * 32 + l31;
+      if constexpr (!R::HOIST) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) zf[g][j].load(zaddr(rb, g, j));
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = dj_crow(r, lane);
-        const int64_t grow = rowbase + row;
-        const T* zp = Z + grow * (4 * H) + u;
-        float zi = dj_to_f32(zp[0]), zf = dj_to_f32(zp[H]), zg = dj_to_f32(zp[2 * H]), zo = dj_to_f32(zp[3 * H]);
-        float ct = dj_to_f32(C[grow * H + u]);
-        float cp = (t > 0) ? dj_to_f32(C[(grow - 32) * H + u]) : 0.f;
-        float dh = dj_to_f32(dH[grow * H + u]) + acc[j][r];
-        float ig = dj_ract(zi, sigm), fg = dj_ract(zf, sigm), gg = dj_tanh(zg), og = dj_ract(zo, sigm);
+        float zi = zf[0][j].get(r), zfv = zf[1][j].get(r), zg = zf[2][j].get(r), zo = zf[3][j].get(r);
+        float ct = cnext[j].get(r);
+        float cp = (t > 0) ? cprev[j].get(r) : 0.f;
+        float dh = dhv[j][r];
+        float ig = dj_ract<SIGM>(zi), fg = dj_ract<SIGM>(zfv), gg = dj_tanh(zg), og = dj_ract<SIGM>(zo);
         float tc = dj_tanh(ct);
-        float dzo = dh * tc * dj_ract_grad(zo, og, sigm);
+        float dzo = dh * tc * dj_ract_grad<SIGM>(zo, og);
         float dc = dcc[j][r] + dh * og * (1.f - tc * tc);
-        float dzi = dc * gg * dj_ract_grad(zi, ig, sigm);
-        float dzf = dc * cp * dj_ract_grad(zf, fg, sigm);
+        float dzi = dc * gg * dj_ract_grad<SIGM>(zi, ig);
+        float dzf = dc * cp * dj_ract_grad<SIGM>(zfv, fg);
         float dzg = dc * ig * (1.f - gg * gg);
         dcc[j][r] = dc * fg;
         T* dp = dzs + row * R::LDZ + u;
@@ -200,14 +346,15 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(T* __restrict__ Z, const 
         dbs[2][j] += dzg;
         dbs[3][j] += dzo;
       }
+      if (t > 0) cnext[j].copy_from(cprev[j]);
     }
-    __syncthreads();
-    // dz_t tile -> global (in place over z_t), coalesced
-    constexpr int VPR = 4 * H / R::EPL;
+    lds_barrier();
+    // dz_t tile -> global row-major, coalesced
+    constexpr int VPRZ = 4 * H / R::EPL;
 #pragma unroll 4
-    for (int v = tid; v < 32 * VPR; v += 256) {
-      int row = v / VPR, cv = (v % VPR) * R::EPL;
-      *(uint4*)(Z + (rowbase + row) * (4 * H) + cv) = *(const uint4*)(dzs + row * R::LDZ + cv);
+    for (int v = tid; v < 32 * VPRZ; v += R::NT) {
+      int row = v / VPRZ, cv = (v % VPRZ) * R::EPL;
+      *(uint4*)(dZ + (rb * 32 + row) * (4 * H) + cv) = *(const uint4*)(dzs + row * R::LDZ + cv);
     }
     if (t > 0) {
       // dh_{t-1} (recurrent part) = dz_t [32 x 4H] * U^T [4H x H]; this wave's H/4 output units
@@ -216,17 +363,26 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(T* __restrict__ Z, const 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
       const T* ap = dzs + l31 * R::LDZ;
-#pragma unroll 8
-      for (int kc = 0; kc < R::NKCB; ++kc) {
-        Frag a = dj_lds_frag(ap + kc * R::KC, h);
+      Frag bq[R::PD][R::NJ];
 #pragma unroll
-        for (int j = 0; j < R::NJ; ++j) {
-          Frag b = up[(j * R::NKCB + kc) * 64];
-          dj_mfma(acc[j], a, b);
+      for (int p = 0; p < R::PD; ++p)
+#pragma unroll
+        for (int j = 0; j < R::NJ; ++j) bq[p][j] = up[(j * R::NKCB + p) * 64];
+#pragma unroll 1
+      for (int kc0 = 0; kc0 < R::NKCB; kc0 += R::UNR) {
+#pragma unroll
+        for (int u = 0; u < R::UNR; ++u) {
+          const int kc = kc0 + u;
+          Frag a = dj_lds_frag(ap + kc * R::KC, h);
+#pragma unroll
+          for (int j = 0; j < R::NJ; ++j) dj_mfma(acc[j], a, bq[u % R::PD][j]);
+          const int kn = (kc + R::PD < R::NKCB) ? kc + R::PD : R::NKCB - 1;
+#pragma unroll
+          for (int j = 0; j < R::NJ; ++j) bq[u % R::PD][j] = up[(j * R::NKCB + kn) * 64];
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
   if (dbias) {
 #pragma unroll
@@ -250,24 +406,35 @@ template <typename T, int H> int launch_pack(const float* U, void* fwd, void* bw
 template <typename T, int H>
 int launch_fwd(int ntiles, int steps, void* Z, const void* Upack, void* Hout, void* Cout, int sigm, int store_z,
                hipStream_t st) {
-  hipLaunchKernelGGL((lstm_fwd_kernel<T, H>), dim3(ntiles), dim3(256), 0, st, (T*)Z, (const T*)Upack, (T*)Hout,
-                     (T*)Cout, steps, sigm, store_z);
+  if (sigm)
+    hipLaunchKernelGGL((lstm_fwd_kernel<T, H, true>), dim3(ntiles), dim3(RecCfg<T, H>::NT), 0, st, (T*)Z, (const T*)Upack, (T*)Hout,
+                       (T*)Cout, steps, store_z);
+  else
+    hipLaunchKernelGGL((lstm_fwd_kernel<T, H, false>), dim3(ntiles), dim3(RecCfg<T, H>::NT), 0, st, (T*)Z, (const T*)Upack,
+                       (T*)Hout, (T*)Cout, steps, store_z);
   return (int)hipGetLastError();
 }
 template <typename T, int H>
-int launch_bwd(int ntiles, int steps, void* Z, const void* UTpack, const void* C, const void* dH, float* dbias,
-               int sigm, hipStream_t st) {
+int launch_bwd(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
+               float* dbias, int sigm, hipStream_t st) {
   using R = RecCfg<T, H>;
   size_t smem = (size_t)32 * R::LDZ * sizeof(T);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_kernel<T, H>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)smem);
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_kernel<T, H, false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)lstm_bwd_kernel<T, H, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((lstm_bwd_kernel<T, H>), dim3(ntiles), dim3(256), smem, st, (T*)Z, (const T*)UTpack, (const T*)C,
-                     (const T*)dH, dbias, steps, sigm);
+  if (sigm)
+    hipLaunchKernelGGL((lstm_bwd_kernel<T, H, true>), dim3(ntiles), dim3(R::NT), smem, st, (const T*)Z, (const T*)UTpack,
+                       (const T*)C, (const T*)dH, (T*)dZ, dbias, steps);
+  else
+    hipLaunchKernelGGL((lstm_bwd_kernel<T, H, false>), dim3(ntiles), dim3(R::NT), smem, st, (const T*)Z,
+                       (const T*)UTpack, (const T*)C, (const T*)dH, (T*)dZ, dbias, steps);
   return (int)hipGetLastError();
 }
 
@@ -288,8 +455,8 @@ int dj_launch_lstm_fwd(int dtype, int H, int ntiles, int steps, void* Z, const v
   if (ntiles <= 0 || steps <= 0) return 0;
   DJ_DISPATCH_TH(launch_fwd, ntiles, steps, Z, Upack, Hout, Cout, sigm, store_z, st)
 }
-int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, void* Z, const void* UTpack, const void* C,
-                       const void* dH, float* dbias, int sigm, hipStream_t st) {
+int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* UTpack, const void* C,
+                       const void* dH, void* dZ, float* dbias, int sigm, hipStream_t st) {
   if (ntiles <= 0 || steps <= 0) return 0;
-  DJ_DISPATCH_TH(launch_bwd, ntiles, steps, Z, UTpack, C, dH, dbias, sigm, st)
+  DJ_DISPATCH_TH(launch_bwd, ntiles, steps, Z, UTpack, C, dH, dZ, dbias, sigm, st)
 }

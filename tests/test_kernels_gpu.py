@@ -45,6 +45,30 @@ def from_rows(r, S, L):
     return r.reshape(tiles, L, 32, D).permute(0, 2, 1, 3).reshape(tiles * 32, L, D)[:S]
 
 
+def to_frag(rows):
+    """row-major [R, Ccols] -> fragment-tiled flat (include/deepj_hip.h, dj_gemm_nt c_mode 2)."""
+    R, Cc = rows.shape
+    x = rows.reshape(R // 32, 32, Cc // 32, 32)             # rb, s, cb, c
+    s = torch.arange(32)
+    lane_hi = (s >> 2) & 1
+    reg = (s & 3) + 4 * (s >> 3)
+    out = torch.zeros(R // 32, Cc // 32, 64, 16, dtype=rows.dtype)
+    for si in range(32):
+        out[:, :, lane_hi[si] * 32:(lane_hi[si] + 1) * 32, reg[si]] = x[:, si, :, :]
+    return out.reshape(-1).contiguous()
+
+
+def from_frag(flat, R, Cc):
+    f = flat.reshape(R // 32, Cc // 32, 64, 16)
+    s = torch.arange(32)
+    lane_hi = (s >> 2) & 1
+    reg = (s & 3) + 4 * (s >> 3)
+    x = torch.zeros(R // 32, 32, Cc // 32, 32, dtype=flat.dtype)
+    for si in range(32):
+        x[:, si, :, :] = f[:, :, lane_hi[si] * 32:(lane_hi[si] + 1) * 32, reg[si]]
+    return x.reshape(R, Cc)
+
+
 def test_dropout_mask_matches_oracle(gpu_device):
     L, lib = _lib()
     for seed, site, p, rows, cols in [(7, 4, 0.5, 1000, 64), (123456789012, 17, 0.2, 333, 259), (0, 1, 0.2, 64, 3)]:
@@ -72,6 +96,11 @@ def test_gemm_nt(gpu_device, dtype, M, N, K):
     torch.testing.assert_close(Cd.float().cpu()[:, :N], ref, rtol=rt, atol=at * K ** 0.5)
     if ldc > N:
         assert float(Cd[:, N:].abs().max()) == 0.0
+    if M % 32 == 0 and N % 32 == 0:
+        Cf = torch.zeros(M * N, dtype=Ad.dtype, device=gpu_device)
+        L.check(lib.dj_gemm_nt(DT[dtype], M, N, K, L.ptr(Ad), K, L.ptr(Bd), K, L.ptr(Cf), N, 2,
+                               L.ptr(bias.to(gpu_device)), _st()), "gemm_nt frag")
+        torch.testing.assert_close(from_frag(Cf.float().cpu(), M, N), ref, rtol=rt, atol=at * K ** 0.5)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -137,30 +166,34 @@ def test_lstm_fwd_bwd(gpu_device, dtype, H, S, Ls, sigm):
     (Href * dHr).sum().backward()
 
     zrows, tiles = to_rows(zx)
-    Zd = _op(zrows, dtype).to(gpu_device)
+    R = zrows.shape[0]
+    Zd = _op(to_frag(zrows), dtype).to(gpu_device)
     Ud = U.to(gpu_device)
     esz = 2 if dtype == "bf16" else 4
     upf = torch.empty(H * 4 * H * esz, dtype=torch.uint8, device=gpu_device)
     upb = torch.empty(H * 4 * H * esz, dtype=torch.uint8, device=gpu_device)
     L.check(lib.dj_lstm_pack(DT[dtype], H, L.ptr(Ud), L.ptr(upf), L.ptr(upb), _st()), "pack")
     Hd = torch.zeros(tiles * Ls * 32, H, dtype=Zd.dtype, device=gpu_device)
-    Cd = torch.zeros_like(Hd)
+    Cd = torch.zeros(R * H, dtype=Zd.dtype, device=gpu_device)
     L.check(lib.dj_lstm_fwd(DT[dtype], H, tiles, Ls, L.ptr(Zd), L.ptr(upf), L.ptr(Hd), L.ptr(Cd), sigm, _st()), "fwd")
     rt, at = _tol(dtype)
     torch.testing.assert_close(from_rows(Hd.float().cpu(), S, Ls), Href.detach(), rtol=rt, atol=at * 5)
-    torch.testing.assert_close(from_rows(Cd.float().cpu(), S, Ls), Cref.detach(), rtol=rt, atol=at * 5)
-    torch.testing.assert_close(from_rows(Zd.float().cpu(), S, Ls), Zref.detach(), rtol=rt, atol=at * 10)
+    torch.testing.assert_close(from_rows(from_frag(Cd.float().cpu(), R, H), S, Ls), Cref.detach(), rtol=rt,
+                               atol=at * 5)
+    torch.testing.assert_close(from_rows(from_frag(Zd.float().cpu(), R, 4 * H), S, Ls), Zref.detach(), rtol=rt,
+                               atol=at * 10)
 
     dHd = _op(to_rows(dH)[0], dtype).to(gpu_device)
     db = torch.zeros(4 * H, dtype=torch.float32, device=gpu_device)
-    L.check(lib.dj_lstm_bwd(DT[dtype], H, tiles, Ls, L.ptr(Zd), L.ptr(upb), L.ptr(Cd), L.ptr(dHd), L.ptr(db), sigm,
-                            _st()), "bwd")
-    dz = from_rows(Zd.float().cpu(), S, Ls)
+    dZd = torch.zeros(R, 4 * H, dtype=Zd.dtype, device=gpu_device)
+    L.check(lib.dj_lstm_bwd(DT[dtype], H, tiles, Ls, L.ptr(Zd), L.ptr(upb), L.ptr(Cd), L.ptr(dHd), L.ptr(dZd),
+                            L.ptr(db), sigm, _st()), "bwd")
+    dz = from_rows(dZd.float().cpu(), S, Ls)
     torch.testing.assert_close(dz, zx_ref.grad, rtol=rt * 2, atol=at * 5)
     torch.testing.assert_close(db.cpu(), zx_ref.grad.sum(dim=(0, 1)), rtol=rt * 2, atol=at * 20)
     # padded sequences of the last tile must produce exactly zero dz
     if S % 32:
-        full = Zd.float().cpu().reshape(tiles, Ls, 32, 4 * H)
+        full = dZd.float().cpu().reshape(tiles, Ls, 32, 4 * H)
         assert float(full[-1, :, S % 32:, :].abs().max()) == 0.0
 
 
