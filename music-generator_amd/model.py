@@ -1,0 +1,414 @@
+"""DeepJ model surface -- drop-in for the reference's model.py.
+
+`build_models(time_steps, input_dropout, dropout)` returns `(model, time_model,
+note_model)` exactly like /root/reference/model.py:128-169.  The three objects share
+one flat fp32 parameter vector in HBM and duck-type the Keras `Model` methods the
+reference calls: fit / predict / summary / load_weights /
+save_weights / get_layer.  All arithmetic runs in libdeepj_hip.so; this file is host
+logic only (batching, shuffling, callbacks, weight files, data-parallel sharding).
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+
+from . import constants as K
+from .constants import *  # noqa: F401,F403  (reference modules star-import constants through model)
+from .engine import DeepJConfig
+
+
+def primary_loss(y_true, y_pred):
+    """Reference model.py:14-20 on host arrays (the training loss itself is computed on
+    the GPU inside dj_train_fwd_bwd; this is for callers that evaluate predictions).
+    Keras/TF1 binary_crossentropy on probabilities with the 1e-7 clip."""
+    y_true = np.asarray(y_true, np.float64)
+    y_pred = np.asarray(y_pred, np.float64)
+
+    def bce(t, p):
+        p = np.clip(p, 1e-7, 1 - 1e-7)
+        z = np.log(p / (1 - p))
+        return np.maximum(z, 0) - z * t + np.log1p(np.exp(-np.abs(z)))
+
+    played = y_true[..., 0]
+    note = bce(y_true[..., 0], y_pred[..., 0]).mean(-1)
+    replay = bce(y_true[..., 1], played * y_pred[..., 1] + (1 - played) * y_true[..., 1]).mean(-1)
+    vol = ((y_true[..., 2] - (played * y_pred[..., 2] + (1 - played) * y_true[..., 2])) ** 2).mean(-1)
+    return note + replay + vol
+
+
+class HipBackend:
+    """The product backend: engines and optimizer state on one MI355X."""
+
+    name = "hip"
+
+    def __init__(self, device=None):
+        import torch
+        from . import _lib
+        _lib.load()                                   # raises if libdeepj_hip.so is missing
+        if not torch.cuda.is_available():
+            raise _lib.DeepJError("no HIP device visible: DeepJ models need an MI355X (there is no CPU path)")
+        if device is None:
+            device = "cuda:%d" % int(os.environ.get("LOCAL_RANK", "0"))
+        self.torch = torch
+        self.device = torch.device(device)
+
+    def tensor(self, a):
+        t = self.torch
+        return t.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+    def numpy(self, t):
+        return t.detach().cpu().numpy()
+
+    def engine(self, cfg, batch, time_steps, input_dropout, dropout):
+        from .engine import Engine
+        return Engine(cfg, batch, time_steps, device=self.device, input_dropout=input_dropout, dropout=dropout)
+
+    def optimizer(self, n, **kw):
+        from .engine import Nadam
+        return Nadam(n, self.device, **kw)
+
+    def init_params(self, cfg, seed):
+        from .engine import init_params_numpy
+        return init_params_numpy(cfg, seed)
+
+    def layout(self, cfg):
+        from .engine import param_layout
+        return param_layout(cfg)
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+class History:
+    def __init__(self):
+        self.history = {}
+        self.epoch = []
+
+
+class _Shared:
+    """State shared by model / time_model / note_model (weights are shared in the
+    reference too: model.py:92-93,163-165)."""
+
+    def __init__(self, cfg, backend, input_dropout, dropout, seed):
+        self.cfg = cfg
+        self.backend = backend
+        self.input_dropout = float(input_dropout)
+        self.dropout = float(dropout)
+        self.layout = backend.layout(cfg)
+        self.nparams = sum(int(np.prod(s)) for _, _, s in self.layout)
+        self.params = backend.tensor(backend.init_params(cfg, seed))
+        self.grads = None
+        self.optimizer = None
+        self.engines = {}
+        self.step = 0
+        self.seed = seed
+
+    def engine(self, batch, time_steps, train):
+        key = (int(batch), int(time_steps), bool(train))
+        if key not in self.engines:
+            pin, pdr = (self.input_dropout, self.dropout) if train else (0.0, 0.0)
+            # keep at most a handful of workspaces alive (each can be GBs)
+            if len(self.engines) >= 6:
+                self.engines.pop(next(iter(self.engines)))
+            self.engines[key] = self.backend.engine(self.cfg, batch, time_steps, pin, pdr)
+        return self.engines[key]
+
+
+class _Layer:
+    """Minimal stand-in for `model.get_layer(name)` (reference visualize.py:13-17):
+    callable on a host array and exposes get_weights()."""
+
+    def __init__(self, shared, name):
+        self.name = name
+        self._s = shared
+
+    def get_weights(self):
+        flat = self._s.backend.numpy(self._s.params)
+        out = []
+        for n, off, shape in self._s.layout:
+            if n.split("/")[0] == self.name:
+                out.append(flat[off:off + int(np.prod(shape))].reshape(shape).copy())
+        if not out:
+            raise ValueError("No such layer: " + self.name)
+        return out
+
+    def __call__(self, x):
+        w = self.get_weights()
+        if len(w) != 2 or w[0].ndim != 2:
+            raise NotImplementedError("only Dense layers are callable on host arrays")
+        return np.asarray(x, np.float32) @ w[0] + w[1]
+
+
+class Model:
+    """Common Keras-like surface.  `kind` in {"model", "time", "note"}."""
+
+    def __init__(self, shared, kind, time_steps):
+        self._s = shared
+        self._kind = kind
+        self.time_steps = int(time_steps)
+        self.stop_training = False
+
+    # ------------------------------------------------------------------ weights
+    def count_params(self):
+        return self._s.nparams
+
+    def get_weights(self):
+        flat = self._s.backend.numpy(self._s.params)
+        return [flat[off:off + int(np.prod(s))].reshape(s).copy() for _, off, s in self._s.layout]
+
+    def set_weights(self, weights):
+        flat = np.concatenate([np.asarray(w, np.float32).ravel() for w in weights])
+        if flat.size != self._s.nparams:
+            raise ValueError("expected %d parameters, got %d" % (self._s.nparams, flat.size))
+        self._s.params.copy_(self._s.backend.tensor(flat))
+
+    def save_weights(self, path, overwrite=True):
+        """Weights-only checkpoint (reference train.py:23 ModelCheckpoint(save_weights_only=True)).
+        Stored as .npz with Keras tensor names and layouts (h5py is not available here)."""
+        if not overwrite and os.path.exists(path):
+            return
+        d = os.path.dirname(path)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        arrays = {n: w for (n, _, _), w in zip(self._s.layout, self.get_weights())}
+        tmp = path + ".tmp.npz"
+        np.savez(tmp, **arrays)
+        os.replace(tmp, path)
+
+    def load_weights(self, path):
+        """Raises on any problem -- util.build_or_load (reference util.py:18-22) catches it."""
+        with np.load(path) as z:
+            ws = []
+            for n, _, shape in self._s.layout:
+                if n not in z:
+                    raise KeyError("weight file has no tensor " + n)
+                w = z[n]
+                if tuple(w.shape) != tuple(shape):
+                    raise ValueError("%s: expected shape %s, file has %s" % (n, shape, w.shape))
+                ws.append(w)
+        self.set_weights(ws)
+
+    def get_layer(self, name):
+        return _Layer(self._s, name)
+
+    def summary(self, print_fn=print):
+        """Parameter table in creation order (reference util.py:16 calls models[0].summary())."""
+        print_fn("_" * 65)
+        print_fn("%-38s %-16s %10s" % ("Tensor", "Shape", "Param #"))
+        print_fn("=" * 65)
+        for n, _, shape in self._s.layout:
+            print_fn("%-38s %-16s %10d" % (n, str(tuple(shape)), int(np.prod(shape))))
+        print_fn("=" * 65)
+        print_fn("Total params: {:,}".format(self._s.nparams))
+        print_fn("Trainable params: {:,}".format(self._s.nparams))
+        print_fn("Backend: %s, compute dtype %s, time_steps %d" % (self._s.backend.name, self._s.cfg.dtype,
+                                                                   self.time_steps))
+        print_fn("_" * 65)
+
+    # ------------------------------------------------------------------ inference
+    def _predict_batch(self, arrays):
+        s, be = self._s, self._s.backend
+        B = arrays[0].shape[0]
+        T = arrays[0].shape[1]
+        eng = s.engine(B, T, train=False)
+        t = [be.tensor(a) for a in arrays]
+        if self._kind == "model":
+            out = eng.predict(s.params, *t)
+        elif self._kind == "time":
+            out = eng.time_model_predict(s.params, *t)
+        else:
+            out = eng.note_model_predict(s.params, *t)
+        return be.numpy(out)
+
+    def predict(self, x, batch_size=32, verbose=0):
+        """Keras Model.predict: inference mode, processed in chunks of `batch_size` (Keras
+        default 32 -- it matters: the reference's pitch_bins feature depends on the batch
+        a sample is evaluated in, SURVEY.md finding 2)."""
+        arrays = [np.asarray(a) for a in (x if isinstance(x, (list, tuple)) else [x])]
+        need = {"model": 4, "time": 3, "note": 3}[self._kind]
+        if len(arrays) != need:
+            raise ValueError("%s.predict expects %d input arrays, got %d" % (self._kind, need, len(arrays)))
+        n = arrays[0].shape[0]
+        outs = [self._predict_batch([a[i:i + batch_size] for a in arrays]) for i in range(0, n, batch_size)]
+        return outs[0] if len(outs) == 1 else np.concatenate(outs, axis=0)
+
+
+class TrainableModel(Model):
+    """`model` of build_models: adds fit / train_on_batch / evaluate (reference train.py:29)."""
+
+    def __init__(self, shared, time_steps):
+        super().__init__(shared, "model", time_steps)
+        self.optimizer_config = dict(lr=0.002, beta_1=0.9, beta_2=0.999, epsilon=1e-8, schedule_decay=0.004)
+
+    def compile(self, optimizer="nadam", loss=None, **kw):
+        """Kept for API parity (model.py:152): only 'nadam' + primary_loss are implemented."""
+        if optimizer != "nadam":
+            raise NotImplementedError("only optimizer='nadam' is implemented")
+
+    def _dist(self):
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                return dist
+        except Exception:
+            pass
+        return None
+
+    def train_on_batch(self, x, y=None):
+        """One optimizer step on the given (global) batch; returns the mean loss.
+        With torch.distributed initialised, every rank passes ITS shard and the
+        gradients are summed over ranks weighted by shard size (one all-reduce)."""
+        s, be = self._s, self._s.backend
+        notes, chosen, beat, style = [np.asarray(a) for a in x]
+        target = np.asarray(y[0] if isinstance(y, (list, tuple)) else y) if y is not None else chosen
+        B, T = notes.shape[0], notes.shape[1]
+        eng = s.engine(B, T, train=True)
+        if s.grads is None:
+            s.grads = be.tensor(np.zeros(s.nparams, np.float32))
+        if s.optimizer is None:
+            s.optimizer = be.optimizer(s.nparams, **self.optimizer_config)
+        dist = self._dist()
+        rank = dist.get_rank() if dist else 0
+        world = dist.get_world_size() if dist else 1
+        seed = (s.seed * 1000003 + s.step * world + rank) & 0xFFFFFFFF
+        t = [be.tensor(a) for a in (notes, chosen, beat, style, target)]
+        loss = eng.train_fwd_bwd(s.params, s.grads, *t, seed=seed)
+        weight = float(B)
+        if dist:
+            import torch
+            cnt = torch.tensor([weight], dtype=torch.float64, device=s.grads.device)
+            dist.all_reduce(cnt)
+            total = float(cnt.cpu()[0])
+            s.grads.mul_(weight / total)                 # shard-size weighting, then one sum
+            dist.all_reduce(s.grads)
+            lw = loss.detach().clone().double() * (weight / total)
+            dist.all_reduce(lw)
+            loss_value = float(lw.cpu()[0])
+        else:
+            loss_value = float(be.numpy(loss)[0])
+        s.optimizer.step(s.params, s.grads, 1.0)
+        s.step += 1
+        return loss_value
+
+    def evaluate(self, x, y=None, batch_size=32, verbose=0):
+        notes, chosen, beat, style = [np.asarray(a) for a in x]
+        target = np.asarray(y[0] if isinstance(y, (list, tuple)) else y) if y is not None else chosen
+        tot, n = 0.0, notes.shape[0]
+        for i in range(0, n, batch_size):
+            sl = slice(i, i + batch_size)
+            b = notes[sl].shape[0]
+            eng = self._s.engine(b, notes.shape[1], train=False)
+            be = self._s.backend
+            _, loss = eng.predict(self._s.params, be.tensor(notes[sl]), be.tensor(chosen[sl]), be.tensor(beat[sl]),
+                                  be.tensor(style[sl]), be.tensor(target[sl]))
+            tot += float(be.numpy(loss)[0]) * b
+        return tot / n
+
+    def fit(self, x=None, y=None, batch_size=32, epochs=1, verbose=1, callbacks=None, shuffle=True,
+            initial_epoch=0, **unused):
+        """Keras-2 Model.fit semantics used by the reference (train.py:29): per epoch the
+        sample order is reshuffled with np.random.shuffle, batches are consecutive slices
+        (last partial batch kept), the epoch loss is the sample-weighted mean of the batch
+        losses, callbacks see on_epoch_end(epoch, logs={'loss': ...}).
+        Data parallel: if torch.distributed is initialised, each global batch is split into
+        contiguous per-rank shards (every rank must call fit with the same data and the
+        same NumPy seed)."""
+        x = [np.asarray(a) for a in x]
+        target = np.asarray(y[0] if isinstance(y, (list, tuple)) else y) if y is not None else x[1]
+        n = x[0].shape[0]
+        callbacks = list(callbacks or [])
+        hist = History()
+        callbacks.append(_HistoryCallback(hist))
+        for cb in callbacks:
+            if hasattr(cb, "set_model"):
+                cb.set_model(self)
+            if hasattr(cb, "set_params"):
+                cb.set_params(dict(batch_size=batch_size, epochs=epochs, samples=n, verbose=verbose,
+                                   metrics=["loss"]))
+        self.stop_training = False
+        _call(callbacks, "on_train_begin", {})
+        dist = self._dist()
+        rank = dist.get_rank() if dist else 0
+        world = dist.get_world_size() if dist else 1
+        index = np.arange(n)
+        for epoch in range(initial_epoch, epochs):
+            _call(callbacks, "on_epoch_begin", epoch, {})
+            if shuffle:
+                np.random.shuffle(index)
+            t0 = time.time()
+            tot, seen = 0.0, 0
+            nb = (n + batch_size - 1) // batch_size
+            for bi in range(nb):
+                ids = index[bi * batch_size:(bi + 1) * batch_size]
+                _call(callbacks, "on_batch_begin", bi, {"batch": bi, "size": len(ids)})
+                if world > 1:
+                    per = (len(ids) + world - 1) // world
+                    mine = ids[rank * per:(rank + 1) * per]
+                    if len(mine) == 0:                    # keep the collective pattern identical
+                        mine = ids[:1]
+                else:
+                    mine = ids
+                loss = self.train_on_batch([a[mine] for a in x], target[mine])
+                tot += loss * len(ids)
+                seen += len(ids)
+                _call(callbacks, "on_batch_end", bi, {"batch": bi, "size": len(ids), "loss": loss})
+                if verbose == 1 and rank == 0:
+                    print("\rEpoch %d/%d  %d/%d  loss: %.4f" % (epoch + 1, epochs, seen, n, tot / seen), end="")
+                if self.stop_training:
+                    break
+            logs = {"loss": tot / max(seen, 1)}
+            if verbose and rank == 0:
+                dt = time.time() - t0
+                print("%sEpoch %d/%d - %.1fs - loss: %.4f - %.0f note-steps/s" % (
+                    "\r" if verbose == 1 else "", epoch + 1, epochs, dt, logs["loss"],
+                    seen * x[0].shape[1] * x[0].shape[2] / max(dt, 1e-9)))
+            _call(callbacks, "on_epoch_end", epoch, logs)
+            if self.stop_training:
+                break
+        _call(callbacks, "on_train_end", {})
+        return hist
+
+
+class _HistoryCallback:
+    def __init__(self, hist):
+        self.hist = hist
+
+    def on_epoch_end(self, epoch, logs=None):
+        self.hist.epoch.append(epoch)
+        for k, v in (logs or {}).items():
+            self.hist.history.setdefault(k, []).append(v)
+
+
+def _call(callbacks, name, *args):
+    for cb in callbacks:
+        fn = getattr(cb, name, None)
+        if fn is not None:
+            fn(*args)
+
+
+def build_models(time_steps=K.SEQ_LEN, input_dropout=0.2, dropout=0.5, *, config: DeepJConfig | None = None,
+                 backend=None, device=None, dtype=None, seed=1234):
+    """Reference model.py:128-169.  Returns (model, time_model, note_model).
+
+    Extra keyword-only arguments (defaults reproduce the reference):
+      config  -- DeepJConfig override (e.g. num_notes=128 for the BASELINE shapes)
+      dtype   -- "f32" (parity mode, default) or "bf16" (throughput mode); env DEEPJ_DTYPE
+      backend -- injection point for tests; the default and only product backend is HIP
+      seed    -- weight initialisation seed (Keras initialisers)
+    """
+    if config is None:
+        config = DeepJConfig(time_steps=time_steps)
+    dtype = dtype or os.environ.get("DEEPJ_DTYPE") or config.dtype
+    if dtype != config.dtype or time_steps != config.time_steps:
+        d = dict(config.__dict__)
+        d.update(dtype=dtype, time_steps=time_steps)
+        config = DeepJConfig(**d)
+    if backend is None:
+        backend = HipBackend(device)
+    shared = _Shared(config, backend, input_dropout, dropout, seed)
+    model = TrainableModel(shared, time_steps)
+    time_model = Model(shared, "time", time_steps)
+    note_model = Model(shared, "note", 1)
+    return model, time_model, note_model
