@@ -1,0 +1,134 @@
+"""Autoregressive sampling with the reference's surface (reference generate.py:13-153):
+MusicGeneration, apply_temperature, process_inputs, generate, write_file, main.
+
+Per generated time step: the sliding 128-step window goes through `time_model` (stateless,
+from zero state -- an incrementally carried time-axis state would NOT be equivalent,
+SURVEY.md a-G), then the notes are sampled low to high, each conditioned on the notes
+already chosen.  Random draws come from NumPy's global MT19937 stream in the reference's
+order (note-major, piece-minor; the replay draw only happens after a successful play
+draw), so a seeded run reproduces the reference's sampled rolls given equal model outputs.
+"""
+import argparse
+import os
+from collections import deque
+
+import numpy as np
+
+from . import smf as midi
+from .constants import *  # noqa: F401,F403
+from .dataset import compute_beat, compute_genre, unclamp_midi
+from .midi_util import midi_encode
+from .util import build_or_load, one_hot
+
+try:
+    from tqdm import tqdm
+except Exception:                                  # pragma: no cover
+    def tqdm(x, **kw):
+        return x
+
+
+class MusicGeneration:
+    """State of one piece being generated (reference generate.py:13-79)."""
+
+    def __init__(self, style, default_temp=1):
+        def window(item):
+            return deque([item() for _ in range(SEQ_LEN)], maxlen=SEQ_LEN)
+
+        self.notes_memory = window(lambda: np.zeros((NUM_NOTES, NOTE_UNITS)))
+        self.beat_memory = window(lambda: np.zeros(NOTES_PER_BAR))
+        self.style_memory = window(lambda: style)
+        self.next_note = np.zeros((NUM_NOTES, NOTE_UNITS))    # the time step under construction
+        self.silent_time = NOTES_PER_BAR
+        self.results = []
+        self.default_temp = default_temp
+        self.temperature = default_temp
+
+    def build_time_inputs(self):
+        return np.array(self.notes_memory), np.array(self.beat_memory), np.array(self.style_memory)
+
+    def build_note_inputs(self, note_features):
+        # one time step only: [1, N, units], [1, N, 3], [1, styles]
+        return np.array(note_features), np.array([self.next_note]), np.array(list(self.style_memory)[-1:])
+
+    def choose(self, prob, n):
+        """Sample note n from (p_play, p_replay, volume) (generate.py:47-58)."""
+        vol = prob[n, -1]
+        p = apply_temperature(prob[n, :-1], self.temperature)
+        if np.random.random() <= p[0]:
+            self.next_note[n, 0] = 1
+            self.next_note[n, 2] = vol
+            if np.random.random() <= p[1]:
+                self.next_note[n, 1] = 1
+
+    def end_time(self, t):
+        """Close the time step: temperature schedule + window update (generate.py:60-79)."""
+        if np.count_nonzero(self.next_note) == 0:
+            self.silent_time += 1
+            if self.silent_time >= NOTES_PER_BAR:
+                self.temperature += 0.1
+        else:
+            self.silent_time = 0
+            self.temperature = self.default_temp
+        done = self.next_note
+        self.notes_memory.append(done)
+        self.beat_memory.append(compute_beat(t, NOTES_PER_BAR))
+        self.results.append(done)
+        self.next_note = np.zeros((NUM_NOTES, NOTE_UNITS))
+        return done
+
+
+def apply_temperature(prob, temperature):
+    """Rescale sigmoid probabilities: sigmoid(logit(p) / T); identity at T == 1
+    (generate.py:81-91).  dtype follows `prob` (float32 from predict)."""
+    if temperature != 1:
+        logit = -np.log(1 / prob - 1)
+        prob = 1 / (1 + np.exp(-logit / temperature))
+    return prob
+
+
+def process_inputs(ins):
+    """[(a0, b0, c0), (a1, b1, c1), ...] -> [array(a*), array(b*), array(c*)] (generate.py:93-96)."""
+    return [np.array(col) for col in zip(*ins)]
+
+
+def generate(models, num_bars, styles):
+    """Generator over time steps; yields the list of per-piece note arrays [N, 3]
+    (reference generate.py:98-121)."""
+    print('Generating with styles:', styles)
+    _, time_model, note_model = models
+    pieces = [MusicGeneration(style) for style in styles]
+    for t in tqdm(range(NOTES_PER_BAR * num_bars)):
+        # note-invariant features of the whole window, last step only
+        feats = np.array(time_model.predict(process_inputs([g.build_time_inputs() for g in pieces])))[:, -1:, :]
+        for n in range(NUM_NOTES):
+            ins = process_inputs([g.build_note_inputs(feats[i, :, :, :]) for i, g in enumerate(pieces)])
+            pred = np.array(note_model.predict(ins))
+            for i, g in enumerate(pieces):
+                g.choose(pred[i][-1], n)
+        yield [g.end_time(t) for g in pieces]
+
+
+def write_file(name, results):
+    """One .mid per generated piece under SAMPLES_DIR (generate.py:123-134)."""
+    for i, result in enumerate(zip(*list(results))):
+        fpath = os.path.join(SAMPLES_DIR, name + '_' + str(i) + '.mid')
+        print('Writing file', fpath)
+        os.makedirs(os.path.dirname(fpath), exist_ok=True)
+        midi.write_midifile(fpath, midi_encode(unclamp_midi(result)))
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description='Generates music.')
+    parser.add_argument('--bars', default=32, type=int, help='Number of bars to generate')
+    parser.add_argument('--styles', default=None, type=int, nargs='+', help='Styles to mix together')
+    args = parser.parse_args(argv)
+    models = build_or_load()
+    if args.styles:
+        style_vecs = [np.mean([one_hot(i, NUM_STYLES) for i in args.styles], axis=0)]
+    else:
+        style_vecs = [compute_genre(i) for i in range(len(genre))]
+    write_file('output', generate(models, args.bars, style_vecs))
+
+
+if __name__ == '__main__':
+    main()

@@ -359,11 +359,16 @@ def forward(cfg, p, notes, chosen, beat, style_in, masks=None, return_time=False
 
 def _bce(target, output, eps=1e-7):
     """Keras/TF1 K.binary_crossentropy(target, output) with from_logits=False:
-    clip to [eps, 1-eps], logit = log(p/(1-p)), then
-    max(l,0) - l*t + log1p(exp(-|l|))  (SURVEY 8a a14)."""
+    clip to [eps, 1-eps], logit = log(p/(1-p)), then TF's
+    sigmoid_cross_entropy_with_logits: max(l,0) - l*t + log1p(exp(-|l|)), written with
+    `where(l >= 0, ...)` selections like TF does, so that autodiff yields the true
+    derivative sigmoid(l) - t also at l == 0 exactly  (SURVEY 8a a14)."""
     o = torch.clamp(output, eps, 1.0 - eps)
     l = torch.log(o / (1.0 - o))
-    return torch.clamp(l, min=0) - l * target + torch.log1p(torch.exp(-torch.abs(l)))
+    pos = l >= 0
+    relu_l = torch.where(pos, l, torch.zeros_like(l))
+    neg_abs = torch.where(pos, -l, l)
+    return relu_l - l * target + torch.log1p(torch.exp(neg_abs))
 
 
 def primary_loss(y_true, y_pred):

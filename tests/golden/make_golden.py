@@ -128,6 +128,23 @@ def codec_golden():
     return g
 
 
+def archive_golden():
+    """Two of the reference's archived generated samples (archives/v1/long_samples): DATA
+    files written by the reference's own midi_encode + python-midi.  The bytes pin this
+    build's SMF reader/writer; the decoded rolls pin midi_decode on real files."""
+    import shutil
+    out = {}
+    src = os.path.join(REF, "archives", "v1", "long_samples")
+    for k, name in enumerate(["Baroque 1.mid", "Romantic 2.mid"]):
+        dst = os.path.join(HERE, "archive_%d.mid" % k)
+        shutil.copyfile(os.path.join(src, name), dst)
+        os.chmod(dst, 0o644)
+        pat = midi.read_midifile(dst)
+        out["archive_%d_roll" % k] = MU.midi_decode(pat)
+        out["archive_%d_resolution" % k] = np.array(pat.resolution)
+    return out
+
+
 def dataset_golden():
     rs = np.random.RandomState(5)
     roll = random_roll(rs, 40, C.MIDI_MAX_NOTES)
@@ -215,6 +232,7 @@ def main():
     with open(os.path.join(HERE, "codec.json"), "w") as f:
         json.dump(codec, f)
     np.savez_compressed(os.path.join(HERE, "dataset.npz"), **dataset_golden())
+    np.savez_compressed(os.path.join(HERE, "archive.npz"), **archive_golden())
     np.savez_compressed(os.path.join(HERE, "temperature.npz"), **temperature_golden())
     gen, meta = generate_golden()
     np.savez_compressed(os.path.join(HERE, "generate.npz"), **gen)

@@ -134,3 +134,57 @@ def test_seed_reproducible_and_mask_sensitive(gpu_device):
     l3, o3, _, _ = _run_train(dcfg, B, T, flat, batch, 6, 0.2, 0.5, gpu_device)
     np.testing.assert_array_equal(o1, o2)
     assert np.abs(o1 - o3).max() > 1e-4
+
+
+def test_keras_surface_on_hip(gpu_device, tmp_path):
+    """build_models -> fit / predict / save / load / generate through the public surface
+    (HIP backend), against the oracle-backed twin of the same host code."""
+    from music_generator_amd.model import build_models
+    from music_generator_amd.data import synthetic_batch
+    from oracle_backend import OracleBackend
+    T = 8
+    hm = build_models(time_steps=T, input_dropout=0.0, dropout=0.0, seed=4)
+    om = build_models(time_steps=T, input_dropout=0.0, dropout=0.0, seed=4, backend=OracleBackend())
+    a = synthetic_batch(48, T, 4, seed=2)
+    x, y = [a[0], a[1], a[2], a[3]], [a[4]]
+    hh = hm[0].fit(x, y, epochs=2, batch_size=2, verbose=0, shuffle=False)
+    oh = om[0].fit(x, y, epochs=2, batch_size=2, verbose=0, shuffle=False)
+    np.testing.assert_allclose(hh.history["loss"], oh.history["loss"], rtol=2e-4)
+    for wa, wb in zip(hm[0].get_weights(), om[0].get_weights()):
+        np.testing.assert_allclose(wa, wb, rtol=0, atol=2e-4)        # 4 Nadam steps of lr 2e-3
+    # predict of all three models on the trained HIP weights vs the oracle on the SAME weights
+    om[0].set_weights(hm[0].get_weights())
+    np.testing.assert_allclose(hm[0].predict(x), om[0].predict(x), rtol=1e-3, atol=1e-5)
+    tf = hm[1].predict([x[0], x[2], x[3]])
+    np.testing.assert_allclose(tf, om[1].predict([x[0], x[2], x[3]]), rtol=1e-3, atol=2e-5)
+    feat, ch, st = tf[:, -1:], x[1][:, -1:], x[3][:, -1]
+    np.testing.assert_allclose(hm[2].predict([feat, ch, st[:, None]]), om[2].predict([feat, ch, st[:, None]]),
+                               rtol=1e-3, atol=1e-5)
+    assert abs(hm[0].evaluate(x, y) - om[0].evaluate(x, y)) < 1e-4
+    ck = str(tmp_path / "m.npz")
+    hm[0].save_weights(ck)
+    hm2 = build_models(time_steps=T, seed=9)
+    hm2[0].load_weights(ck)
+    np.testing.assert_array_equal(hm2[0].get_weights()[5], hm[0].get_weights()[5])
+
+
+def test_generate_with_hip_models_matches_oracle_models(gpu_device):
+    """generate() (reference sampling semantics, NumPy RNG stream) with the HIP models vs the
+    same harness with the CPU-oracle models: identical sampled rolls under the same seed.
+    Bit-exact note indices need every Bernoulli draw to fall on the same side of p for both
+    paths; with fp32 outputs agreeing to ~1e-6 a flip has probability ~1e-6 per draw, so a
+    short seeded run is deterministic in practice (DESIGN.md 'Sampling parity')."""
+    from music_generator_amd import generate as Gn
+    from music_generator_amd.dataset import compute_genre
+    from music_generator_amd.model import build_models
+    from oracle_backend import OracleBackend
+    hm = build_models(seed=21)
+    om = build_models(seed=21, backend=OracleBackend())
+    styles = [compute_genre(i) for i in range(3)]
+    np.random.seed(5)
+    a = np.array(list(Gn.generate(hm, 1, styles))[:3])
+    np.random.seed(5)
+    g = Gn.generate(om, 1, styles)
+    b = np.array([next(g) for _ in range(3)])
+    np.testing.assert_array_equal(a[:3, :, :, :2], b[:, :, :, :2])       # play / replay decisions
+    np.testing.assert_allclose(a[:3, :, :, 2], b[:, :, :, 2], rtol=1e-3, atol=1e-5)   # volumes
