@@ -46,7 +46,7 @@ def category_flops(cfg, B, T, N):
 
 def launches_per_step(cfg):
     Lt, Ln = cfg.time_axis_layers, cfg.note_axis_layers
-    return {"gemm_xw": Lt + Ln, "gemm_dx": Lt + Ln, "gemm_dw": 2 * (Lt + Ln), "lstm_fwd_time": Lt,
+    return {"gemm_xw": Lt + Ln, "gemm_dx": Lt + Ln, "gemm_dw": Lt + Ln, "lstm_fwd_time": Lt,
             "lstm_bwd_time": Lt, "lstm_fwd_note": Ln, "lstm_bwd_note": Ln}
 
 

@@ -108,6 +108,13 @@ int32_t dj_gemm_nt(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A
  * A one recurrence step earlier (zeros at step 0): the recurrent-kernel gradient. */
 int32_t dj_gemm_tn(int32_t dtype, int64_t M, int32_t Ka, int32_t ka_valid, int32_t N, const void* A, int32_t lda,
                    const void* B, int32_t ldb, float* C, int32_t ldc, int32_t a_shift, int32_t steps, void* stream);
+/* Both weight gradients of one LSTM layer in one pass over dZ [M,N] (N = 4H):
+ *   dW[D,N] += X[M,:D]^T dZ   (X row-major [M,DP], DP = D padded to a multiple of 8)
+ *   dU[H,N] += Hprev^T dZ     (Hs row-major [M,H]; Hprev = Hs one recurrence step (32 rows)
+ *                              earlier within a sequence tile, zero at step 0)
+ * `zeros` points at >= 16 zero bytes.  TF autodiff of the Keras LSTM kernels (model.py:84,122). */
+int32_t dj_lstm_wgrad(int32_t dtype, int64_t M, int32_t steps, const void* X, int32_t DP, int32_t D, const void* Hs,
+                      int32_t H, const void* dZ, int32_t N, float* dW, float* dU, const void* zeros, void* stream);
 /* Pack a Keras recurrent_kernel U[H,4H] (fp32) into MFMA B-fragment order for the
  * forward (U) and backward (U^T) recurrences; each output holds H*4H operand elements. */
 int32_t dj_lstm_pack(int32_t dtype, int32_t H, const float* U, void* upack_fwd, void* upack_bwd, void* stream);

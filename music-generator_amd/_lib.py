@@ -44,6 +44,8 @@ _SIGS = {
                                C.c_int32, C.c_int32, _P, _P]),
     "dj_gemm_tn": (C.c_int32, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32,
                                _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "dj_lstm_wgrad": (C.c_int32, [C.c_int32, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P,
+                                  C.c_int32, _P, _P, _P, _P]),
     "dj_lstm_pack": (C.c_int32, [C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "dj_lstm_fwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P]),
     "dj_lstm_bwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),

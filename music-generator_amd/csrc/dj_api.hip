@@ -67,7 +67,7 @@ struct Plan {
   int64_t w_Wt_n[MAXL], w_Wc_n[MAXL], w_Uf_n[MAXL], w_Ub_n[MAXL];
   int64_t w_X_t[MAXL], w_Z_t[MAXL], w_H_t[MAXL], w_C_t[MAXL];
   int64_t w_X_n[MAXL], w_Z_n[MAXL], w_H_n[MAXL], w_C_n[MAXL];
-  int64_t w_dH_t, w_dX_t, w_dH_n, w_dX_n, w_featin, w_dZ_t, w_dZ_n;
+  int64_t w_dH_t, w_dX_t, w_dH_n, w_dX_n, w_featin, w_dZ_t, w_dZ_n, w_zero;
   int64_t ws_bytes;
 };
 
@@ -146,6 +146,7 @@ int make_plan(const dj_config* cfg, Plan& p) {
   p.w_featin = wtake(p.Mn * p.Ht * p.esz);   // note_model.predict: features in NA order
   p.w_dZ_t = wtake(p.Mt * 4 * p.Ht * p.esz);  // row-major dz of the layer in flight (BPTT)
   p.w_dZ_n = wtake(p.Mn * 4 * p.Hn * p.esz);
+  p.w_zero = wtake(256);                      // a zero line (h_{-1} rows of the fused weight-gradient GEMM)
   p.ws_bytes = w;
   return 0;
 }
@@ -303,9 +304,8 @@ int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int st
   }
   {
     ProfScope ps(PC_GEMM_DW, c.st);
-    RUN(dj_launch_gemm_tn(dt, M, L.DP, L.D, 4 * L.H, c.at(wX), L.DP, c.at(wdZ), 4 * L.H, G + L.W, 4 * L.H, 0, 0, c.st));
-    RUN(dj_launch_gemm_tn(dt, M, L.H, L.H, 4 * L.H, c.at(wH), L.H, c.at(wdZ), 4 * L.H, G + L.U, 4 * L.H, 32, steps,
-                          c.st));
+    RUN(dj_launch_lstm_wgrad(dt, M, steps, c.at(wX), L.DP, L.D, c.at(wH), L.H, c.at(wdZ), 4 * L.H, G + L.W, G + L.U,
+                             c.at(c.p.w_zero), c.st));
   }
   const void* Bt = dt == DJ_F32 ? (const void*)(c.P + L.W) : (const void*)c.at(wWc);
   ProfScope ps(PC_GEMM_DX, c.st);
@@ -533,6 +533,13 @@ int32_t dj_note_model_predict(const dj_config* cfg, const float* params, const f
   RUN(dj_launch_canonical_to_na(p.c.dtype, features, c.at(p.w_featin), p.B, p.T, p.N, p.Ht, c.st));
   RUN(note_axis_forward(c, p.w_featin, 1, -1, chosen, nullptr, out, nullptr, nullptr));
   return 0;
+}
+
+int32_t dj_lstm_wgrad(int32_t dtype, int64_t M, int32_t steps, const void* X, int32_t DP, int32_t D, const void* Hs,
+                      int32_t H, const void* dZ, int32_t N, float* dW, float* dU, const void* zeros, void* stream) {
+  if (dtype != DJ_F32 && dtype != DJ_BF16) return 1106;
+  if ((M % 32) || steps < 1 || D > DP || !zeros) return 1231;
+  return dj_launch_lstm_wgrad(dtype, M, steps, X, DP, D, Hs, H, dZ, N, dW, dU, zeros, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ live kernel timing

@@ -12,6 +12,8 @@
 // tile's global loads in flight during the MFMAs (register-staged pipeline).
 // LDS rows hold k contiguously with a 16-byte pad: 144-byte row stride makes the
 // ds_read_b128 fragment reads bank-conflict free (MI355X_MICROARCH LDS table).
+#include <stdlib.h>
+
 #include "dj_kernels.h"
 
 namespace {
@@ -327,6 +329,272 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(int64_t M, int Ka, in
     }
 }
 
+
+// ------------------------------------------------------------------ TN, bf16, DMA ring + transposed LDS reads
+// 128 (Ka) x 256 (N) output tile, BK = 32 rows of M per stage, 3-stage LDS ring filled by
+// global_load_lds (no registers, no VALU on the way in; tiles stay in their natural k-major
+// [row][col] form) and consumed with ds_read_b64_tr_b16, the gfx950 transposing LDS read
+// that delivers, per lane, 4 consecutive k of one column -- exactly an MFMA operand half.
+// Each 16-byte chunk c of LDS row r is stored at chunk c ^ ((r&3)<<2) (applied on the DMA
+// SOURCE address, cdna_hip_programming.md rule 21) so the 4-row x 64-byte footprint of a
+// transposed read covers all 64 banks once.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+// LDS-DMA of 16 B per lane: LDS destination = lds_base (wave-uniform byte address, via M0) +
+// 16*lane; the global source address is per lane.  Issued from inline asm so that hipcc does
+// not drain it with vmcnt(0) before every LDS read -- completion is tracked by our own counted
+// s_waitcnt + barrier (cdna_hip_programming.md 5.7: M0 written in the statement that reads it).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long)(const __attribute__((address_space(3))) void*)p;
+}
+union TrFrag {
+  s16x4 h[2];
+  bf16x8 v;
+};
+constexpr int TN2_BK = 32, TN2_TA = 128, TN2_TB = 256;
+constexpr int TN2_ABYTES = TN2_BK * TN2_TA * 2, TN2_BBYTES = TN2_BK * TN2_TB * 2, TN2_STAGE = TN2_ABYTES + TN2_BBYTES;
+constexpr int TN2_NS = 3;
+
+__global__ __launch_bounds__(256) void gemm_tn_bf16_dma_kernel(int64_t M, int Ka, int ka_valid, int N,
+                                                               const bf16_t* __restrict__ A, int lda,
+                                                               const bf16_t* __restrict__ B, int ldb,
+                                                               float* __restrict__ C, int ldc, int ntn, int ntiles,
+                                                               int64_t rows_per_split, int a_shift, int steps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
+  const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+  const int n0 = (tile % ntn) * TN2_TB, i0 = (tile / ntn) * TN2_TA;
+  const int64_t ms = (int64_t)split * rows_per_split;
+  int64_t me = ms + rows_per_split;
+  if (me > M) me = M;
+  const int nkt = (int)((me - ms) / TN2_BK);
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- DMA: per stage 8 x 1 KiB pieces of A (4 rows each) and 16 of B (2 rows each)
+  auto issue = [&](int kt) {
+    const int64_t mt = ms + (int64_t)kt * TN2_BK;
+    unsigned char* sa = smem + (kt % TN2_NS) * TN2_STAGE;
+    unsigned char* sb = sa + TN2_ABYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = w * 2 + i, row = piece * 4 + (lane >> 4), cp = lane & 15;
+      const int c = cp ^ ((row & 3) << 2);
+      int64_t m = mt + row;
+      if (a_shift) m = m >= a_shift ? m - a_shift : 0;
+      int col = i0 + c * 8;
+      if (col >= lda) col = 0;   // outside the operand: any in-bounds address (those output rows are dropped)
+      glds16(A + m * lda + col, __builtin_amdgcn_readfirstlane(lds_addr(sa) + piece * 1024));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = w * 4 + i, row = piece * 2 + (lane >> 5), cp = lane & 31;
+      const int c = cp ^ ((row & 3) << 2);
+      glds16(B + (mt + row) * ldb + n0 + c * 8, __builtin_amdgcn_readfirstlane(lds_addr(sb) + piece * 1024));
+    }
+  };
+
+  // ---- per-lane constants of the transposed reads
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, hgrp = g >> 1, colgrp = g & 1;
+  const int rowl = 8 * hgrp + q;                       // + 16*ks + 4*rd
+  const int chl = 2 * colgrp + (p >> 1);               // + tile column base / 8
+  const int sub = (p & 1) * 8;
+  auto compute = [&](int kt) {
+    const unsigned char* sa = smem + (kt % TN2_NS) * TN2_STAGE;
+    const unsigned char* sb = sa + TN2_ABYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      TrFrag a[2], b[4];
+#pragma unroll
+      for (int rd = 0; rd < 2; ++rd) {
+        const int row = 16 * ks + 4 * rd + rowl;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int c = ((wr * 64 + mi * 32) >> 3) + chl;
+          a[mi].h[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(sa + row * (TN2_TA * 2) + ((c ^ (q << 2)) << 4) + sub));
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int c = ((wc * 128 + ni * 32) >> 3) + chl;
+          b[ni].h[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(sb + row * (TN2_TB * 2) + ((c ^ (q << 2)) << 4) + sub));
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) dj_mfma(acc[mi][ni], a[mi].v, b[ni].v);
+    }
+  };
+
+  if (nkt > 0) issue(0);
+  if (nkt > 1) issue(1);
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // stage kt landed; stage kt+1 (6 DMAs) may still fly
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nkt) issue(kt + 2);
+    bool skip = false;
+    if (a_shift) skip = (((ms + (int64_t)kt * TN2_BK) >> 5) % steps) == 0;   // h_{-1} = 0: no contribution
+    if (!skip) compute(kt);
+  }
+
+  const int l31 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wc * 128 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wr * 64 + i * 32 + dj_crow(r, lane);
+        if (row < ka_valid) atomicAdd(C + (int64_t)row * ldc + col, acc[i][j][r]);
+      }
+    }
+}
+
+
+// ------------------------------------------------------------------ fused LSTM weight gradient (bf16)
+// dW = X^T dZ and dU = Hprev^T dZ of one layer in ONE pass over dZ: the A operand is the
+// virtual matrix [X (DP cols) | Hprev (H cols)] (Hprev = H one recurrence step earlier, zero
+// rows at step 0 -> sourced from a zero line), cut into 256-column tiles.  256 x 256 output
+// tile per 512-thread workgroup (8 waves as 4 x 2, each 64 x 128), BK = 32, 4-stage LDS ring
+// (128 KiB) filled by LDS-DMA, operands consumed with ds_read_b64_tr_b16 (see the kernel above).
+struct WgradArgs {
+  int64_t M;
+  const bf16_t* X; int DP, D;        // layer input [M, DP], D valid columns -> dW [D, N]
+  const bf16_t* Hs; int H;           // layer output [M, H] (row-major), shifted by 32 rows -> dU [H, N]
+  int steps;
+  const bf16_t* dZ; int N;           // [M, N]
+  float* dW; float* dU;              // fp32, += (atomics)
+  const bf16_t* zeros;               // >= 16 zero bytes
+  int ntn, ntiles;
+  int64_t rows_per_split;
+};
+constexpr int WG_BK = 32, WG_T = 256, WG_TILE_BYTES = WG_BK * WG_T * 2, WG_STAGE = 2 * WG_TILE_BYTES, WG_NS = 4;
+
+__global__ __launch_bounds__(512) void lstm_wgrad_bf16_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
+  const int tile = blockIdx.x % a.ntiles, split = blockIdx.x / a.ntiles;
+  const int n0 = (tile % a.ntn) * WG_T, v0 = (tile / a.ntn) * WG_T;   // v0: first virtual A column of the tile
+  const int64_t ms = (int64_t)split * a.rows_per_split;
+  int64_t me = ms + a.rows_per_split;
+  if (me > a.M) me = a.M;
+  const int nkt = (int)((me - ms) / WG_BK);
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // this lane's DMA duties per stage: 2 pieces of A and 2 of B (1 KiB = 2 rows of 512 B each)
+  auto issue = [&](int kt) {
+    const int64_t mt = ms + (int64_t)kt * WG_BK;
+    const bool step0 = ((mt >> 5) % a.steps) == 0;
+    unsigned char* sa = smem + (kt % WG_NS) * WG_STAGE;
+    unsigned char* sb = sa + WG_TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = w * 2 + i, row = piece * 2 + (lane >> 5), cp = lane & 31;
+      const int c = cp ^ ((row & 3) << 2);
+      const int vcol = v0 + c * 8;
+      const int64_t m = mt + row;
+      const bf16_t* src = a.zeros;
+      if (vcol < a.DP)
+        src = a.X + m * a.DP + vcol;
+      else if (vcol < a.DP + a.H && !step0)
+        src = a.Hs + (m - 32) * a.H + (vcol - a.DP);
+      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(sa) + piece * 1024));
+      glds16(a.dZ + m * a.N + n0 + c * 8, __builtin_amdgcn_readfirstlane(lds_addr(sb) + piece * 1024));
+    }
+  };
+
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, hgrp = g >> 1, colgrp = g & 1;
+  const int rowl = 8 * hgrp + q, chl = 2 * colgrp + (p >> 1), sub = (p & 1) * 8;
+  auto compute = [&](int kt) {
+    const unsigned char* sa = smem + (kt % WG_NS) * WG_STAGE;
+    const unsigned char* sb = sa + WG_TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      TrFrag fa[2], fb[4];
+#pragma unroll
+      for (int rd = 0; rd < 2; ++rd) {
+        const int row = 16 * ks + 4 * rd + rowl;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int c = ((wr * 64 + mi * 32) >> 3) + chl;
+          fa[mi].h[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(sa + row * (WG_T * 2) + ((c ^ (q << 2)) << 4) + sub));
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int c = ((wc * 128 + ni * 32) >> 3) + chl;
+          fb[ni].h[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (s16x4 __attribute__((address_space(3)))*)(sb + row * (WG_T * 2) + ((c ^ (q << 2)) << 4) + sub));
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) dj_mfma(acc[mi][ni], fa[mi].v, fb[ni].v);
+    }
+  };
+
+#pragma unroll
+  for (int s = 0; s < WG_NS - 1; ++s)
+    if (s < nkt) issue(s);
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int rem = nkt - 1 - kt;            // stages issued after kt that may still be in flight: min(rem, NS-2)
+    if (rem >= 2)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (rem == 1)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + WG_NS - 1 < nkt) issue(kt + WG_NS - 1);
+    compute(kt);
+  }
+
+  const int l31 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int vr = v0 + wr * 64 + i * 32 + dj_crow(r, lane);
+      float* dst = nullptr;
+      if (vr < a.D)
+        dst = a.dW + (int64_t)vr * a.N;
+      else if (vr >= a.DP && vr < a.DP + a.H)
+        dst = a.dU + (int64_t)(vr - a.DP) * a.N;
+      if (!dst) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(dst + n0 + wc * 128 + j * 32 + l31, acc[i][j][r]);
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ launchers (internal C++ API)
@@ -365,6 +633,25 @@ int dj_launch_gemm_tn(int dtype, int64_t M, int Ka, int ka_valid, int N, const v
   rps = ((rps + 63) / 64) * 64;
   int splits = (int)((M + rps - 1) / rps);
   dim3 grid((unsigned)(ntiles * splits)), block(256);
+  if (dtype == DJ_BF16 && (N % TN2_TB) == 0 && (M % TN2_BK) == 0 && !getenv("DJ_TN_OLD")) {
+    // DMA-ring kernel: 128 x 256 tiles, ~2 resident rounds of workgroups
+    int ntn2 = N / TN2_TB, nta2 = (Ka + TN2_TA - 1) / TN2_TA, nt2 = ntn2 * nta2;
+    int64_t want = (512 + nt2 - 1) / nt2;
+    int64_t rps2 = (M + want - 1) / want;
+    rps2 = ((rps2 + TN2_BK - 1) / TN2_BK) * TN2_BK;
+    int splits2 = (int)((M + rps2 - 1) / rps2);
+    const size_t smem = (size_t)TN2_NS * TN2_STAGE;
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_bf16_dma_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_bf16_dma_kernel, dim3((unsigned)(nt2 * splits2)), block, smem, st, M, Ka, ka_valid, N,
+                       (const bf16_t*)A, lda, (const bf16_t*)B, ldb, C, ldc, ntn2, nt2, rps2, a_shift, steps);
+    return (int)hipGetLastError();
+  }
   if (dtype == DJ_F32)
     hipLaunchKernelGGL(gemm_tn_f32_kernel, grid, block, 0, st, M, Ka, N, (const float*)A, lda, (const float*)B, ldb, C,
                        ldc, ntn, ntiles, rps, a_shift, steps, ka_valid);
@@ -372,4 +659,37 @@ int dj_launch_gemm_tn(int dtype, int64_t M, int Ka, int ka_valid, int N, const v
     hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, block, 0, st, M, Ka, N, (const bf16_t*)A, lda, (const bf16_t*)B, ldb,
                        C, ldc, ntn, ntiles, rps, a_shift, steps, ka_valid);
   return (int)hipGetLastError();
+}
+
+// dW [D,N] += X^T dZ, dU [H,N] += Hprev^T dZ.  bf16: one fused DMA-ring kernel; fp32: two generic launches.
+int dj_launch_lstm_wgrad(int dtype, int64_t M, int steps, const void* X, int DP, int D, const void* Hs, int H,
+                         const void* dZ, int N, float* dW, float* dU, const void* zeros, hipStream_t st) {
+  if (M <= 0) return 0;
+  if (dtype == DJ_BF16 && (N % WG_T) == 0 && (M % 32) == 0 && (DP % 8) == 0 && (H % 8) == 0 && zeros &&
+      !getenv("DJ_WGRAD_OLD")) {
+    WgradArgs a;
+    a.M = M; a.X = (const bf16_t*)X; a.DP = DP; a.D = D; a.Hs = (const bf16_t*)Hs; a.H = H; a.steps = steps;
+    a.dZ = (const bf16_t*)dZ; a.N = N; a.dW = dW; a.dU = dU; a.zeros = (const bf16_t*)zeros;
+    a.ntn = N / WG_T;
+    int nta = (DP + H + WG_T - 1) / WG_T;
+    a.ntiles = a.ntn * nta;
+    int64_t want = (256 + a.ntiles - 1) / a.ntiles;
+    int64_t rps = (M + want - 1) / want;
+    rps = ((rps + WG_BK - 1) / WG_BK) * WG_BK;
+    a.rows_per_split = rps;
+    int splits = (int)((M + rps - 1) / rps);
+    const size_t smem = (size_t)WG_NS * WG_STAGE;
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute((const void*)lstm_wgrad_bf16_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(lstm_wgrad_bf16_kernel, dim3((unsigned)(a.ntiles * splits)), dim3(512), smem, st, a);
+    return (int)hipGetLastError();
+  }
+  int rc = dj_launch_gemm_tn(dtype, M, DP, D, N, X, DP, dZ, N, dW, N, 0, 0, st);
+  if (rc) return rc;
+  return dj_launch_gemm_tn(dtype, M, H, H, N, Hs, H, dZ, N, dU, N, 32, steps, st);
 }

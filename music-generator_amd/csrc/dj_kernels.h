@@ -54,6 +54,8 @@ int dj_launch_gemm_nt(int dtype, int M, int N, int K, const void* A, int lda, co
                       int c_mode, const float* bias, hipStream_t st);
 int dj_launch_gemm_tn(int dtype, int64_t M, int Ka, int ka_valid, int N, const void* A, int lda, const void* B, int ldb, float* C,
                       int ldc, int a_shift, int steps, hipStream_t st);
+int dj_launch_lstm_wgrad(int dtype, int64_t M, int steps, const void* X, int DP, int D, const void* Hs, int H,
+                         const void* dZ, int N, float* dW, float* dU, const void* zeros, hipStream_t st);
 // dj_lstm.hip
 int dj_launch_lstm_pack(int dtype, int H, const float* U, void* fwd, void* bwd, hipStream_t st);
 int dj_launch_lstm_fwd(int dtype, int H, int ntiles, int steps, void* Z, const void* Upack, void* Hout, void* Cout,

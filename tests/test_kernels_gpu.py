@@ -127,6 +127,33 @@ def test_gemm_tn(gpu_device, dtype, M, Ka, kv, N, shift, steps):
     torch.testing.assert_close(Cd.cpu(), ref, rtol=rt, atol=at * M ** 0.5)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("tiles,steps,DP,D,H,N", [(4, 6, 96, 94, 256, 1024), (3, 5, 264, 259, 128, 512),
+                                                  (8, 4, 128, 128, 128, 512), (2, 3, 256, 256, 256, 1024)])
+def test_lstm_wgrad_fused(gpu_device, dtype, tiles, steps, DP, D, H, N):
+    """dW = X^T dZ and dU = Hprev^T dZ in one launch vs a torch fp32 reference."""
+    L, lib = _lib()
+    M = tiles * steps * 32
+    g = torch.Generator().manual_seed(M + DP)
+    X = torch.randn(M, DP, generator=g)
+    X[:, D:] = 0
+    Hs = torch.randn(M, H, generator=g)
+    dZ = torch.randn(M, N, generator=g) * 0.1
+    Xd, Hd, Zd = [_op(t, dtype).to(gpu_device) for t in (X, Hs, dZ)]
+    dW = torch.full((D, N), 0.25, dtype=torch.float32, device=gpu_device)
+    dU = torch.full((H, N), -0.5, dtype=torch.float32, device=gpu_device)
+    zeros = torch.zeros(64, dtype=torch.float32, device=gpu_device)
+    L.check(lib.dj_lstm_wgrad(DT[dtype], M, steps, L.ptr(Xd), DP, D, L.ptr(Hd), H, L.ptr(Zd), N, L.ptr(dW), L.ptr(dU),
+                              L.ptr(zeros), _st()), "wgrad")
+    Hp = torch.zeros(M, H)
+    Hp[32:] = Hd.float().cpu()[:-32]
+    Hp[((torch.arange(M) // 32) % steps) == 0] = 0
+    rt, at = _tol(dtype)
+    torch.testing.assert_close(dW.cpu(), 0.25 + Xd.float().cpu()[:, :D].T @ Zd.float().cpu(), rtol=rt,
+                               atol=at * M ** 0.5)
+    torch.testing.assert_close(dU.cpu(), -0.5 + Hp.T @ Zd.float().cpu(), rtol=rt, atol=at * M ** 0.5)
+
+
 def _lstm_setup(S, Ls, D, H, seed):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(S, Ls, D, generator=g) * 0.5
