@@ -2,9 +2,34 @@
 // features), style projections, inter-layer glue (dropout + style add + axis swap),
 // play/replay/volume head with the masked loss, and the Nadam update.
 // All HBM-bound; every kernel reads each activation once with coalesced rows.
+#include <stdlib.h>
+
 #include "dj_kernels.h"
 
 namespace {
+
+// 8 consecutive operand elements <-> 8 floats (16-byte accesses)
+__device__ __forceinline__ void load8(const float* p, float (&x)[8]) {
+  float4 a = ((const float4*)p)[0], b = ((const float4*)p)[1];
+  x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&x)[8]) {
+  uint4 v = *(const uint4*)p;
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    x[2 * i] = __uint_as_float(w[i] << 16);
+    x[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+  }
+}
+__device__ __forceinline__ void store8(float* p, const float (&x)[8]) {
+  ((float4*)p)[0] = make_float4(x[0], x[1], x[2], x[3]);
+  ((float4*)p)[1] = make_float4(x[4], x[5], x[6], x[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&x)[8]) {
+  *(uint4*)p = make_uint4(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]),
+                          pack_bf16x2(x[6], x[7]));
+}
 
 // ------------------------------------------------------------------ small dense (fp32)
 // C[m, n] = act(A[m,:K] . W[:K, n] + b[n])      (reference model.py:141-142 style
@@ -18,15 +43,35 @@ __global__ void dense_small_kernel(const float* __restrict__ A, int M, int K, co
   for (int k = 0; k < K; ++k) s += A[(int64_t)m * K + k] * W[(int64_t)k * N + n];
   C[idx] = act_tanh ? dj_tanh(s) : s;
 }
-// dA[m,k] (+)= sum_n dC[m,n] * W[k,n]
-__global__ void dense_small_bwd_x_kernel(const float* __restrict__ dC, int M, int N, const float* __restrict__ W, int K,
-                                         float* __restrict__ dA, int accumulate) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)M * K) return;
-  int m = idx / K, k = idx % K;
-  float s = 0.f;
-  for (int n = 0; n < N; ++n) s += dC[(int64_t)m * N + n] * W[(int64_t)k * N + n];
-  dA[idx] = accumulate ? dA[idx] + s : s;
+// dA[m,k] (+)= sum_n dC[m,n] * W[k,n].  Block = 8 rows; W^T staged in LDS ([n][K], conflict-free
+// across k), the 8 dC rows too; thread (k, row pair).
+__global__ __launch_bounds__(256) void dense_small_bwd_x_kernel(const float* __restrict__ dC, int M, int N,
+                                                                const float* __restrict__ W, int K,
+                                                                float* __restrict__ dA, int accumulate) {
+  extern __shared__ float sm[];
+  float* wt = sm;               // [N][K]
+  float* dc = sm + N * K;       // [8][N]
+  const int tid = threadIdx.x, m0 = blockIdx.x * 8;
+  for (int i = tid; i < N * K; i += 256) {
+    int k = i / N, n = i % N;   // coalesced read of W[k][n]
+    wt[n * K + k] = W[i];
+  }
+  for (int i = tid; i < 8 * N; i += 256) {
+    int r = i / N, n = i % N;
+    dc[i] = (m0 + r < M) ? dC[(int64_t)(m0 + r) * N + n] : 0.f;
+  }
+  __syncthreads();
+  const int k = tid % 64, rp = tid / 64;   // rows 2*rp, 2*rp+1
+  if (k >= K) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int n = 0; n < N; ++n) {
+    float w = wt[n * K + k];
+    s0 += dc[(2 * rp) * N + n] * w;
+    s1 += dc[(2 * rp + 1) * N + n] * w;
+  }
+  int m = m0 + 2 * rp;
+  if (m < M) dA[(int64_t)m * K + k] = accumulate ? dA[(int64_t)m * K + k] + s0 : s0;
+  if (m + 1 < M) dA[(int64_t)(m + 1) * K + k] = accumulate ? dA[(int64_t)(m + 1) * K + k] + s1 : s1;
 }
 // dW[k,n] += sum_m A[m,k] dC[m,n];  db[n] += sum_m dC[m,n].  One block per
 // (row chunk, 64-col strip); thread (kq, n) owns K/4 rows of dW for its column.
@@ -48,6 +93,7 @@ __global__ __launch_bounds__(256) void dense_small_bwd_w_kernel(const float* __r
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   float bsum = 0.f;
+#pragma unroll 4
   for (int m = m0; m < m1; ++m) {
     float d = dC[(int64_t)m * N + n];
     bsum += d;
@@ -288,43 +334,81 @@ __global__ void glue_fwd_kernel(GlueArgs a, const T* __restrict__ Hin, T* __rest
   const int64_t rin = a.in_na ? dj_row_na(b, t, n, a.T, a.N) : dj_row_ta(b, t, n, a.T, a.N);
   const int64_t rout = a.out_na ? dj_row_na(b, t, n, a.T, a.N) : dj_row_ta(b, t, n, a.T, a.N);
   const uint32_t ko = dj_rowkey(a.d_out, r), ks = dj_rowkey(a.d_style, r);
-  T outv[8];
+  const int d0 = ch * 8;
+  float v[8];
+  if (d0 + 8 <= a.Hd) {                      // whole chunk comes from the producing layer's h
+    load8(Hin + rin * a.Hd + d0, v);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int d = ch * 8 + e;
-    float v = 0.f;
-    if (d < a.Hd) {
-      v = dj_to_f32(Hin[rin * a.Hd + d]) * dj_keep(a.d_out, ko, d);
-    } else if (a.chosen && d < a.Hd + 3 && n > 0) {
-      v = a.chosen[(int64_t)(r - 1) * 3 + (d - a.Hd)] * dj_keep(a.d_chosen, dj_rowkey(a.d_chosen, r - 1), d - a.Hd);
+    for (int e = 0; e < 8; ++e) v[e] *= dj_keep(a.d_out, ko, d0 + e);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int d = d0 + e;
+      v[e] = 0.f;
+      if (d < a.Hd)
+        v[e] = dj_to_f32(Hin[rin * a.Hd + d]) * dj_keep(a.d_out, ko, d);
+      else if (a.chosen && d < a.Hd + 3 && n > 0)
+        v[e] = a.chosen[(int64_t)(r - 1) * 3 + (d - a.Hd)] *
+               dj_keep(a.d_chosen, dj_rowkey(a.d_chosen, r - 1), d - a.Hd);
     }
-    if (a.sp && d < a.D) v += a.sp[(int64_t)bt * a.D + d] * dj_keep(a.d_style, ks, d);
-    if (d >= a.D) v = 0.f;
-    outv[e] = dj_from_f32<T>(v);
   }
-  T* dst = X + rout * a.DP + ch * 8;
+  if (a.sp) {
+    if (d0 + 8 <= a.D) {
+      const float* sp = a.sp + (int64_t)bt * a.D + d0;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) dst[e] = outv[e];
+      for (int e = 0; e < 8; ++e) v[e] += sp[e] * dj_keep(a.d_style, ks, d0 + e);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (d0 + e < a.D) v[e] += a.sp[(int64_t)bt * a.D + d0 + e] * dj_keep(a.d_style, ks, d0 + e);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (d0 + e >= a.D) v[e] = 0.f;
+  store8(X + rout * a.DP + d0, v);
 }
 
 // backward: dH = dX * keep_out ; dpre[bt,d] = (sum_n dX * keep_style) * (1 - sp^2)
+// One workgroup per (b,t); thread = (8-column chunk, note group); 16-byte accesses.
 template <typename T>
-__global__ void glue_bwd_kernel(GlueArgs a, const T* __restrict__ dX, T* __restrict__ dH, float* __restrict__ dpre) {
+__global__ __launch_bounds__(256) void glue_bwd_kernel(GlueArgs a, const T* __restrict__ dX, T* __restrict__ dH,
+                                                       float* __restrict__ dpre) {
+  extern __shared__ float red[];                  // [groups][DP]
   const int bt = blockIdx.x, t = bt % a.T, b = bt / a.T;
-  for (int d = threadIdx.x; d < a.D; d += blockDim.x) {
-    float s = 0.f;
-    for (int n = 0; n < a.N; ++n) {
+  const int chunks = a.DP / 8, groups = 256 / chunks;
+  const int ch = threadIdx.x % chunks, grp = threadIdx.x / chunks;
+  const int d0 = ch * 8;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (grp < groups) {
+    for (int n = grp; n < a.N; n += groups) {
       const uint32_t r = (uint32_t)bt * a.N + n;
       const int64_t rin = a.in_na ? dj_row_na(b, t, n, a.T, a.N) : dj_row_ta(b, t, n, a.T, a.N);
       const int64_t rout = a.out_na ? dj_row_na(b, t, n, a.T, a.N) : dj_row_ta(b, t, n, a.T, a.N);
-      float v = dj_to_f32(dX[rout * a.DP + d]);
-      if (a.sp) s += v * dj_keep(a.d_style, dj_rowkey(a.d_style, r), d);
-      if (d < a.Hd) dH[rin * a.Hd + d] = dj_from_f32<T>(v * dj_keep(a.d_out, dj_rowkey(a.d_out, r), d));
+      float v[8];
+      load8(dX + rout * a.DP + d0, v);
+      if (a.sp) {
+        const uint32_t ks = dj_rowkey(a.d_style, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += v[e] * dj_keep(a.d_style, ks, d0 + e);
+      }
+      if (d0 + 8 <= a.Hd) {
+        const uint32_t ko = dj_rowkey(a.d_out, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= dj_keep(a.d_out, ko, d0 + e);
+        store8(dH + rin * a.Hd + d0, v);
+      }
     }
-    if (a.sp) {
-      float sp = a.sp[(int64_t)bt * a.D + d];
-      dpre[(int64_t)bt * a.D + d] = s * (1.f - sp * sp);
-    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[grp * a.DP + d0 + e] = s[e];
+  }
+  if (!a.sp) return;
+  __syncthreads();
+  for (int d = threadIdx.x; d < a.D; d += 256) {
+    float tot = 0.f;
+    for (int gI = 0; gI < groups; ++gI) tot += red[gI * a.DP + d];
+    const float sp = a.sp[(int64_t)bt * a.D + d];
+    dpre[(int64_t)bt * a.D + d] = tot * (1.f - sp * sp);
   }
 }
 
@@ -339,97 +423,131 @@ __device__ __forceinline__ float bce_clip(float t, float p, float& pc, bool& inr
   return fmaxf(l, 0.f) - l * t + log1pf(expf(-fabsf(l)));
 }
 
+// HD/8 lanes per note row (each lane 8 hidden units, one 16-byte load), 64/(HD/8) rows per wave.
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void head_loss_kernel(HeadArgs a, const T* __restrict__ Hn, T* __restrict__ dH) {
-  constexpr int PER = HD / 64;
-  const int lane = threadIdx.x & 63;
+  constexpr int LPR = HD / 8, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, sub = lane % LPR, slot = lane / LPR, d0 = sub * 8;
   const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-  float w0[PER], w1[PER], w2[PER], g0[PER], g1[PER], g2[PER];
+  float w0[8], w1[8], w2[8], g0[8], g1[8], g2[8];
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    int d = lane + 64 * i;
-    w0[i] = a.Wn[d * 2];
-    w1[i] = a.Wn[d * 2 + 1];
-    w2[i] = a.Wv[d];
-    g0[i] = g1[i] = g2[i] = 0.f;
+  for (int e = 0; e < 8; ++e) {
+    w0[e] = a.Wn[(d0 + e) * 2];
+    w1[e] = a.Wn[(d0 + e) * 2 + 1];
+    w2[e] = a.Wv[d0 + e];
+    g0[e] = g1[e] = g2[e] = 0.f;
   }
   const float b0 = a.bn[0], b1 = a.bn[1], b2 = a.bv[0];
   float gb0 = 0.f, gb1 = 0.f, gb2 = 0.f, lsum = 0.f;
   const int64_t rows = (int64_t)a.B * a.T * a.N;
-  for (int64_t r = wave; r < rows; r += nwaves) {
-    const int n = r % a.N, bt = r / a.N, t = bt % a.T, b = bt / a.T;
+  for (int64_t base = wave * RPW; base < rows; base += nwaves * RPW) {
+    const int64_t r = base + slot;
+    const bool live = r < rows;
+    const int64_t rr = live ? r : rows - 1;
+    const int n = rr % a.N, bt = rr / a.N, t = bt % a.T, b = bt / a.T;
     const int64_t row = dj_row_na(b, t, n, a.T, a.N);
-    const uint32_t rk = dj_rowkey(a.d_out, (uint32_t)r);
-    float x[PER], kp[PER];
+    const uint32_t rk = dj_rowkey(a.d_out, (uint32_t)rr);
+    float x[8], kp[8];
+    load8(Hn + row * HD + d0, x);
     float l0 = 0.f, l1 = 0.f, l2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      int d = lane + 64 * i;
-      kp[i] = dj_keep(a.d_out, rk, d);
-      x[i] = dj_to_f32(Hn[row * HD + d]) * kp[i];
-      l0 += x[i] * w0[i];
-      l1 += x[i] * w1[i];
-      l2 += x[i] * w2[i];
+    for (int e = 0; e < 8; ++e) {
+      kp[e] = dj_keep(a.d_out, rk, d0 + e);
+      x[e] *= kp[e];
+      l0 += x[e] * w0[e];
+      l1 += x[e] * w1[e];
+      l2 += x[e] * w2[e];
     }
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
-      l0 += __shfl_xor(l0, s);
-      l1 += __shfl_xor(l1, s);
-      l2 += __shfl_xor(l2, s);
+    for (int sft = LPR / 2; sft > 0; sft >>= 1) {
+      l0 += __shfl_xor(l0, sft);
+      l1 += __shfl_xor(l1, sft);
+      l2 += __shfl_xor(l2, sft);
     }
     l0 += b0;
     l1 += b1;
     l2 += b2;
     const float p0 = dj_sigmoid(l0), p1 = dj_sigmoid(l1);
-    if (a.out && lane == 0) {
-      a.out[r * 3] = p0;
-      a.out[r * 3 + 1] = p1;
-      a.out[r * 3 + 2] = l2;
+    if (a.out && live && sub == 0) {
+      a.out[rr * 3] = p0;
+      a.out[rr * 3 + 1] = p1;
+      a.out[rr * 3 + 2] = l2;
     }
-    if (!a.target) continue;
-    const float t0 = a.target[r * 3], t1 = a.target[r * 3 + 1], t2 = a.target[r * 3 + 2];
+    if (!a.target || !live) continue;
+    const float t0 = a.target[rr * 3], t1 = a.target[rr * 3 + 1], t2 = a.target[rr * 3 + 2];
     const float played = t0;
     float pc;
     bool inr;
-    float L = bce_clip(t0, p0, pc, inr);
-    float d0 = inr ? (p0 - t0) : 0.f;
+    float Lv = bce_clip(t0, p0, pc, inr);
+    float dl0 = inr ? (p0 - t0) : 0.f;
     const float pe = played * p1 + (1.f - played) * t1;
-    L += bce_clip(t1, pe, pc, inr);
-    float d1 = inr ? (pc - t1) / (pc * (1.f - pc)) * played * p1 * (1.f - p1) : 0.f;
+    Lv += bce_clip(t1, pe, pc, inr);
+    float dl1 = inr ? (pc - t1) / (pc * (1.f - pc)) * played * p1 * (1.f - p1) : 0.f;
     const float ve = played * l2 + (1.f - played) * t2;
     const float diff = t2 - ve;
-    L += diff * diff;
-    float d2 = -2.f * diff * played;
-    d0 *= a.inv_count;
-    d1 *= a.inv_count;
-    d2 *= a.inv_count;
-    lsum += L;
-    gb0 += d0;
-    gb1 += d1;
-    gb2 += d2;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      int d = lane + 64 * i;
-      g0[i] += x[i] * d0;
-      g1[i] += x[i] * d1;
-      g2[i] += x[i] * d2;
-      if (dH) dH[row * HD + d] = dj_from_f32<T>((d0 * w0[i] + d1 * w1[i] + d2 * w2[i]) * kp[i]);
+    Lv += diff * diff;
+    float dl2 = -2.f * diff * played;
+    dl0 *= a.inv_count;
+    dl1 *= a.inv_count;
+    dl2 *= a.inv_count;
+    if (sub == 0) {
+      lsum += Lv;
+      gb0 += dl0;
+      gb1 += dl1;
+      gb2 += dl2;
     }
+    float dh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      g0[e] += x[e] * dl0;
+      g1[e] += x[e] * dl1;
+      g2[e] += x[e] * dl2;
+      dh[e] = (dl0 * w0[e] + dl1 * w1[e] + dl2 * w2[e]) * kp[e];
+    }
+    if (dH) store8(dH + row * HD + d0, dh);
   }
   if (!a.target) return;
+  // fold the RPW row slots of the wave
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    int d = lane + 64 * i;
-    atomicAdd(a.dWn + d * 2, g0[i]);
-    atomicAdd(a.dWn + d * 2 + 1, g1[i]);
-    atomicAdd(a.dWv + d, g2[i]);
+  for (int sft = LPR; sft < 64; sft <<= 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      g0[e] += __shfl_xor(g0[e], sft);
+      g1[e] += __shfl_xor(g1[e], sft);
+      g2[e] += __shfl_xor(g2[e], sft);
+    }
+    gb0 += __shfl_xor(gb0, sft);
+    gb1 += __shfl_xor(gb1, sft);
+    gb2 += __shfl_xor(gb2, sft);
+    lsum += __shfl_xor(lsum, sft);
+  }
+  // fold the block's waves in LDS, then one coalesced run of global atomics per block
+  __shared__ float red[3 * HD + 4];
+  for (int i = threadIdx.x; i < 3 * HD + 4; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  if (slot == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      atomicAdd(&red[(d0 + e) * 2], g0[e]);
+      atomicAdd(&red[(d0 + e) * 2 + 1], g1[e]);
+      atomicAdd(&red[2 * HD + d0 + e], g2[e]);
+    }
   }
   if (lane == 0) {
-    atomicAdd(a.dbn, gb0);
-    atomicAdd(a.dbn + 1, gb1);
-    atomicAdd(a.dbv, gb2);
-    if (a.loss) atomicAdd(a.loss, lsum * a.inv_count);
+    atomicAdd(&red[3 * HD], gb0);
+    atomicAdd(&red[3 * HD + 1], gb1);
+    atomicAdd(&red[3 * HD + 2], gb2);
+    atomicAdd(&red[3 * HD + 3], lsum);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * HD; i += blockDim.x) atomicAdd(a.dWn + i, red[i]);
+  for (int i = threadIdx.x; i < HD; i += blockDim.x) atomicAdd(a.dWv + i, red[2 * HD + i]);
+  if (threadIdx.x == 0) {
+    atomicAdd(a.dbn, red[3 * HD]);
+    atomicAdd(a.dbn + 1, red[3 * HD + 1]);
+    atomicAdd(a.dbv, red[3 * HD + 2]);
+    if (a.loss) atomicAdd(a.loss, red[3 * HD + 3] * a.inv_count);
   }
 }
 
@@ -506,14 +624,23 @@ int dj_launch_dense_small(const float* A, int M, int K, const float* W, const fl
 }
 int dj_launch_dense_small_bwd_x(const float* dC, int M, int N, const float* W, int K, float* dA, int accumulate,
                                 hipStream_t st) {
-  hipLaunchKernelGGL(dense_small_bwd_x_kernel, dim3(nblk((int64_t)M * K)), dim3(256), 0, st, dC, M, N, W, K, dA,
-                     accumulate);
+  if (K > 64) return 1020;
+  const size_t smb = ((size_t)N * K + 8 * (size_t)N) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)dense_small_bwd_x_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  if (smb > 96 * 1024) return 1026;
+  hipLaunchKernelGGL(dense_small_bwd_x_kernel, dim3((M + 7) / 8), dim3(256), smb, st, dC, M, N, W, K, dA, accumulate);
   return (int)hipGetLastError();
 }
 int dj_launch_dense_small_bwd_w(const float* A, int M, int K, const float* dC, int N, float* dW, float* db,
                                 hipStream_t st) {
   if (K > 64) return 1020;
-  const int rpb = 128;
+  const int rpb = 32;
   dim3 grid((M + rpb - 1) / rpb, (N + 63) / 64);
   hipLaunchKernelGGL(dense_small_bwd_w_kernel, grid, dim3(256), (size_t)rpb * K * sizeof(float), st, A, M, K, dC, N, dW,
                      db, rpb);
@@ -561,16 +688,18 @@ int dj_launch_glue_fwd(int dtype, const void* ga, const void* Hin, void* X, hipS
 }
 int dj_launch_glue_bwd(int dtype, const void* ga, const void* dX, void* dH, float* dpre, hipStream_t st) {
   const GlueArgs& a = *(const GlueArgs*)ga;
-  DJ_T_DISPATCH(hipLaunchKernelGGL(glue_bwd_kernel<float>, dim3(a.B * a.T), dim3(256), 0, st, a, (const float*)dX,
+  if (a.DP % 8 || a.DP > 2048 || a.Hd % 8) return 1025;
+  const size_t sm = (size_t)(256 / (a.DP / 8)) * a.DP * sizeof(float);
+  DJ_T_DISPATCH(hipLaunchKernelGGL(glue_bwd_kernel<float>, dim3(a.B * a.T), dim3(256), sm, st, a, (const float*)dX,
                                    (float*)dH, dpre),
-                hipLaunchKernelGGL(glue_bwd_kernel<bf16_t>, dim3(a.B * a.T), dim3(256), 0, st, a, (const bf16_t*)dX,
+                hipLaunchKernelGGL(glue_bwd_kernel<bf16_t>, dim3(a.B * a.T), dim3(256), sm, st, a, (const bf16_t*)dX,
                                    (bf16_t*)dH, dpre))
   return (int)hipGetLastError();
 }
 int dj_launch_head(int dtype, const void* ha, const void* Hn, void* dH, hipStream_t st) {
   const HeadArgs& a = *(const HeadArgs*)ha;
   int64_t rows = (int64_t)a.B * a.T * a.N;
-  int grid = (int)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
+  int grid = (int)((rows + 15) / 16 < 2048 ? (rows + 15) / 16 : 2048);
   if (a.Hd == 128) {
     DJ_T_DISPATCH(hipLaunchKernelGGL((head_loss_kernel<float, 128>), dim3(grid), dim3(256), 0, st, a, (const float*)Hn,
                                      (float*)dH),
