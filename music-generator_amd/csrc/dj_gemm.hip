@@ -485,7 +485,7 @@ struct WgradArgs {
   const bf16_t* dZ; int N;           // [M, N]
   float* dW; float* dU;              // fp32, += (atomics)
   const bf16_t* zeros;               // >= 16 zero bytes
-  int ntn, ntiles;
+  int ntn, ntiles, xcd_map;
   int64_t rows_per_split;
 };
 constexpr int WG_BK = 32, WG_T = 256, WG_TILE_BYTES = WG_BK * WG_T * 2, WG_STAGE = 2 * WG_TILE_BYTES, WG_NS = 4;
@@ -494,12 +494,22 @@ __global__ __launch_bounds__(512) void lstm_wgrad_bf16_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
-  const int tile = blockIdx.x % a.ntiles, split = blockIdx.x / a.ntiles;
+  // all tiles of one row split read the same rows of dZ / X / H: keep them on one XCD (blocks b, b+8, ...)
+  int tile, split;
+  if (a.xcd_map) {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    tile = idx % a.ntiles;
+    split = (idx / a.ntiles) * 8 + xcd;
+  } else {
+    tile = blockIdx.x % a.ntiles;
+    split = blockIdx.x / a.ntiles;
+  }
   const int n0 = (tile % a.ntn) * WG_T, v0 = (tile / a.ntn) * WG_T;   // v0: first virtual A column of the tile
   const int64_t ms = (int64_t)split * a.rows_per_split;
   int64_t me = ms + a.rows_per_split;
   if (me > a.M) me = a.M;
   const int nkt = (int)((me - ms) / WG_BK);
+  if (nkt <= 0) return;                    // empty trailing split (uniform for the workgroup)
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -595,6 +605,139 @@ __global__ __launch_bounds__(512) void lstm_wgrad_bf16_kernel(WgradArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------ NT, bf16, persistent DMA ring
+// C[M,N] = A[M,K] Bt[N,K]^T (+bias).  256 x 128 output tile per 512-thread workgroup (8 waves
+// as 4 x 2, each 64 x 64), BK = 64, 3-stage LDS ring filled by LDS-DMA.  The K loops of this
+// model are short (K = 96..1024), so every workgroup is persistent over output tiles and the
+// ring runs ahead ACROSS tile boundaries: the epilogue of tile i overlaps the loads of tile i+1.
+// LDS rows are 128 B (64 bf16); 16-byte chunk c of row r lives at chunk c ^ ((r>>1)&7), applied
+// on the DMA source address, which makes the ds_read_b128 operand reads conflict-free.
+// XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so the ntn column
+// tiles of one 256-row A panel are given to `ntn` workgroups of ONE XCD at the same time -- the
+// panel is fetched from HBM once and re-read from that XCD's L2 (speed only, never correctness).
+__device__ uint4 dj_zero_line[4];     // 64 zero bytes: DMA source for out-of-range rows / k-tail
+constexpr int NT2_BM = 256, NT2_BN = 128, NT2_BK = 64, NT2_NS = 3;
+constexpr int NT2_ABYTES = NT2_BM * NT2_BK * 2, NT2_BBYTES = NT2_BN * NT2_BK * 2, NT2_STAGE = NT2_ABYTES + NT2_BBYTES;
+
+template <typename TC>
+__global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int K, const bf16_t* __restrict__ A,
+                                                               int lda, const bf16_t* __restrict__ Bt, int ldb,
+                                                               TC* __restrict__ C, int ldc,
+                                                               const float* __restrict__ bias, int ntn, int ntm,
+                                                               int c_frag, int xcd_map) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
+  const int nk = (K + NT2_BK - 1) / NT2_BK;
+  // tile schedule of this persistent workgroup: tile(tl) = (mt0 + tl*mstride, nt)
+  int nt, mt0, mstride, my_tiles;
+  if (xcd_map) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, teams = (int)(gridDim.x >> 3) / ntn;
+    const int team = slot / ntn;
+    nt = slot % ntn;
+    mt0 = xcd + 8 * team;
+    mstride = 8 * teams;
+    my_tiles = (team < teams && mt0 < ntm) ? (ntm - mt0 + mstride - 1) / mstride : 0;
+  } else {
+    nt = blockIdx.x % ntn;
+    mt0 = blockIdx.x / ntn;
+    mstride = gridDim.x / ntn;      // launcher guarantees gridDim.x % ntn == 0 in this mode
+    my_tiles = mt0 < ntm ? (ntm - mt0 + mstride - 1) / mstride : 0;
+  }
+  const int n0 = nt * NT2_BN;
+  const int nstages = my_tiles * nk;
+  const bf16_t* zl = (const bf16_t*)dj_zero_line;
+
+  auto issue = [&](int s) {
+    const int tl = s / nk, kt = s - tl * nk;
+    const int m0 = (mt0 + tl * mstride) * NT2_BM, k0 = kt * NT2_BK;
+    unsigned char* sa = smem + (s % NT2_NS) * NT2_STAGE;
+    unsigned char* sb = sa + NT2_ABYTES;
+    const int rsub = lane >> 3, cp = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = w * 4 + i, row = piece * 8 + rsub;
+      const int kk = k0 + ((cp ^ ((row >> 1) & 7)) << 3);
+      const bf16_t* src = (m0 + row < M && kk < K) ? A + (int64_t)(m0 + row) * lda + kk : zl;
+      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(sa) + piece * 1024));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = w * 2 + i, row = piece * 8 + rsub;
+      const int kk = k0 + ((cp ^ ((row >> 1) & 7)) << 3);
+      const bf16_t* src = (n0 + row < N && kk < K) ? Bt + (int64_t)(n0 + row) * ldb + kk : zl;
+      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(sb) + piece * 1024));
+    }
+  };
+
+  f32x16 acc[2][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  zero_acc();
+
+  if (nstages > 0) issue(0);
+  if (nstages > 1) issue(1);
+  for (int s = 0; s < nstages; ++s) {
+    if (s + 1 < nstages)
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + 2 < nstages) issue(s + 2);
+    const unsigned char* sa = smem + (s % NT2_NS) * NT2_STAGE;
+    const unsigned char* sb = sa + NT2_ABYTES;
+#pragma unroll
+    for (int kc = 0; kc < NT2_BK / 16; ++kc) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra = wr * 64 + i * 32 + l31, rb = wc * 64 + i * 32 + l31;
+        fa[i] = *(const bf16x8*)(sa + ra * 128 + (((2 * kc + h) ^ ((ra >> 1) & 7)) << 4));
+        fb[i] = *(const bf16x8*)(sb + rb * 128 + (((2 * kc + h) ^ ((rb >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dj_mfma(acc[i][j], fa[i], fb[j]);
+    }
+    const int tl = s / nk, kt = s - tl * nk;
+    if (kt == nk - 1) {       // tile finished: epilogue (the next tiles' DMA is already in flight)
+      const int m0 = (mt0 + tl * mstride) * NT2_BM;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = n0 + wc * 64 + j * 32 + l31;
+          const int rowb = m0 + wr * 64 + i * 32;
+          if (col < N && rowb < M) {
+            const float bv = bias ? bias[col] : 0.f;
+            if (c_frag) {
+              float x[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) x[r] = acc[i][j][r] + bv;
+              const int64_t rb = rowb >> 5, cb = (n0 + wc * 64 + j * 32) >> 5;
+              store_frag(C + ((rb * (N >> 5) + cb) * 64 + lane) * 16, x);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int row = rowb + dj_crow(r, lane);
+                if (row < M) C[(int64_t)row * ldc + col] = dj_from_f32<TC>(acc[i][j][r] + bv);
+              }
+            }
+          }
+        }
+      zero_acc();
+    }
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ launchers (internal C++ API)
@@ -605,6 +748,40 @@ int dj_launch_gemm_nt(int dtype, int M, int N, int K, const void* A, int lda, co
   if ((K % epl) || (lda % epl) || (ldb % epl)) return 1001;
   const int c_is_f32 = c_mode == 1, c_frag = c_mode == 2;
   if (c_frag && ((M % 32) || (N % 32))) return 1004;
+  if (dtype == DJ_BF16 && !getenv("DJ_NT_OLD")) {
+    const int ntn2 = (N + NT2_BN - 1) / NT2_BN, ntm2 = (M + NT2_BM - 1) / NT2_BM;
+    // persistent grid: one workgroup per CU.  XCD-aware schedule when there is enough work:
+    // 32 slots per XCD are split into teams of ntn2 workgroups, one A panel per team at a time.
+    int grid2, xcd_map = 0;
+    if (ntn2 <= 32 && ntm2 >= 64 && !getenv("DJ_NT_NOXCD")) {
+      grid2 = 256;
+      xcd_map = 1;
+    } else {
+      int mrows = 256 / ntn2;                       // concurrent A panels
+      if (mrows < 1) mrows = 1;
+      if (mrows > ntm2) mrows = ntm2;
+      grid2 = mrows * ntn2;
+    }
+    const size_t smem = (size_t)NT2_NS * NT2_STAGE;
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_dma_kernel<bf16_t>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)gemm_nt_bf16_dma_kernel<float>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+      attr_done = true;
+    }
+    if (c_is_f32)
+      hipLaunchKernelGGL(gemm_nt_bf16_dma_kernel<float>, dim3(grid2), dim3(512), smem, st, M, N, K, (const bf16_t*)A,
+                         lda, (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn2, ntm2, c_frag, xcd_map);
+    else
+      hipLaunchKernelGGL(gemm_nt_bf16_dma_kernel<bf16_t>, dim3(grid2), dim3(512), smem, st, M, N, K,
+                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn2, ntm2, c_frag,
+                         xcd_map);
+    return (int)hipGetLastError();
+  }
   int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
   dim3 grid((unsigned)(ntn * (int64_t)ntm)), block(256);
   if (dtype == DJ_F32) {
@@ -674,10 +851,12 @@ int dj_launch_lstm_wgrad(int dtype, int64_t M, int steps, const void* X, int DP,
     int nta = (DP + H + WG_T - 1) / WG_T;
     a.ntiles = a.ntn * nta;
     int64_t want = (256 + a.ntiles - 1) / a.ntiles;
+    want = (want + 7) / 8 * 8;                       // multiple of 8 row splits: one XCD per split residue
     int64_t rps = (M + want - 1) / want;
     rps = ((rps + WG_BK - 1) / WG_BK) * WG_BK;
     a.rows_per_split = rps;
-    int splits = (int)((M + rps - 1) / rps);
+    int splits = (int)want;                          // trailing splits may be empty (nkt = 0)
+    a.xcd_map = getenv("DJ_WG_NOXCD") ? 0 : 1;
     const size_t smem = (size_t)WG_NS * WG_STAGE;
     static bool attr_done = false;
     if (!attr_done) {
