@@ -91,6 +91,35 @@ def cpu_baseline(cfg, T, N, sample_b, pin, pdr):
             "loss": loss}
 
 
+def generation_bench(dtype, steps):
+    """Secondary metric (BASELINE configs[3]): autoregressive sampling, 3 genre style vectors,
+    N=48 notes, fused dj_generate_step per time step (time-axis window + incremental note axis)."""
+    import contextlib
+    import io
+    from music_generator_amd import generate as Gn
+    from music_generator_amd.dataset import compute_genre
+    from music_generator_amd.model import build_models
+    models = build_models(dtype=dtype, seed=5)
+    styles = [compute_genre(i) for i in range(3)]
+    np.random.seed(0)
+    bars = (steps + 1 + 15) // 16
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        g = Gn.generate(models, bars, styles)
+        next(g)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        for _ in g:
+            n += 1
+            if n >= steps:
+                break
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"metric": "gen notes/sec", "value": round(3 * 48 * n / dt, 1), "unit": "notes/sec",
+            "ms_per_time_step": round(dt / n * 1e3, 3), "pieces": 3, "notes": 48, "window": 128, "steps": n,
+            "dtype": dtype, "path": "dj_generate_step (fused), NumPy MT19937 draws in reference order"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +131,7 @@ def main():
     ap.add_argument("--notes", type=int, default=128)
     ap.add_argument("--cpu-sample", type=int, default=2, help="sequences in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--gen-steps", type=int, default=32, help="generated time steps for the secondary metric (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -205,6 +235,10 @@ def main():
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and args.gen_steps > 0:
+            del eng
+            torch.cuda.empty_cache()
+            out["generation"] = generation_bench(args.dtype, args.gen_steps)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

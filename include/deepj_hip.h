@@ -94,6 +94,18 @@ int32_t dj_time_model_predict(const dj_config* cfg, const float* params, const f
 int32_t dj_note_model_predict(const dj_config* cfg, const float* params, const float* features, const float* chosen,
                               const float* style, float* out, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* One generated time step for cfg->batch (<= 8) pieces = the loop body of generate()
+ * (generate.py:104-118): time_model on the sliding window notes_win [G,T,N,3] / beat_win
+ * [G,T,16] / style_win [G,T,S] (stateless, from zero state), then the N notes sampled low
+ * to high with the note-axis state carried from note to note (equivalent to the reference's
+ * N note_model.predict calls).  uniforms [2*N*G] (float64, device) are consumed in the
+ * reference's draw order (note-major, piece-minor, replay draw only after a successful play
+ * draw, generate.py:52-58); *draws_used returns how many were consumed.  temperature [G]
+ * (apply_temperature, generate.py:81-91).  next_notes [G,N,3] = (play, replay, volume). */
+int32_t dj_generate_step(const dj_config* cfg, const float* params, const float* notes_win, const float* beat_win,
+                         const float* style_win, const double* uniforms, const float* temperature, float* next_notes,
+                         int32_t* draws_used, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- single-kernel entry points (unit-tested against the oracle one by one) ---- */
 
 /* C[M,N] = A[M,K] * Bt[N,K]^T + bias[N]; operands in `dtype`.  c_mode: 0 = row-major C in the

@@ -56,7 +56,7 @@ _SIGS = {
     "dj_profile_read": (C.c_int32, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dj_generate_step": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
 }
-OPTIONAL = {"dj_generate_step"}
+OPTIONAL = set()
 
 
 def load():

@@ -82,3 +82,8 @@ int dj_launch_cvt_to_f32(int dtype, const void* in, int64_t n, float* out, hipSt
 int dj_launch_nadam(float* p, const float* g, float* m, float* v, int64_t n, const void* na, hipStream_t st);
 int dj_launch_ta_to_canonical(int dtype, const void* Hin, float* out, int B, int T, int N, int Hd, hipStream_t st);
 int dj_launch_canonical_to_na(int dtype, const float* in, void* out, int B, int T, int N, int Hd, hipStream_t st);
+// dj_gen.hip
+int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int Ln, int S, int SU, const float* P,
+                             const int64_t* offs /* [6 + 5*Ln] */, const void* Htime, const float* style_last,
+                             int64_t style_stride, float* scratch, const double* uniforms, const float* temperature,
+                             float* next_notes, int* draws_used, int sigm, hipStream_t st);

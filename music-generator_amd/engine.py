@@ -210,6 +210,25 @@ class Engine:
         return out
 
 
+    def generate_step(self, params, notes_win, beat_win, style_win, uniforms, temperature):
+        """One generated time step for all `batch` pieces (dj_generate_step).  uniforms:
+        float64 device tensor [2*N*G]; temperature: float32 device tensor [G].
+        Returns (next_notes [G,N,3] float32 device, draws_used int32 device [1])."""
+        s3, sb, ss = self._shapes()
+        self._check(notes_win, s3, "notes"); self._check(beat_win, sb, "beat"); self._check(style_win, ss, "style")
+        G, N = self.batch, self.cfg.num_notes
+        assert uniforms.dtype == torch.float64 and uniforms.numel() >= 2 * N * G
+        assert temperature.dtype == torch.float32 and temperature.numel() == G
+        out = torch.empty((G, N, 3), dtype=torch.float32, device=self.device)
+        used = torch.zeros(1, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.dj_generate_step(C.byref(self.c), _lib.ptr(params), _lib.ptr(notes_win), _lib.ptr(beat_win),
+                                           _lib.ptr(style_win), _lib.ptr(uniforms), _lib.ptr(temperature),
+                                           _lib.ptr(out), _lib.ptr(used), self.ws_ptr, self.ws_bytes, _stream_ptr())
+        _lib.check(rc, "dj_generate_step")
+        return out, used
+
+
 class Nadam:
     """Keras-2 Nadam state (model.py:152) around dj_nadam_step."""
 

@@ -91,13 +91,50 @@ def process_inputs(ins):
     return [np.array(col) for col in zip(*ins)]
 
 
+def _fused_engine(models, n_pieces):
+    """The fused MI355X step (dj_generate_step) is used when the models are this package's
+    HIP models; any other duck-typed models (or DEEPJ_GENERATE_SLOW=1) take the reference
+    loop over predict() below."""
+    if os.environ.get("DEEPJ_GENERATE_SLOW") or n_pieces > 8:
+        return None
+    shared = getattr(models[1], "_s", None)
+    if shared is None or getattr(shared.backend, "name", "") != "hip":
+        return None
+    return shared, shared.engine(n_pieces, SEQ_LEN, train=False)
+
+
+def _fused_step(shared, engine, pieces):
+    """All N notes of one time step for every piece in one device call.  The device consumes
+    pre-drawn uniforms in the reference's order; NumPy's global stream is then advanced by
+    exactly the number consumed, so the stream position matches the reference loop."""
+    import torch
+    be = shared.backend
+    notes, beat, style = process_inputs([g.build_time_inputs() for g in pieces])
+    n_u = 2 * NUM_NOTES * len(pieces)
+    state = np.random.get_state()
+    uniforms = np.random.random_sample(n_u)
+    np.random.set_state(state)
+    u_dev = torch.as_tensor(uniforms, dtype=torch.float64).to(be.device)
+    temps = be.tensor(np.array([g.temperature for g in pieces], np.float32))
+    nxt, used = engine.generate_step(shared.params, be.tensor(notes), be.tensor(beat), be.tensor(style), u_dev, temps)
+    nxt = be.numpy(nxt)
+    np.random.random_sample(int(used.cpu()[0]))
+    for i, g in enumerate(pieces):
+        g.next_note[:, :] = nxt[i]
+
+
 def generate(models, num_bars, styles):
     """Generator over time steps; yields the list of per-piece note arrays [N, 3]
     (reference generate.py:98-121)."""
     print('Generating with styles:', styles)
     _, time_model, note_model = models
     pieces = [MusicGeneration(style) for style in styles]
+    fused = _fused_engine(models, len(pieces))
     for t in tqdm(range(NOTES_PER_BAR * num_bars)):
+        if fused is not None:
+            _fused_step(fused[0], fused[1], pieces)
+            yield [g.end_time(t) for g in pieces]
+            continue
         # note-invariant features of the whole window, last step only
         feats = np.array(time_model.predict(process_inputs([g.build_time_inputs() for g in pieces])))[:, -1:, :]
         for n in range(NUM_NOTES):
