@@ -208,8 +208,16 @@ def main():
         dom = max(fl, key=lambda k: kernels.get(k, 0.0))
         ms = kernels[dom]
         achieved = fl[dom] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        traffic, tsrc = None, None
+        try:                                            # HBM bytes per launch of that kernel from the committed PMC passes
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if args.dtype == "bf16" and (B, T, N) == (64, 128, 128) and dom in pm:
+                traffic, tsrc = pm[dom], "profiles/pmc_traffic.json: " + pm["source"]
+        except Exception:
+            pass
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype],
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
+                "traffic_source": tsrc,
                 "launches_per_step": lps[dom], "avg_launch_ms": round(ms / lps[dom], 4),
                 "flops_per_launch": fl[dom] / lps[dom]}
 
