@@ -106,6 +106,26 @@ int32_t dj_generate_step(const dj_config* cfg, const float* params, const float*
                          const float* style_win, const double* uniforms, const float* temperature, float* next_notes,
                          int32_t* draws_used, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Device-resident variant for hipGraph capture: ALL per-run state lives in HBM -- the sliding
+ * windows (ping-pong: *_src is read, *_dst receives the window advanced by one step), the
+ * MusicGeneration temperature / silent_time schedule (generate.py:60-79), the running offset
+ * into a pre-drawn pool of uniforms, and the emitted notes results[step] ([steps_cap,G,N,3]).
+ * One call = one time step, no host round trip, identical launch sequence every step, so the
+ * caller can capture two calls (src->dst, dst->src) into a graph and replay it. */
+typedef struct dj_gen_state {
+  int32_t step;                /* time steps generated so far (index into results)            */
+  int32_t draw_off;            /* uniforms consumed so far (index into the pool)              */
+  int32_t pad0, pad1;
+  double temperature[8];       /* per piece, float64 like the reference                        */
+  double default_temp[8];
+  int32_t silent[8];           /* silent_time, starts at NOTES_PER_BAR (generate.py:24)        */
+} dj_gen_state;
+int32_t dj_gen_state_size(void);
+int32_t dj_generate_step_resident(const dj_config* cfg, const float* params, void* state, float* results,
+                                  const double* uniform_pool, const float* notes_src, float* notes_dst,
+                                  const float* beat_src, float* beat_dst, const float* style_win, void* workspace,
+                                  int64_t workspace_bytes, void* stream);
+
 /* ---- single-kernel entry points (unit-tested against the oracle one by one) ---- */
 
 /* C[M,N] = A[M,K] * Bt[N,K]^T + bias[N]; operands in `dtype`.  c_mode: 0 = row-major C in the

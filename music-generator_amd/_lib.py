@@ -54,6 +54,8 @@ _SIGS = {
     "dj_profile_category_count": (C.c_int32, []),
     "dj_profile_category_name": (C.c_char_p, [C.c_int32]),
     "dj_profile_read": (C.c_int32, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "dj_gen_state_size": (C.c_int32, []),
+    "dj_generate_step_resident": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "dj_generate_step": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
 }
 OPTIONAL = set()

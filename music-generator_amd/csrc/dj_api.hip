@@ -566,8 +566,40 @@ int32_t dj_generate_step(const dj_config* cfg, const float* params, const float*
   }
   return dj_launch_generate_notes(p.c.dtype, p.B, p.T, p.N, p.Ht, p.Hn, p.Ln, p.S, p.SU, params, offs,
                                   c.at(p.w_H_t[p.Lt - 1]), style_win + (int64_t)(p.T - 1) * p.S, (int64_t)p.T * p.S,
-                                  c.at<float>(p.w_dX_n), uniforms, temperature, next_notes, draws_used,
-                                  p.c.recurrent_sigmoid, c.st);
+                                  c.at<float>(p.w_dX_n), uniforms, temperature, next_notes, draws_used, nullptr,
+                                  nullptr, p.c.recurrent_sigmoid, c.st);
+}
+
+int32_t dj_gen_state_size(void) { return dj_gen_state_bytes(); }
+
+int32_t dj_generate_step_resident(const dj_config* cfg, const float* params, void* state, float* results,
+                                  const double* uniform_pool, const float* notes_src, float* notes_dst,
+                                  const float* beat_src, float* beat_dst, const float* style_win, void* ws,
+                                  int64_t ws_bytes, void* stream) {
+  Plan p;
+  RUN(make_plan(cfg, p));
+  RUN(check_ws(p, ws, ws_bytes));
+  if (!params || !state || !results || !uniform_pool || !notes_src || !notes_dst || !beat_src || !beat_dst || !style_win)
+    return 1210;
+  if (p.B > 8 || p.NB != 16) return 1301;
+  const int64_t need = (int64_t)(8 * 64 + 4 * 8 * 512 + (int64_t)p.B * p.N * 4 * p.Hn) * 4;
+  if (need > p.Mn * (int64_t)p.nl[0].DP * p.esz) return 1302;
+  Ctx c{p, params, (char*)ws, (hipStream_t)stream, false, 0};
+  for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], false));
+  RUN(style_forward(c, style_win));
+  RUN(time_axis_forward(c, notes_src, beat_src));
+  int64_t offs[6 + 5 * MAXL];
+  offs[0] = p.p_style_W; offs[1] = p.p_style_b; offs[2] = p.p_nd_W; offs[3] = p.p_nd_b; offs[4] = p.p_vd_W;
+  offs[5] = p.p_vd_b;
+  for (int l = 0; l < p.Ln; ++l) {
+    offs[6 + 5 * l] = p.nl[l].dW; offs[7 + 5 * l] = p.nl[l].db; offs[8 + 5 * l] = p.nl[l].W; offs[9 + 5 * l] = p.nl[l].U;
+    offs[10 + 5 * l] = p.nl[l].b;
+  }
+  RUN(dj_launch_generate_notes(p.c.dtype, p.B, p.T, p.N, p.Ht, p.Hn, p.Ln, p.S, p.SU, params, offs,
+                               c.at(p.w_H_t[p.Lt - 1]), style_win + (int64_t)(p.T - 1) * p.S, (int64_t)p.T * p.S,
+                               c.at<float>(p.w_dX_n), uniform_pool, nullptr, nullptr, nullptr, state, results,
+                               p.c.recurrent_sigmoid, c.st));
+  return dj_launch_gen_advance(state, results, notes_src, notes_dst, beat_src, beat_dst, p.B, p.T, p.N, p.NB, c.st);
 }
 
 // ------------------------------------------------------------------ live kernel timing

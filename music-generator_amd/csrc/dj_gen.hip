@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int GEN_MAXG = 8;
+struct DjGenState;
 
 struct GenArgs {
   int G, N, Hn, Ht, Ln, S, SU, T;
@@ -27,10 +28,24 @@ struct GenArgs {
   int64_t style_stride;
   float* svec;                    // scratch: style [G,SU], sp_l [Ln][G][D0max]
   float* zx0;                     // scratch: [G, N, 4Hn]
-  const double* uniforms;         // [2*N*G]
+  const double* uniforms;         // [2*N*G]  (or the whole pool when `state` is set)
   const float* temperature;       // [G]
   float* next_notes;              // [G, N, 3]
   int* draws_used;
+  // device-resident generation (dj_generate_run): overrides the three fields above
+  struct DjGenState* state;
+  float* results;                 // [steps_cap, G, N, 3]
+};
+
+// Per-run state kept in HBM so that a generated time step needs no host round trip and the
+// kernel sequence can be captured once and replayed as a hipGraph.
+struct DjGenState {
+  int step;                       // time steps generated so far
+  int draw_off;                   // uniforms consumed so far
+  int pad0, pad1;
+  double temperature[GEN_MAXG];   // MusicGeneration.temperature (float64 like the reference)
+  double default_temp[GEN_MAXG];
+  int silent[GEN_MAXG];           // MusicGeneration.silent_time
 };
 
 // style = style_in W_s + b_s ; sp_l = tanh(style Wd_l + bd_l)    (model.py:141-142,110-113)
@@ -88,7 +103,8 @@ __global__ void gen_sample_kernel(GenArgs a) {
   const int col = threadIdx.x;
   for (int i = threadIdx.x; i < 2 * a.Ln * G * Hn; i += blockDim.x) hs[i] = 0.f;
   for (int i = threadIdx.x; i < G * 4; i += blockDim.x) chosen[i] = 0.f;
-  if (threadIdx.x == 0) kdraw = 0;
+  if (threadIdx.x == 0) kdraw = a.state ? a.state->draw_off : 0;
+  float* out_notes = a.state ? a.results + (int64_t)a.state->step * G * a.N * 3 : a.next_notes;
   __syncthreads();
 
   for (int n = 0; n < a.N; ++n) {
@@ -166,7 +182,7 @@ __global__ void gen_sample_kernel(GenArgs a) {
       for (int g = 0; g < G; ++g) {
         float pp = dj_sigmoid(logit[g * 4]), pr = dj_sigmoid(logit[g * 4 + 1]);
         const float vol = logit[g * 4 + 2];
-        const float temp = a.temperature[g];
+        const float temp = a.state ? (float)a.state->temperature[g] : a.temperature[g];
         if (temp != 1.0f) {                       // apply_temperature, float32 like the reference (generate.py:81-91)
           float x0 = -logf(1.0f / pp - 1.0f), x1 = -logf(1.0f / pr - 1.0f);
           pp = 1.0f / (1.0f + expf(-x0 / temp));
@@ -181,7 +197,7 @@ __global__ void gen_sample_kernel(GenArgs a) {
         chosen[g * 4] = play;
         chosen[g * 4 + 1] = rep;
         chosen[g * 4 + 2] = v;
-        float* o = a.next_notes + ((int64_t)g * a.N + n) * 3;
+        float* o = out_notes + ((int64_t)g * a.N + n) * 3;
         o[0] = play;
         o[1] = rep;
         o[2] = v;
@@ -190,10 +206,62 @@ __global__ void gen_sample_kernel(GenArgs a) {
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) *a.draws_used = kdraw;
+  if (threadIdx.x == 0) {
+    if (a.state)
+      a.state->draw_off = kdraw;
+    else
+      *a.draws_used = kdraw;
+  }
+}
+
+
+// end_time() of the reference on the device (generate.py:60-79): silence / temperature schedule,
+// then the windows slide by one step: dst[:, t] = src[:, t+1], dst[:, T-1] = new notes / beat(t).
+__global__ void gen_advance_kernel(DjGenState* st, const float* __restrict__ results, const float* __restrict__ nsrc,
+                                   float* __restrict__ ndst, const float* __restrict__ bsrc, float* __restrict__ bdst,
+                                   int G, int T, int N, int NB, int phase) {
+  const int step = st->step;
+  const float* nn = results + (int64_t)step * G * N * 3;
+  const int tot_n = G * T * N * 3, tot_b = G * T * NB;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < tot_n + tot_b; i += gridDim.x * blockDim.x) {
+    if (i < tot_n) {
+      const int e = i % (N * 3), t = (i / (N * 3)) % T, g = i / (N * 3 * T);
+      ndst[i] = t + 1 < T ? nsrc[i + N * 3] : nn[g * N * 3 + e];
+    } else {
+      const int j = i - tot_n, e = j % NB, t = (j / NB) % T;
+      bdst[j] = t + 1 < T ? bsrc[j + NB] : ((e == step % NB) ? 1.f : 0.f);   // compute_beat(t, NOTES_PER_BAR)
+    }
+  }
+}
+// runs after gen_advance_kernel of the same step (separate launch: every block above reads st->step)
+__global__ void gen_state_kernel(DjGenState* st, const float* __restrict__ results, int G, int N) {
+  const int g = threadIdx.x;
+  if (g < G) {
+    const float* nn = results + ((int64_t)st->step * G + g) * N * 3;
+    bool any = false;
+    for (int i = 0; i < N * 3; ++i) any = any || (nn[i] != 0.f);
+    if (!any) {
+      st->silent[g] += 1;
+      if (st->silent[g] >= 16) st->temperature[g] += 0.1;
+    } else {
+      st->silent[g] = 0;
+      st->temperature[g] = st->default_temp[g];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) st->step += 1;
 }
 
 }  // namespace
+
+int dj_launch_gen_advance(void* state, const float* results, const float* nsrc, float* ndst, const float* bsrc,
+                          float* bdst, int G, int T, int N, int NB, hipStream_t st) {
+  hipLaunchKernelGGL(gen_advance_kernel, dim3(64), dim3(256), 0, st, (DjGenState*)state, results, nsrc, ndst, bsrc,
+                     bdst, G, T, N, NB, 0);
+  hipLaunchKernelGGL(gen_state_kernel, dim3(1), dim3(64), 0, st, (DjGenState*)state, results, G, N);
+  return (int)hipGetLastError();
+}
+int dj_gen_state_bytes() { return (int)sizeof(DjGenState); }
 
 // Htime: TA-ordered top time-axis h buffer of the window (operand dtype).  scratch: float workspace
 // of at least GEN_MAXG*64 + 4*GEN_MAXG*512 + G*N*4Hn floats.
@@ -201,7 +269,7 @@ int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int
                              const int64_t* offs /* [6 + 5*Ln] */, const void* Htime, const float* style_last,
                              int64_t style_stride,
                              float* scratch, const double* uniforms, const float* temperature, float* next_notes,
-                             int* draws_used, int sigm, hipStream_t st) {
+                             int* draws_used, void* state, float* results, int sigm, hipStream_t st) {
   if (G < 1 || G > GEN_MAXG || Ln < 1 || Ln > 4 || 4 * Hn > 1024 || Ht + 3 > 512 || SU > 64) return 1300;
   GenArgs a;
   a.G = G; a.N = N; a.Hn = Hn; a.Ht = Ht; a.Ln = Ln; a.S = S; a.SU = SU; a.T = T; a.P = P;
@@ -217,6 +285,7 @@ int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int
   a.svec = scratch;
   a.zx0 = scratch + GEN_MAXG * 64 + 4 * GEN_MAXG * 512;
   a.uniforms = uniforms; a.temperature = temperature; a.next_notes = next_notes; a.draws_used = draws_used;
+  a.state = (DjGenState*)state; a.results = results;
   hipLaunchKernelGGL(gen_prep_kernel, dim3(1), dim3(256), 0, st, a);
   dim3 gz((4 * Hn + 255) / 256, G * N);
   if (dtype == DJ_F32)

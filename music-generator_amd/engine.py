@@ -229,6 +229,89 @@ class Engine:
         return out, used
 
 
+GEN_STATE_DTYPE = np.dtype([("step", "<i4"), ("draw_off", "<i4"), ("pad0", "<i4"), ("pad1", "<i4"),
+                            ("temperature", "<f8", (8,)), ("default_temp", "<f8", (8,)), ("silent", "<i4", (8,))])
+
+
+class ResidentGeneration:
+    """Device-resident sampling run (dj_generate_step_resident): windows, temperature schedule,
+    RNG-draw offset and emitted notes live in HBM; two ping-pong steps are captured into one
+    hipGraph (through torch.cuda.CUDAGraph) and replayed.  `run(k, uniforms)` advances k steps."""
+
+    def __init__(self, engine: Engine, params, styles, default_temp=1.0, steps_cap=4096, use_graph=True):
+        self.e, self.params = engine, params
+        G, T, N = engine.batch, engine.time_steps, engine.cfg.num_notes
+        dev = engine.device
+        assert engine.lib.dj_gen_state_size() == GEN_STATE_DTYPE.itemsize
+        z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)
+        self.notes = [z(G, T, N, 3), z(G, T, N, 3)]
+        self.beat = [z(G, T, engine.cfg.notes_per_bar), z(G, T, engine.cfg.notes_per_bar)]
+        st = np.asarray(styles, np.float32)                       # [G, S], repeated over the window
+        self.style = torch.from_numpy(np.repeat(st[:, None, :], T, axis=1).copy()).to(dev)
+        self.results = z(steps_cap, G, N, 3)
+        self.cap = steps_cap
+        host = np.zeros(1, GEN_STATE_DTYPE)
+        host["temperature"][0, :G] = default_temp
+        host["default_temp"][0, :G] = default_temp
+        host["silent"][0, :G] = engine.cfg.notes_per_bar          # generate.py:24
+        self.state = torch.from_numpy(host.view(np.uint8).copy()).to(dev)
+        self.pool = torch.zeros(2 * N * G * 64, dtype=torch.float64, device=dev)
+        self.cur = 0                                              # which window buffer is current
+        self.graph = None
+        self._want_graph = use_graph
+
+    def _step(self, src):
+        e = self.e
+        with torch.cuda.device(e.device):
+            rc = e.lib.dj_generate_step_resident(
+                C.byref(e.c), _lib.ptr(self.params), _lib.ptr(self.state), _lib.ptr(self.results), _lib.ptr(self.pool),
+                _lib.ptr(self.notes[src]), _lib.ptr(self.notes[1 - src]), _lib.ptr(self.beat[src]),
+                _lib.ptr(self.beat[1 - src]), _lib.ptr(self.style), e.ws_ptr, e.ws_bytes, _stream_ptr())
+        _lib.check(rc, "dj_generate_step_resident")
+
+    def read_state(self):
+        return self.state.cpu().numpy().view(GEN_STATE_DTYPE)[0]
+
+    def _set_draw_off(self, v):
+        host = self.read_state().copy()
+        host["draw_off"] = v
+        self.state.copy_(torch.from_numpy(np.array([host]).view(np.uint8).reshape(-1)))
+
+    def run(self, k, uniforms):
+        """Advance k time steps consuming `uniforms` (float64, >= 2*N*G*k values, reference
+        draw order).  Returns (notes [k,G,N,3] float32 numpy, draws consumed)."""
+        G, N = self.e.batch, self.e.cfg.num_notes
+        assert len(uniforms) >= 2 * N * G * k and len(uniforms) <= self.pool.numel()
+        st0 = int(self.read_state()["step"])
+        assert st0 + k <= self.cap
+        self.pool[:len(uniforms)].copy_(torch.as_tensor(np.asarray(uniforms, np.float64)))
+        self._set_draw_off(0)
+        done = 0
+        if self._want_graph and self.graph is None and self.cur == 0 and k >= 2:
+            try:                                                  # capture two ping-pong steps once
+                self._step(0); self._step(1)                      # warm-up (also one-time function attributes)
+                done = 2
+                torch.cuda.synchronize(self.e.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._step(0); self._step(1)
+                self.graph = g
+            except Exception:
+                self.graph = None
+                self._want_graph = False
+                torch.cuda.synchronize(self.e.device)
+        while done < k:
+            if self.graph is not None and self.cur == 0 and k - done >= 2:
+                self.graph.replay()
+                done += 2
+            else:
+                self._step(self.cur)
+                self.cur ^= 1
+                done += 1
+        out = self.results[st0:st0 + k].cpu().numpy()
+        return out, int(self.read_state()["draw_off"])
+
+
 class Nadam:
     """Keras-2 Nadam state (model.py:152) around dj_nadam_step."""
 

@@ -91,10 +91,12 @@ def process_inputs(ins):
     return [np.array(col) for col in zip(*ins)]
 
 
+GEN_CHUNK = NOTES_PER_BAR          # time steps per device launch batch of the resident path
+
+
 def _fused_engine(models, n_pieces):
-    """The fused MI355X step (dj_generate_step) is used when the models are this package's
-    HIP models; any other duck-typed models (or DEEPJ_GENERATE_SLOW=1) take the reference
-    loop over predict() below."""
+    """The fused MI355X path is used when the models are this package's HIP models; any other
+    duck-typed models (or DEEPJ_GENERATE_SLOW=1) take the reference loop over predict() below."""
     if os.environ.get("DEEPJ_GENERATE_SLOW") or n_pieces > 8:
         return None
     shared = getattr(models[1], "_s", None)
@@ -103,24 +105,57 @@ def _fused_engine(models, n_pieces):
     return shared, shared.engine(n_pieces, SEQ_LEN, train=False)
 
 
+def _draw_ahead(n):
+    """n uniforms from NumPy's global stream WITHOUT consuming them."""
+    state = np.random.get_state()
+    u = np.random.random_sample(n)
+    np.random.set_state(state)
+    return u
+
+
 def _fused_step(shared, engine, pieces):
-    """All N notes of one time step for every piece in one device call.  The device consumes
-    pre-drawn uniforms in the reference's order; NumPy's global stream is then advanced by
-    exactly the number consumed, so the stream position matches the reference loop."""
+    """All N notes of one time step for every piece in one device call (dj_generate_step).  The
+    device consumes pre-drawn uniforms in the reference's order; NumPy's global stream is then
+    advanced by exactly the number consumed, so its position matches the reference loop."""
     import torch
     be = shared.backend
     notes, beat, style = process_inputs([g.build_time_inputs() for g in pieces])
-    n_u = 2 * NUM_NOTES * len(pieces)
-    state = np.random.get_state()
-    uniforms = np.random.random_sample(n_u)
-    np.random.set_state(state)
-    u_dev = torch.as_tensor(uniforms, dtype=torch.float64).to(be.device)
+    u_dev = torch.as_tensor(_draw_ahead(2 * NUM_NOTES * len(pieces)), dtype=torch.float64).to(be.device)
     temps = be.tensor(np.array([g.temperature for g in pieces], np.float32))
     nxt, used = engine.generate_step(shared.params, be.tensor(notes), be.tensor(beat), be.tensor(style), u_dev, temps)
     nxt = be.numpy(nxt)
     np.random.random_sample(int(used.cpu()[0]))
     for i, g in enumerate(pieces):
         g.next_note[:, :] = nxt[i]
+
+
+def _generate_resident(shared, engine, pieces, total_steps):
+    """Device-resident run: windows / temperature schedule / draw offset stay in HBM and the
+    step is replayed from a hipGraph (engine.ResidentGeneration).  The host mirrors every step
+    into the MusicGeneration objects (same end_time logic), GEN_CHUNK steps at a time."""
+    from .engine import ResidentGeneration
+    run = ResidentGeneration(engine, shared.params, [g.style_memory[-1] for g in pieces],
+                             default_temp=pieces[0].default_temp, steps_cap=total_steps,
+                             use_graph=not os.environ.get("DEEPJ_GENERATE_NOGRAPH"))
+    t = 0
+    while t < total_steps:
+        k = min(GEN_CHUNK, total_steps - t)
+        notes, used = run.run(k, _draw_ahead(2 * NUM_NOTES * len(pieces) * k))
+        spent = 0
+        for j in range(k):
+            # advance the real stream step by step: one draw per note + one per played note, so the
+            # stream position at every yield equals the reference loop's
+            d = NUM_NOTES * len(pieces) + int(notes[j, :, :, 0].sum())
+            np.random.random_sample(d)
+            spent += d
+            for i, g in enumerate(pieces):
+                g.next_note[:, :] = notes[j, i]
+            yield [g.end_time(t + j) for g in pieces]
+        assert spent == used, (spent, used)
+        t += k
+    st = run.read_state()                                  # device schedule == host schedule
+    for i, g in enumerate(pieces):
+        assert abs(st["temperature"][i] - g.temperature) < 1e-9 and st["silent"][i] == g.silent_time
 
 
 def generate(models, num_bars, styles):
@@ -130,6 +165,10 @@ def generate(models, num_bars, styles):
     _, time_model, note_model = models
     pieces = [MusicGeneration(style) for style in styles]
     fused = _fused_engine(models, len(pieces))
+    if fused is not None and not os.environ.get("DEEPJ_GENERATE_STEPWISE"):
+        yield from tqdm(_generate_resident(fused[0], fused[1], pieces, NOTES_PER_BAR * num_bars),
+                        total=NOTES_PER_BAR * num_bars)
+        return
     for t in tqdm(range(NOTES_PER_BAR * num_bars)):
         if fused is not None:
             _fused_step(fused[0], fused[1], pieces)

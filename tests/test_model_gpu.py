@@ -204,6 +204,7 @@ def test_fused_generation_step_matches_predict_loop(gpu_device, monkeypatch):
     w[names.index("note_dense/bias")] = np.array([0.5, 0.0], np.float32)
     hm[0].set_weights(w)
     styles = [compute_genre(i) for i in range(3)]
+    monkeypatch.setenv("DEEPJ_GENERATE_STEPWISE", "1")          # the per-step API (dj_generate_step)
     np.random.seed(11)
     fast = np.array(list(Gn.generate(hm, 1, styles))[:6])
     after_fast = np.random.random_sample(3)
@@ -229,3 +230,32 @@ def test_fused_generation_step_matches_predict_loop(gpu_device, monkeypatch):
         next(g3)
     pos_slow = np.random.random_sample(3)
     np.testing.assert_array_equal(pos_fast, pos_slow)
+
+
+def test_resident_graph_generation_matches_stepwise(gpu_device, monkeypatch):
+    """Device-resident, hipGraph-replayed generation == step-wise fused == predict loop."""
+    from music_generator_amd import generate as Gn
+    from music_generator_amd.dataset import compute_genre
+    from music_generator_amd.model import build_models
+    hm = build_models(seed=33)
+    w = hm[0].get_weights()
+    names = [n for n, _, _ in hm[0]._s.layout]
+    w[names.index("note_dense/bias")] = np.array([-0.5, 0.0], np.float32)
+    hm[0].set_weights(w)
+    styles = [compute_genre(i) for i in range(3)]
+    np.random.seed(3)
+    gen = Gn.generate(hm, 2, styles)                           # 32 steps: 2 chunks, graph replays
+    head = [next(gen) for _ in range(5)]
+    pos_mid = np.random.get_state()[2]                         # stream position after 5 yielded steps
+    res = np.array(head + list(gen))
+    pos_res = np.random.random_sample(2)
+    monkeypatch.setenv("DEEPJ_GENERATE_STEPWISE", "1")
+    np.random.seed(3)
+    gen = Gn.generate(hm, 2, styles)
+    head = [next(gen) for _ in range(5)]
+    assert np.random.get_state()[2] == pos_mid
+    stp = np.array(head + list(gen))
+    pos_stp = np.random.random_sample(2)
+    np.testing.assert_array_equal(res, stp)
+    np.testing.assert_array_equal(pos_res, pos_stp)
+    assert 0 < res[..., 0].sum() < res[..., 0].size              # some notes, some silence
