@@ -12,8 +12,6 @@
 // tile's global loads in flight during the MFMAs (register-staged pipeline).
 // LDS rows hold k contiguously with a 16-byte pad: 144-byte row stride makes the
 // ds_read_b128 fragment reads bank-conflict free (MI355X_MICROARCH LDS table).
-#include <stdlib.h>
-
 #include "dj_kernels.h"
 
 namespace {
@@ -748,12 +746,12 @@ int dj_launch_gemm_nt(int dtype, int M, int N, int K, const void* A, int lda, co
   if ((K % epl) || (lda % epl) || (ldb % epl)) return 1001;
   const int c_is_f32 = c_mode == 1, c_frag = c_mode == 2;
   if (c_frag && ((M % 32) || (N % 32))) return 1004;
-  if (dtype == DJ_BF16 && !getenv("DJ_NT_OLD")) {
+  if (dtype == DJ_BF16) {
     const int ntn2 = (N + NT2_BN - 1) / NT2_BN, ntm2 = (M + NT2_BM - 1) / NT2_BM;
     // persistent grid: one workgroup per CU.  XCD-aware schedule when there is enough work:
     // 32 slots per XCD are split into teams of ntn2 workgroups, one A panel per team at a time.
     int grid2, xcd_map = 0;
-    if (ntn2 <= 32 && ntm2 >= 64 && !getenv("DJ_NT_NOXCD")) {
+    if (ntn2 <= 32 && ntm2 >= 64) {
       grid2 = 256;
       xcd_map = 1;
     } else {
@@ -810,7 +808,7 @@ int dj_launch_gemm_tn(int dtype, int64_t M, int Ka, int ka_valid, int N, const v
   rps = ((rps + 63) / 64) * 64;
   int splits = (int)((M + rps - 1) / rps);
   dim3 grid((unsigned)(ntiles * splits)), block(256);
-  if (dtype == DJ_BF16 && (N % TN2_TB) == 0 && (M % TN2_BK) == 0 && !getenv("DJ_TN_OLD")) {
+  if (dtype == DJ_BF16 && (N % TN2_TB) == 0 && (M % TN2_BK) == 0) {
     // DMA-ring kernel: 128 x 256 tiles, ~2 resident rounds of workgroups
     int ntn2 = N / TN2_TB, nta2 = (Ka + TN2_TA - 1) / TN2_TA, nt2 = ntn2 * nta2;
     int64_t want = (512 + nt2 - 1) / nt2;
@@ -842,8 +840,7 @@ int dj_launch_gemm_tn(int dtype, int64_t M, int Ka, int ka_valid, int N, const v
 int dj_launch_lstm_wgrad(int dtype, int64_t M, int steps, const void* X, int DP, int D, const void* Hs, int H,
                          const void* dZ, int N, float* dW, float* dU, const void* zeros, hipStream_t st) {
   if (M <= 0) return 0;
-  if (dtype == DJ_BF16 && (N % WG_T) == 0 && (M % 32) == 0 && (DP % 8) == 0 && (H % 8) == 0 && zeros &&
-      !getenv("DJ_WGRAD_OLD")) {
+  if (dtype == DJ_BF16 && (N % WG_T) == 0 && (M % 32) == 0 && (DP % 8) == 0 && (H % 8) == 0 && zeros) {
     WgradArgs a;
     a.M = M; a.X = (const bf16_t*)X; a.DP = DP; a.D = D; a.Hs = (const bf16_t*)Hs; a.H = H; a.steps = steps;
     a.dZ = (const bf16_t*)dZ; a.N = N; a.dW = dW; a.dU = dU; a.zeros = (const bf16_t*)zeros;
@@ -856,7 +853,7 @@ int dj_launch_lstm_wgrad(int dtype, int64_t M, int steps, const void* X, int DP,
     rps = ((rps + WG_BK - 1) / WG_BK) * WG_BK;
     a.rows_per_split = rps;
     int splits = (int)want;                          // trailing splits may be empty (nkt = 0)
-    a.xcd_map = getenv("DJ_WG_NOXCD") ? 0 : 1;
+    a.xcd_map = 1;
     const size_t smem = (size_t)WG_NS * WG_STAGE;
     static bool attr_done = false;
     if (!attr_done) {
