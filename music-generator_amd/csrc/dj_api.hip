@@ -67,7 +67,7 @@ struct Plan {
   int64_t w_Wt_n[MAXL], w_Wc_n[MAXL], w_Uf_n[MAXL], w_Ub_n[MAXL];
   int64_t w_X_t[MAXL], w_Z_t[MAXL], w_H_t[MAXL], w_C_t[MAXL];
   int64_t w_X_n[MAXL], w_Z_n[MAXL], w_H_n[MAXL], w_C_n[MAXL];
-  int64_t w_dH_t, w_dX_t, w_dH_n, w_dX_n, w_featin, w_dZ_t, w_dZ_n, w_zero;
+  int64_t w_dH_t, w_dX_t, w_dH_n, w_dX_n, w_featin, w_dZ_t, w_dZ_n, w_zero, w_Xcol, w_Ycol;
   int64_t ws_bytes;
 };
 
@@ -146,6 +146,8 @@ int make_plan(const dj_config* cfg, Plan& p) {
   p.w_featin = wtake(p.Mn * p.Ht * p.esz);   // note_model.predict: features in NA order
   p.w_dZ_t = wtake(p.Mt * 4 * p.Ht * p.esz);  // row-major dz of the layer in flight (BPTT)
   p.w_dZ_n = wtake(p.Mn * 4 * p.Hn * p.esz);
+  p.w_Xcol = wtake(p.Mt * 80 * p.esz);       // im2col view of the (dropped-out) notes, conv-kernel tap order
+  p.w_Ycol = wtake(p.Mt * 64 * p.esz);       // tanh(conv) stash, overwritten by its gradient in BPTT
   p.w_zero = wtake(256);                      // a zero line (h_{-1} rows of the fused weight-gradient GEMM)
   p.ws_bytes = w;
   return 0;
@@ -229,7 +231,8 @@ int time_axis_forward(const Ctx& c, const float* notes, const float* beat) {
   fa.d_style = mkdrop(c.seed, DJ_SITE_TSTYLE + 0, pdr, c.train);
   {
     ProfScope ps(PC_FEATURE_FWD, c.st);
-    RUN(dj_launch_feature_fwd(dt, &fa, c.at(p.w_X_t[0]), c.st));
+    RUN(dj_launch_feature_fwd(dt, &fa, c.at(p.w_X_t[0]), c.train ? c.at(p.w_Xcol) : nullptr,
+                              c.train ? c.at(p.w_Ycol) : nullptr, c.st));
   }
   for (int l = 0; l < p.Lt; ++l) {
     const LstmP& L = p.tl[l];
@@ -456,8 +459,10 @@ int32_t dj_train_fwd_bwd(const dj_config* cfg, const float* params, float* grads
       fa.d_notes = mkdrop(seed, DJ_SITE_NOTES, pin, true); fa.d_beat = mkdrop(seed, DJ_SITE_BEAT, pin, true);
       fa.d_conv = mkdrop(seed, DJ_SITE_CONV, pdr, true); fa.d_style = mkdrop(seed, DJ_SITE_TSTYLE + 0, pdr, true);
       ProfScope ps(PC_FEATURE_BWD, c.st);
-      RUN(dj_launch_feature_bwd(dt, &fa, c.at(p.w_dX_t), G + p.p_conv_W, G + p.p_conv_b,
-                                c.at<float>(p.w_dpre_t[0]), c.st));
+      RUN(dj_launch_feature_bwd(dt, &fa, c.at(p.w_dX_t), c.at(p.w_Ycol), G + p.p_conv_b, c.at<float>(p.w_dpre_t[0]),
+                                c.st));
+      // dWc[72,64] = Xcol^T (dropped notes, im2col) * d(conv pre-activation)
+      RUN(dj_launch_gemm_tn(dt, p.Mt, 80, 72, 64, c.at(p.w_Xcol), 80, c.at(p.w_Ycol), 64, G + p.p_conv_W, 64, 0, 0, c.st));
     }
   }
   // style Dense layers and the style embedding (model.py:141-142,77,110-113)

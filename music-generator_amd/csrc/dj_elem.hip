@@ -129,10 +129,14 @@ __global__ void bins_kernel(const float* __restrict__ notes, float* __restrict__
 // ------------------------------------------------------------------ feature assembly
 
 constexpr int CONV_K = 24, CONV_C = 3, CONV_O = 64, CONV_L = 11;   // 'same': pad 11 left / 12 right
+constexpr int XCOL_LD = 80;                                        // 72 taps padded to a multiple of 8
 
 // x0[b,n,t,:] = concat[pos, class, bins, drop(tanh(conv)), drop(beat)] + drop(tanh-style)  (model.py:56-82)
+// Training additionally stashes Ycol = tanh(conv) [rows,64] and the im2col view Xcol [rows,80]
+// (72 taps in conv-kernel order k*3+c, zero padded) so BPTT gets dWc from an MFMA TN GEMM.
 template <typename T>
-__global__ __launch_bounds__(256) void feature_fwd_kernel(FeatArgs a, T* __restrict__ X) {
+__global__ __launch_bounds__(256) void feature_fwd_kernel(FeatArgs a, T* __restrict__ X, T* __restrict__ Xcol,
+                                                          T* __restrict__ Ycol) {
   extern __shared__ float sm[];
   const int NQ = ((a.N + 3) / 4 + 3) / 4 * 4;   // notes per thread-group, multiple of 4
   const int XR = NQ * 4 + CONV_K + 3;           // padded note rows in LDS
@@ -177,9 +181,12 @@ __global__ __launch_bounds__(256) void feature_fwd_kernel(FeatArgs a, T* __restr
         if (n < a.N) {
           uint32_t r = (uint32_t)bt * a.N + n;
           int col = conv_col0 + o;
-          float v = dj_tanh(acc[dn]) * dj_keep(a.d_conv, dj_rowkey(a.d_conv, r), o);
+          const float y = dj_tanh(acc[dn]);
+          const int64_t row = dj_row_ta(b, t, n, a.T, a.N);
+          float v = y * dj_keep(a.d_conv, dj_rowkey(a.d_conv, r), o);
           v += a.sp0[(int64_t)bt * a.F + col] * dj_keep(a.d_style, dj_rowkey(a.d_style, r), col);
-          X[dj_row_ta(b, t, n, a.T, a.N) * a.FP + col] = dj_from_f32<T>(v);
+          X[row * a.FP + col] = dj_from_f32<T>(v);
+          if (Ycol) Ycol[row * CONV_O + o] = dj_from_f32<T>(y);
         }
       }
     }
@@ -204,51 +211,37 @@ __global__ __launch_bounds__(256) void feature_fwd_kernel(FeatArgs a, T* __restr
       if (col < a.F) v += a.sp0[(int64_t)bt * a.F + col] * dj_keep(a.d_style, dj_rowkey(a.d_style, r), col);
       X[dj_row_ta(b, t, n, a.T, a.N) * a.FP + col] = dj_from_f32<T>(v);
     }
+    if (Xcol) {
+      for (int i = tid; i < a.N * XCOL_LD; i += 256) {
+        const int n = i / XCOL_LD, q = i % XCOL_LD;
+        const float v = q < CONV_K * CONV_C ? xin[(n + q / CONV_C) * 3 + q % CONV_C] : 0.f;
+        Xcol[dj_row_ta(b, t, n, a.T, a.N) * XCOL_LD + q] = dj_from_f32<T>(v);
+      }
+    }
   }
 }
 
-// backward of the above: conv kernel/bias gradients and the style-projection gradient
+// backward of the above.  One workgroup per (b,t):
+//   dpre0[bt,d]  = (sum_n dX[b,n,t,d] * keep_style) * (1 - sp^2)          (style Dense gradient)
+//   Ycol[row,o] <- dX[row,14+o] * keep_conv * (1 - y^2)   in place        (conv pre-activation grad)
+//   dbc[o]     += sum of that; dWc comes from dj_gemm_tn(Xcol^T, Ycol) afterwards.
 template <typename T>
-__global__ __launch_bounds__(256) void feature_bwd_kernel(FeatArgs a, const T* __restrict__ dX,
-                                                          float* __restrict__ dWc, float* __restrict__ dbc,
-                                                          float* __restrict__ dpre0) {
-  extern __shared__ float sm[];
-  const int NQ = ((a.N + 3) / 4 + 3) / 4 * 4;
-  const int XR = NQ * 4 + CONV_K + 3;
-  float* xin = sm;                 // [XR][3]
-  float* red = sm + XR * 3;        // [2][FP] partial style sums, later [4][64] reduction scratch
-  const int tid = threadIdx.x, o = tid & 63, ng = tid >> 6;
-  float wreg[CONV_K * CONV_C], dwreg[CONV_K * CONV_C];
-#pragma unroll
-  for (int i = 0; i < CONV_K * CONV_C; ++i) {
-    wreg[i] = a.Wc[i * CONV_O + o];
-    dwreg[i] = 0.f;
-  }
-  const float bo = a.bc[o];
-  float dbo = 0.f;
+__global__ __launch_bounds__(256) void feature_bwd_kernel(FeatArgs a, const T* __restrict__ dX, T* __restrict__ Ycol,
+                                                          float* __restrict__ dbc, float* __restrict__ dpre0) {
+  __shared__ float red[2 * 128 + 4 * 64];
+  const int tid = threadIdx.x;
   const int conv_col0 = 2 + a.octave;
-
+  float bsum = 0.f;                                  // thread (o = tid&63, ng = tid>>6)
   for (int bt = blockIdx.x; bt < a.B * a.T; bt += gridDim.x) {
     const int b = bt / a.T, t = bt % a.T;
     __syncthreads();
-    for (int i = tid; i < XR * 3; i += 256) {
-      int n = i / 3 - CONV_L, c = i % 3;
-      float v = 0.f;
-      if (n >= 0 && n < a.N) {
-        uint32_t r = (uint32_t)bt * a.N + n;
-        v = a.notes[(int64_t)r * 3 + c] * dj_keep(a.d_notes, dj_rowkey(a.d_notes, r), c);
-      }
-      xin[i] = v;
-    }
-    __syncthreads();
-    // style gradient: dpre0[bt, d] = (sum_n dX[b,n,t,d] * keep) * (1 - sp^2); two n-halves
     {
-      int d = tid % 128, part = tid / 128;
-      float s = 0.f;
+      const int d = tid % 128, part = tid / 128;
       if (d < a.F) {
-        int nh = (a.N + 1) / 2;
+        float s = 0.f;
+        const int nh = (a.N + 1) / 2;
         for (int n = part * nh; n < (part + 1) * nh && n < a.N; ++n) {
-          uint32_t r = (uint32_t)bt * a.N + n;
+          const uint32_t r = (uint32_t)bt * a.N + n;
           s += dj_to_f32(dX[dj_row_ta(b, t, n, a.T, a.N) * a.FP + d]) * dj_keep(a.d_style, dj_rowkey(a.d_style, r), d);
         }
         red[part * 128 + d] = s;
@@ -256,68 +249,25 @@ __global__ __launch_bounds__(256) void feature_bwd_kernel(FeatArgs a, const T* _
     }
     __syncthreads();
     if (tid < a.F) {
-      float sp = a.sp0[(int64_t)bt * a.F + tid];
+      const float sp = a.sp0[(int64_t)bt * a.F + tid];
       dpre0[(int64_t)bt * a.F + tid] = (red[tid] + red[128 + tid]) * (1.f - sp * sp);
     }
-    // conv gradients
-    for (int nb = ng * NQ; nb < (ng + 1) * NQ && nb < a.N; nb += 4) {
-      float acc[4] = {bo, bo, bo, bo};
-#pragma unroll
-      for (int kk = 0; kk < CONV_K + 3; ++kk)
-#pragma unroll
-        for (int c = 0; c < CONV_C; ++c) {
-          float xv = xin[(nb + kk) * 3 + c];
-#pragma unroll
-          for (int dn = 0; dn < 4; ++dn) {
-            int k = kk - dn;
-            if (k >= 0 && k < CONV_K) acc[dn] += xv * wreg[k * CONV_C + c];
-          }
-        }
-      float g[4];
-#pragma unroll
-      for (int dn = 0; dn < 4; ++dn) {
-        int n = nb + dn;
-        g[dn] = 0.f;
-        if (n < a.N) {
-          uint32_t r = (uint32_t)bt * a.N + n;
-          float y = dj_tanh(acc[dn]);
-          float up = dj_to_f32(dX[dj_row_ta(b, t, n, a.T, a.N) * a.FP + conv_col0 + o]);
-          g[dn] = up * dj_keep(a.d_conv, dj_rowkey(a.d_conv, r), o) * (1.f - y * y);
-        }
-        dbo += g[dn];
-      }
-#pragma unroll
-      for (int kk = 0; kk < CONV_K + 3; ++kk)
-#pragma unroll
-        for (int c = 0; c < CONV_C; ++c) {
-          float xv = xin[(nb + kk) * 3 + c];
-#pragma unroll
-          for (int dn = 0; dn < 4; ++dn) {
-            int k = kk - dn;
-            if (k >= 0 && k < CONV_K) dwreg[k * CONV_C + c] += xv * g[dn];
-          }
-        }
+    const int o = tid & 63, ng = tid >> 6;
+    for (int n = ng; n < a.N; n += 4) {
+      const uint32_t r = (uint32_t)bt * a.N + n;
+      const int64_t row = dj_row_ta(b, t, n, a.T, a.N);
+      const float y = dj_to_f32(Ycol[row * CONV_O + o]);
+      const float g = dj_to_f32(dX[row * a.FP + conv_col0 + o]) * dj_keep(a.d_conv, dj_rowkey(a.d_conv, r), o) *
+                      (1.f - y * y);
+      Ycol[row * CONV_O + o] = dj_from_f32<T>(g);
+      bsum += g;
     }
   }
-  // reduce the 4 note-groups through LDS, then one atomic per (k,c,o) per workgroup
   __syncthreads();
-  float* r4 = sm;   // [4][64] reuse
-  for (int i = 0; i <= CONV_K * CONV_C; ++i) {
-    float v = (i < CONV_K * CONV_C) ? dwreg[0] : dbo;
-    // rotate registers so that dwreg[0] is always the next one (keeps indexing static)
-#pragma unroll
-    for (int q = 0; q + 1 < CONV_K * CONV_C; ++q) dwreg[q] = dwreg[q + 1];
-    r4[ng * 64 + o] = v;
-    __syncthreads();
-    if (ng == 0) {
-      float s = r4[o] + r4[64 + o] + r4[128 + o] + r4[192 + o];
-      if (i < CONV_K * CONV_C)
-        atomicAdd(dWc + i * CONV_O + o, s);
-      else
-        atomicAdd(dbc + o, s);
-    }
-    __syncthreads();
-  }
+  float* r4 = red + 256;
+  r4[(tid >> 6) * 64 + (tid & 63)] = bsum;
+  __syncthreads();
+  if (tid < 64) atomicAdd(dbc + tid, r4[tid] + r4[64 + tid] + r4[128 + tid] + r4[192 + tid]);
 }
 
 // ------------------------------------------------------------------ inter-layer glue
@@ -656,24 +606,25 @@ static size_t feat_smem(int N) {
   int XR = NQ * 4 + CONV_K + 3;
   return (size_t)(XR * 3 + 256) * sizeof(float);
 }
-int dj_launch_feature_fwd(int dtype, const void* fa, void* X, hipStream_t st) {
+int dj_launch_feature_fwd(int dtype, const void* fa, void* X, void* Xcol, void* Ycol, hipStream_t st) {
   const FeatArgs& a = *(const FeatArgs*)fa;
   if (a.FP - CONV_O > 64 || a.FP % 8) return 1021;
   int grid = a.B * a.T < 2048 ? a.B * a.T : 2048;
-  DJ_T_DISPATCH(hipLaunchKernelGGL(feature_fwd_kernel<float>, dim3(grid), dim3(256), feat_smem(a.N), st, a, (float*)X),
+  DJ_T_DISPATCH(hipLaunchKernelGGL(feature_fwd_kernel<float>, dim3(grid), dim3(256), feat_smem(a.N), st, a, (float*)X,
+                                   (float*)Xcol, (float*)Ycol),
                 hipLaunchKernelGGL(feature_fwd_kernel<bf16_t>, dim3(grid), dim3(256), feat_smem(a.N), st, a,
-                                   (bf16_t*)X))
+                                   (bf16_t*)X, (bf16_t*)Xcol, (bf16_t*)Ycol))
   return (int)hipGetLastError();
 }
-int dj_launch_feature_bwd(int dtype, const void* fa, const void* dX, float* dWc, float* dbc, float* dpre0,
+int dj_launch_feature_bwd(int dtype, const void* fa, const void* dX, void* Ycol, float* dbc, float* dpre0,
                           hipStream_t st) {
   const FeatArgs& a = *(const FeatArgs*)fa;
   if (a.F > 128) return 1022;
-  int grid = a.B * a.T < 512 ? a.B * a.T : 512;
-  DJ_T_DISPATCH(hipLaunchKernelGGL(feature_bwd_kernel<float>, dim3(grid), dim3(256), feat_smem(a.N), st, a,
-                                   (const float*)dX, dWc, dbc, dpre0),
-                hipLaunchKernelGGL(feature_bwd_kernel<bf16_t>, dim3(grid), dim3(256), feat_smem(a.N), st, a,
-                                   (const bf16_t*)dX, dWc, dbc, dpre0))
+  int grid = a.B * a.T < 2048 ? a.B * a.T : 2048;
+  DJ_T_DISPATCH(hipLaunchKernelGGL(feature_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, a, (const float*)dX,
+                                   (float*)Ycol, dbc, dpre0),
+                hipLaunchKernelGGL(feature_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a, (const bf16_t*)dX,
+                                   (bf16_t*)Ycol, dbc, dpre0))
   return (int)hipGetLastError();
 }
 int dj_launch_glue_fwd(int dtype, const void* ga, const void* Hin, void* X, hipStream_t st) {

@@ -70,8 +70,8 @@ int dj_launch_dense_small_bwd_x(const float* dC, int M, int N, const float* W, i
 int dj_launch_dense_small_bwd_w(const float* A, int M, int K, const float* dC, int N, float* dW, float* db,
                                 hipStream_t st);
 int dj_launch_bins(const float* notes, float* bins, int B, int T, int N, int octave, DjDrop dn, hipStream_t st);
-int dj_launch_feature_fwd(int dtype, const void* fa, void* X, hipStream_t st);
-int dj_launch_feature_bwd(int dtype, const void* fa, const void* dX, float* dWc, float* dbc, float* dpre0,
+int dj_launch_feature_fwd(int dtype, const void* fa, void* X, void* Xcol, void* Ycol, hipStream_t st);
+int dj_launch_feature_bwd(int dtype, const void* fa, const void* dX, void* Ycol, float* dbc, float* dpre0,
                           hipStream_t st);
 int dj_launch_glue_fwd(int dtype, const void* ga, const void* Hin, void* X, hipStream_t st);
 int dj_launch_glue_bwd(int dtype, const void* ga, const void* dX, void* dH, float* dpre, hipStream_t st);
