@@ -35,18 +35,23 @@ def category_flops(cfg, B, T, N):
     F = 1 + cfg.octave + 1 + cfg.octave_units + cfg.notes_per_bar
     t_in = [F] + [Ht] * (cfg.time_axis_layers - 1)
     n_in = [Ht + cfg.note_units] + [Hn] * (cfg.note_axis_layers - 1)
-    xw = sum(2 * rows * d * 4 * Ht for d in t_in) + sum(2 * rows * d * 4 * Hn for d in n_in)
+    xw_t, xw_n = sum(2 * rows * d * 4 * Ht for d in t_in), sum(2 * rows * d * 4 * Hn for d in n_in)
+    xw = xw_t + xw_n
     rec_t = cfg.time_axis_layers * 2 * rows * Ht * 4 * Ht
     rec_n = cfg.note_axis_layers * 2 * rows * Hn * 4 * Hn
+    # the forward recurrent kernel carries the input projection x*W of every layer with D <= 2H
+    # (dj_api.hip fuse_xw); the others keep a separate GEMM launch (category gemm_xw)
+    fx_t = sum(2 * rows * d * 4 * Ht for d in t_in if d <= 2 * Ht)
+    fx_n = sum(2 * rows * d * 4 * Hn for d in n_in if d <= 2 * Hn)
     return {
-        "gemm_xw": xw, "gemm_dx": xw, "gemm_dw": xw + rec_t + rec_n,
-        "lstm_fwd_time": rec_t, "lstm_bwd_time": rec_t, "lstm_fwd_note": rec_n, "lstm_bwd_note": rec_n,
+        "gemm_xw": xw - fx_t - fx_n, "gemm_dx": xw, "gemm_dw": xw + rec_t + rec_n, "lstm_fwd_time": rec_t + fx_t,
+        "lstm_bwd_time": rec_t, "lstm_fwd_note": rec_n + fx_n, "lstm_bwd_note": rec_n,
     }
 
 
 def launches_per_step(cfg):
     Lt, Ln = cfg.time_axis_layers, cfg.note_axis_layers
-    return {"gemm_xw": Lt + Ln, "gemm_dx": Lt + Ln, "gemm_dw": Lt + Ln, "lstm_fwd_time": Lt,
+    return {"gemm_xw": 1, "gemm_dx": Lt + Ln, "gemm_dw": Lt + Ln, "lstm_fwd_time": Lt,
             "lstm_bwd_time": Lt, "lstm_fwd_note": Ln, "lstm_bwd_note": Ln}
 
 
@@ -223,8 +228,8 @@ def main():
 
     if rank == 0:
         value = world * B * T * N * args.steps / elapsed
-        flops_step = 3 * (category_flops(cfg, B, T, N)["gemm_xw"] + category_flops(cfg, B, T, N)["lstm_fwd_time"]
-                          + category_flops(cfg, B, T, N)["lstm_fwd_note"])
+        cf = category_flops(cfg, B, T, N)
+        flops_step = 3 * (cf["gemm_xw"] + cf["lstm_fwd_time"] + cf["lstm_fwd_note"])
         out = {
             "metric": "note-steps/sec (train)", "value": round(value, 1), "unit": "note-steps/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

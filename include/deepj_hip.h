@@ -156,6 +156,14 @@ int32_t dj_lstm_pack(int32_t dtype, int32_t H, const float* U, void* upack_fwd, 
  * Row order: ((tile*steps + step)*32 + seq_in_tile). */
 int32_t dj_lstm_fwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, void* Z, const void* upack_fwd,
                     void* Hout, void* Cout, int32_t recurrent_sigmoid, void* stream);
+/* The same sweep with the input projection fused in (what the training / predict paths use):
+ * z_t = x_t W + h_{t-1} U + b with X row-major [rows, DP] (D valid columns), W packed by
+ * dj_lstm_pack_w (4H * roundup(D, 2*kchunk) operand elements; kchunk = 16 bf16 / 8 fp32),
+ * bias[4H] fp32.  Zstash (fragment-tiled, may be NULL) receives the pre-activations. */
+int32_t dj_lstm_pack_w(int32_t dtype, int32_t H, const float* W, int32_t D, void* wpack, void* stream);
+int32_t dj_lstm_fwd_fused(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* X, int32_t DP,
+                          int32_t D, const void* wpack, const float* bias, void* Zstash, const void* upack_fwd,
+                          void* Hout, void* Cout, int32_t recurrent_sigmoid, void* stream);
 /* BPTT sweep: Z / C = the forward's fragment-tiled pre-activations / cell states; dH = dL/dh
  * per step (row-major [rows, H]); dZ (row-major [rows, 4H]) receives dL/dz;
  * dbias[4H] += column sums of dz. */

@@ -241,6 +241,166 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_kernel(T* __restrict__ Z, cons
   }
 }
 
+
+// ---------------------------------------------------------------- forward with fused input projection
+// z_t = x_t W + h_{t-1} U + b computed entirely inside the persistent kernel: the x*W GEMM launch and
+// the 2 x 4H-wide Zx round trip through HBM disappear; the price is a second fragment stream (W)
+// from L2 per step.  X tiles (32 x DP, row-major) are prefetched one step ahead into LDS.
+// Wpack[((w*4+g)*NKX + kc)*64 + lane][e] = W[kc*KC + EPL*h + e][g*H + w*32 + l31]   (zero for k >= D)
+template <typename T, int H>
+__global__ void pack_w_fwd_kernel(const float* __restrict__ W, int D, int NKX, T* __restrict__ out) {
+  using R = RecCfg<T, H>;
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 4 * H * NKX * R::KC) return;
+  int e = idx % R::EPL, lane = (idx / R::EPL) % 64, rest = idx / (R::EPL * 64);
+  int kc = rest % NKX;
+  rest /= NKX;
+  int g = rest % 4, w = rest / 4;
+  int k = kc * R::KC + R::EPL * (lane >> 5) + e;
+  int col = g * H + w * R::UW + (lane & 31);
+  out[idx] = dj_from_f32<T>(k < D ? W[(int64_t)k * 4 * H + col] : 0.f);
+}
+
+constexpr int FUSED_DPMAX = 288;   // widest layer input supported by the register prefetch (259 -> 264 here)
+
+template <typename T, int H, bool SIGM>
+__global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restrict__ X, int DP, int NKX,
+                                                               const T* __restrict__ Wpack,
+                                                               const float* __restrict__ bias, T* __restrict__ Zst,
+                                                               const T* __restrict__ Upack, T* __restrict__ Hout,
+                                                               T* __restrict__ Cout, int steps) {
+  using R = RecCfg<T, H>;
+  using Frag = typename DjFrag<T>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int LDX = NKX * R::KC + R::EPL;
+  T* hs0 = (T*)smem_raw;                       // [2][32][LDH]
+  T* xs0 = hs0 + 2 * 32 * R::LDH;              // [2][32][LDX]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  const int64_t tile = blockIdx.x;
+
+  float c[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r] = 0.f;
+  float bv[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bv[g] = bias[g * H + w * R::UW + l31];
+  const Frag* up = (const Frag*)Upack + (int64_t)w * 4 * R::NKC * 64 + lane;
+  const Frag* wp = (const Frag*)Wpack + (int64_t)w * 4 * NKX * 64 + lane;
+  auto zaddr = [&](int64_t rb, int g) { return Zst + ((rb * R::NCB + (g * H + w * R::UW) / 32) * 64 + lane) * 16; };
+  auto caddr = [&](int64_t rb) { return Cout + ((rb * R::NCBH + (w * R::UW) / 32) * 64 + lane) * 16; };
+
+  // X tile staging: NVX 16-byte vectors per tile, up to NVMAX per thread
+  constexpr int NVMAX = (32 * FUSED_DPMAX / R::EPL + R::NT - 1) / R::NT;
+  const int vpr = DP / R::EPL, nvx = 32 * vpr;
+  uint4 xr[NVMAX];
+  auto x_load = [&](int64_t rb) {
+#pragma unroll
+    for (int i = 0; i < NVMAX; ++i) {
+      const int v = tid + i * R::NT;
+      if (v < nvx) xr[i] = *(const uint4*)(X + (rb * 32 + v / vpr) * DP + (v % vpr) * R::EPL);
+    }
+  };
+  auto x_store = [&](T* xs) {
+#pragma unroll
+    for (int i = 0; i < NVMAX; ++i) {
+      const int v = tid + i * R::NT;
+      if (v < nvx) *(uint4*)(xs + (v / vpr) * LDX + (v % vpr) * R::EPL) = xr[i];
+    }
+  };
+  // zero both X buffers once (k-tail columns DP..NKX*KC stay zero), then stage X[0]
+  for (int i = tid; i < 2 * 32 * LDX * (int)sizeof(T) / 16; i += R::NT) ((uint4*)xs0)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  x_load(tile * steps);
+  x_store(xs0);
+  lds_barrier();
+
+  int cur = 0;
+  for (int t = 0; t < steps; ++t) {
+    const int64_t rb = tile * steps + t;
+    const T* xs = xs0 + (t & 1) * 32 * LDX;
+    f32x16 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][r] = bv[g];
+    {   // x_t * W
+      const T* xp = xs + l31 * LDX;
+      Frag bq[2][4];
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[p][q] = wp[(q * NKX + p) * 64];
+#pragma unroll 1
+      for (int kc0 = 0; kc0 < NKX; kc0 += 2) {      // NKX is even (launcher pads)
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+          const int kc = kc0 + uu;
+          Frag a = dj_lds_frag(xp + kc * R::KC, h);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dj_mfma(acc[q], a, bq[uu][q]);
+          const int kn = (kc + 2 < NKX) ? kc + 2 : NKX - 1;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bq[uu][q] = wp[(q * NKX + kn) * 64];
+        }
+      }
+    }
+    if (t > 0) {   // h_{t-1} * U
+      const T* hp = hs0 + cur * 32 * R::LDH + l31 * R::LDH;
+      Frag bq[R::PD][4];
+#pragma unroll
+      for (int p = 0; p < R::PD; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[p][q] = up[(q * R::NKC + p) * 64];
+#pragma unroll 1
+      for (int kc0 = 0; kc0 < R::NKC; kc0 += R::UNR) {
+#pragma unroll
+        for (int uu = 0; uu < R::UNR; ++uu) {
+          const int kc = kc0 + uu;
+          Frag a = dj_lds_frag(hp + kc * R::KC, h);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dj_mfma(acc[q], a, bq[uu % R::PD][q]);
+          const int kn = (kc + R::PD < R::NKC) ? kc + R::PD : R::NKC - 1;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bq[uu % R::PD][q] = up[(q * R::NKC + kn) * 64];
+        }
+      }
+    }
+    // next X tile: issued after the weight streams of this step (in-order vmcnt), lands under the gate math
+    if (t + 1 < steps) x_load(rb + 1);
+    T* hn = hs0 + (cur ^ 1) * 32 * R::LDH;
+    const int u = w * R::UW + l31;
+    float cv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float zi = acc[0][r], zf = acc[1][r], zg = acc[2][r], zo = acc[3][r];
+      const float ig = dj_ract<SIGM>(zi), fg = dj_ract<SIGM>(zf), gg = dj_tanh(zg), og = dj_ract<SIGM>(zo);
+      const float cn = fg * c[r] + ig * gg;
+      c[r] = cn;
+      cv[r] = cn;
+      hn[dj_crow(r, lane) * R::LDH + u] = dj_from_f32<T>(og * dj_tanh(cn));
+    }
+    if (Cout) store_frag(caddr(rb), cv);
+    if (Zst) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float zv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zv[r] = acc[g][r];
+        store_frag(zaddr(rb, g), zv);
+      }
+    }
+    if (t + 1 < steps) x_store(xs0 + ((t + 1) & 1) * 32 * LDX);
+    lds_barrier();
+    constexpr int VPR = H / R::EPL;
+#pragma unroll
+    for (int v = tid; v < 32 * VPR; v += R::NT) {
+      int row = v / VPR, cvv = (v % VPR) * R::EPL;
+      *(uint4*)(Hout + (rb * 32 + row) * H + cvv) = *(const uint4*)(hn + row * R::LDH + cvv);
+    }
+    cur ^= 1;
+  }
+}
+
 // ---------------------------------------------------------------- backward (BPTT)
 // Z: fragment-tiled pre-activations (read only); dZ: row-major [M,4H] output.
 template <typename T, int H, bool SIGM>
@@ -438,6 +598,38 @@ int launch_bwd(int ntiles, int steps, const void* Z, const void* UTpack, const v
   return (int)hipGetLastError();
 }
 
+
+template <typename T, int H>
+int launch_pack_w(const float* W, int D, int NKX, void* out, hipStream_t st) {
+  using R = RecCfg<T, H>;
+  int n = 4 * H * NKX * R::KC;
+  hipLaunchKernelGGL((pack_w_fwd_kernel<T, H>), dim3((n + 255) / 256), dim3(256), 0, st, W, D, NKX, (T*)out);
+  return (int)hipGetLastError();
+}
+template <typename T, int H, bool SIGM>
+int launch_fwd_fused_s(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
+                       void* Zst, const void* Upack, void* Hout, void* Cout, hipStream_t st) {
+  using R = RecCfg<T, H>;
+  const size_t smem = ((size_t)2 * 32 * R::LDH + (size_t)2 * 32 * (NKX * R::KC + R::EPL)) * sizeof(T);
+  if (smem > 160 * 1024 || DP > FUSED_DPMAX || DP % R::EPL || NKX % 2 || NKX * R::KC < DP) return 1011;
+  static size_t attr = 0;
+  if (smem > attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_fused_kernel<T, H, SIGM>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr = 160 * 1024;
+  }
+  hipLaunchKernelGGL((lstm_fwd_fused_kernel<T, H, SIGM>), dim3(ntiles), dim3(R::NT), smem, st, (const T*)X, DP, NKX,
+                     (const T*)Wpack, bias, (T*)Zst, (const T*)Upack, (T*)Hout, (T*)Cout, steps);
+  return (int)hipGetLastError();
+}
+template <typename T, int H>
+int launch_fwd_fused(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
+                     void* Zst, const void* Upack, void* Hout, void* Cout, int sigm, hipStream_t st) {
+  return sigm ? launch_fwd_fused_s<T, H, true>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, st)
+              : launch_fwd_fused_s<T, H, false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, st);
+}
+
 }  // namespace
 
 #define DJ_DISPATCH_TH(FN, ...)                                     \
@@ -459,4 +651,20 @@ int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, c
                        const void* dH, void* dZ, float* dbias, int sigm, hipStream_t st) {
   if (ntiles <= 0 || steps <= 0) return 0;
   DJ_DISPATCH_TH(launch_bwd, ntiles, steps, Z, UTpack, C, dH, dZ, dbias, sigm, st)
+}
+
+// k-chunks of the fused input projection for a layer input of width D: ceil(D / KC) rounded up to even
+int dj_lstm_fused_nkx(int dtype, int D) {
+  const int kc = dtype == DJ_F32 ? 8 : 16;
+  int n = (D + kc - 1) / kc;
+  return (n + 1) / 2 * 2;
+}
+int dj_launch_lstm_pack_w(int dtype, int H, const float* W, int D, int NKX, void* out, hipStream_t st) {
+  DJ_DISPATCH_TH(launch_pack_w, W, D, NKX, out, st)
+}
+int dj_launch_lstm_fwd_fused(int dtype, int H, int ntiles, int steps, const void* X, int DP, int NKX,
+                             const void* Wpack, const float* bias, void* Zst, const void* Upack, void* Hout,
+                             void* Cout, int sigm, hipStream_t st) {
+  if (ntiles <= 0 || steps <= 0) return 0;
+  DJ_DISPATCH_TH(launch_fwd_fused, ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, sigm, st)
 }

@@ -247,3 +247,42 @@ def test_nadam_matches_oracle(gpu_device):
         tp.grad = torch.from_numpy((rs.randn(n) * 0.1).astype(np.float32))
         topt.step()
     np.testing.assert_allclose(tp.detach().numpy(), pref, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("H,S,Ls,D", [(256, 64, 5, 94), (128, 40, 6, 259), (256, 32, 3, 256), (128, 96, 4, 128)])
+def test_lstm_fwd_fused_input_projection(gpu_device, dtype, H, S, Ls, D):
+    """z = x W + h U + b inside the recurrent kernel (dj_lstm_fwd_fused) vs the restated cell."""
+    L, lib = _lib()
+    DP = (D + 7) // 8 * 8
+    x, W, U, b = _lstm_setup(S, Ls, D, H, H + D)
+    rnd = (lambda t: t.to(torch.bfloat16).float()) if dtype == "bf16" else (lambda t: t)
+    xr, Wr, Ur = rnd(x), rnd(W), rnd(U)
+    h = torch.zeros(S, H); c = torch.zeros(S, H)
+    hs, cs, zs = [], [], []
+    for t in range(Ls):
+        z = xr[:, t] @ Wr + b + h @ Ur
+        i, f, gg, o = O.hard_sigmoid(z[:, :H]), O.hard_sigmoid(z[:, H:2 * H]), torch.tanh(z[:, 2 * H:3 * H]), \
+            O.hard_sigmoid(z[:, 3 * H:])
+        c = f * c + i * gg
+        h = o * torch.tanh(c)
+        hs.append(h); cs.append(c); zs.append(z)
+    Href, Cref, Zref = torch.stack(hs, 1), torch.stack(cs, 1), torch.stack(zs, 1)
+    xp = torch.zeros(S, Ls, DP); xp[:, :, :D] = x
+    xrows, tiles = to_rows(xp)
+    R = xrows.shape[0]
+    Xd = _op(xrows, dtype).to(gpu_device)
+    esz = 2 if dtype == "bf16" else 4
+    wpack = torch.zeros(4 * H * (DP + 32) * esz, dtype=torch.uint8, device=gpu_device)
+    upf = torch.empty(H * 4 * H * esz, dtype=torch.uint8, device=gpu_device)
+    L.check(lib.dj_lstm_pack_w(DT[dtype], H, L.ptr(W.contiguous().to(gpu_device)), D, L.ptr(wpack), _st()), "packw")
+    L.check(lib.dj_lstm_pack(DT[dtype], H, L.ptr(U.to(gpu_device)), L.ptr(upf), None, _st()), "pack")
+    Zd = torch.zeros(R * 4 * H, dtype=Xd.dtype, device=gpu_device)
+    Hd = torch.zeros(R, H, dtype=Xd.dtype, device=gpu_device)
+    Cd = torch.zeros(R * H, dtype=Xd.dtype, device=gpu_device)
+    L.check(lib.dj_lstm_fwd_fused(DT[dtype], H, tiles, Ls, L.ptr(Xd), DP, D, L.ptr(wpack), L.ptr(b.to(gpu_device)),
+                                  L.ptr(Zd), L.ptr(upf), L.ptr(Hd), L.ptr(Cd), 0, _st()), "fwd_fused")
+    rt, at = _tol(dtype)
+    torch.testing.assert_close(from_rows(Hd.float().cpu(), S, Ls), Href, rtol=rt, atol=at * 5)
+    torch.testing.assert_close(from_rows(from_frag(Cd.float().cpu(), R, H), S, Ls), Cref, rtol=rt, atol=at * 5)
+    torch.testing.assert_close(from_rows(from_frag(Zd.float().cpu(), R, 4 * H), S, Ls), Zref, rtol=rt, atol=at * 10)
