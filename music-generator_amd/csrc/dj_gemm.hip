@@ -780,18 +780,11 @@ int dj_launch_gemm_nt(int dtype, int M, int N, int K, const void* A, int lda, co
                          xcd_map);
     return (int)hipGetLastError();
   }
+  // fp32 (parity mode): register-staged 128 x 128 kernel on v_mfma_f32_32x32x2_f32
   int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
   dim3 grid((unsigned)(ntn * (int64_t)ntm)), block(256);
-  if (dtype == DJ_F32) {
-    hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, block, 0, st, M, N, K, (const float*)A, lda,
-                       (const float*)Bt, ldb, (float*)C, ldc, bias, ntn, c_frag);
-  } else if (c_is_f32) {
-    hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, float>), grid, block, 0, st, M, N, K, (const bf16_t*)A, lda,
-                       (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn, c_frag);
-  } else {
-    hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, block, 0, st, M, N, K, (const bf16_t*)A, lda,
-                       (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn, c_frag);
-  }
+  hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, block, 0, st, M, N, K, (const float*)A, lda,
+                     (const float*)Bt, ldb, (float*)C, ldc, bias, ntn, c_frag);
   return (int)hipGetLastError();
 }
 

@@ -41,8 +41,11 @@ template <typename T, int H> struct RecCfg {
   static constexpr int NCB = 4 * H / 32;  // 32-col blocks of Z
   static constexpr int NCBH = H / 32;     // 32-col blocks of C
   static constexpr int VPT = 16 / EPL;    // 16-byte vectors per 16-register fragment (bf16: 2, f32: 4)
-  static constexpr int PD = 2;            // U prefetch depth in k-chunks
+  static constexpr int PD = sizeof(T) == 2 ? 4 : 2;   // U prefetch depth in k-chunks
   static constexpr int UNR = 4;           // k-chunks per unrolled body (multiple of PD)
+  // BPTT product: one MFMA per k-chunk and wave, so the ring must be deeper to cover L2 latency
+  // (measured: PD 2 left the 64-iteration loop latency-bound at 9.3 us/step)
+  static constexpr int PDB = sizeof(T) == 2 ? 8 : 4, UNRB = 8;
   static constexpr bool HOIST = sizeof(T) == 2;   // prefetch Z fragments a step ahead (register budget)
 };
 
@@ -523,22 +526,22 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
       const T* ap = dzs + l31 * R::LDZ;
-      Frag bq[R::PD][R::NJ];
+      Frag bq[R::PDB][R::NJ];
 #pragma unroll
-      for (int p = 0; p < R::PD; ++p)
+      for (int p = 0; p < R::PDB; ++p)
 #pragma unroll
         for (int j = 0; j < R::NJ; ++j) bq[p][j] = up[(j * R::NKCB + p) * 64];
 #pragma unroll 1
-      for (int kc0 = 0; kc0 < R::NKCB; kc0 += R::UNR) {
+      for (int kc0 = 0; kc0 < R::NKCB; kc0 += R::UNRB) {
 #pragma unroll
-        for (int u = 0; u < R::UNR; ++u) {
+        for (int u = 0; u < R::UNRB; ++u) {
           const int kc = kc0 + u;
           Frag a = dj_lds_frag(ap + kc * R::KC, h);
 #pragma unroll
-          for (int j = 0; j < R::NJ; ++j) dj_mfma(acc[j], a, bq[u % R::PD][j]);
-          const int kn = (kc + R::PD < R::NKCB) ? kc + R::PD : R::NKCB - 1;
+          for (int j = 0; j < R::NJ; ++j) dj_mfma(acc[j], a, bq[u % R::PDB][j]);
+          const int kn = (kc + R::PDB < R::NKCB) ? kc + R::PDB : R::NKCB - 1;
 #pragma unroll
-          for (int j = 0; j < R::NJ; ++j) bq[u % R::PD][j] = up[(j * R::NKCB + kn) * 64];
+          for (int j = 0; j < R::NJ; ++j) bq[u % R::PDB][j] = up[(j * R::NKCB + kn) * 64];
         }
       }
     }
