@@ -126,7 +126,7 @@ int make_plan(const dj_config* cfg, Plan& p) {
   for (int l = 0; l < p.Lt; ++l) {
     const LstmP& L = p.tl[l];
     p.w_sp_t[l] = wtake(p.BT * L.D * 4); p.w_dpre_t[l] = wtake(p.BT * L.D * 4);
-    p.w_Wt_t[l] = wtake((int64_t)4 * L.H * (L.DP + 32) * p.esz); p.w_Wc_t[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
+    p.w_Wt_t[l] = wtake((int64_t)4 * L.H * (L.DP + 64) * p.esz); p.w_Wc_t[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
     p.w_Uf_t[l] = wtake((int64_t)L.H * 4 * L.H * p.esz); p.w_Ub_t[l] = wtake((int64_t)L.H * 4 * L.H * p.esz);
     p.w_X_t[l] = wtake(p.Mt * L.DP * p.esz); p.w_Z_t[l] = wtake(p.Mt * 4 * L.H * p.esz);
     p.w_H_t[l] = wtake(p.Mt * L.H * p.esz); p.w_C_t[l] = wtake(p.Mt * L.H * p.esz);
@@ -135,7 +135,7 @@ int make_plan(const dj_config* cfg, Plan& p) {
   for (int l = 0; l < p.Ln; ++l) {
     const LstmP& L = p.nl[l];
     p.w_sp_n[l] = wtake(p.BT * L.D * 4); p.w_dpre_n[l] = wtake(p.BT * L.D * 4);
-    p.w_Wt_n[l] = wtake((int64_t)4 * L.H * (L.DP + 32) * p.esz); p.w_Wc_n[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
+    p.w_Wt_n[l] = wtake((int64_t)4 * L.H * (L.DP + 64) * p.esz); p.w_Wc_n[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
     p.w_Uf_n[l] = wtake((int64_t)L.H * 4 * L.H * p.esz); p.w_Ub_n[l] = wtake((int64_t)L.H * 4 * L.H * p.esz);
     p.w_X_n[l] = wtake(p.Mn * L.DP * p.esz); p.w_Z_n[l] = wtake(p.Mn * 4 * L.H * p.esz);
     p.w_H_n[l] = wtake(p.Mn * L.H * p.esz); p.w_C_n[l] = wtake(p.Mn * L.H * p.esz);

@@ -326,45 +326,29 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[g][r] = bv[g];
-    {   // x_t * W
+    {   // one continuous fragment stream: NKX chunks of x_t * W, then (t > 0) NKC chunks of h_{t-1} * U
       const T* xp = xs + l31 * LDX;
-      Frag bq[2][4];
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bq[p][q] = wp[(q * NKX + p) * 64];
-#pragma unroll 1
-      for (int kc0 = 0; kc0 < NKX; kc0 += 2) {      // NKX is even (launcher pads)
-#pragma unroll
-        for (int uu = 0; uu < 2; ++uu) {
-          const int kc = kc0 + uu;
-          Frag a = dj_lds_frag(xp + kc * R::KC, h);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) dj_mfma(acc[q], a, bq[uu][q]);
-          const int kn = (kc + 2 < NKX) ? kc + 2 : NKX - 1;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) bq[uu][q] = wp[(q * NKX + kn) * 64];
-        }
-      }
-    }
-    if (t > 0) {   // h_{t-1} * U
       const T* hp = hs0 + cur * 32 * R::LDH + l31 * R::LDH;
+      const int ntot = NKX + (t > 0 ? R::NKC : 0);          // NKX and NKC are multiples of PD
+      auto bfrag = [&](int kc, int q) {
+        return kc < NKX ? wp[(q * NKX + kc) * 64] : up[(q * R::NKC + (kc - NKX)) * 64];
+      };
       Frag bq[R::PD][4];
 #pragma unroll
       for (int p = 0; p < R::PD; ++p)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bq[p][q] = up[(q * R::NKC + p) * 64];
+        for (int q = 0; q < 4; ++q) bq[p][q] = bfrag(p, q);
 #pragma unroll 1
-      for (int kc0 = 0; kc0 < R::NKC; kc0 += R::UNR) {
+      for (int kc0 = 0; kc0 < ntot; kc0 += R::PD) {
 #pragma unroll
-        for (int uu = 0; uu < R::UNR; ++uu) {
+        for (int uu = 0; uu < R::PD; ++uu) {
           const int kc = kc0 + uu;
-          Frag a = dj_lds_frag(hp + kc * R::KC, h);
+          Frag a = kc < NKX ? dj_lds_frag(xp + kc * R::KC, h) : dj_lds_frag(hp + (kc - NKX) * R::KC, h);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) dj_mfma(acc[q], a, bq[uu % R::PD][q]);
-          const int kn = (kc + R::PD < R::NKC) ? kc + R::PD : R::NKC - 1;
+          for (int q = 0; q < 4; ++q) dj_mfma(acc[q], a, bq[uu][q]);
+          const int kn = (kc + R::PD < ntot) ? kc + R::PD : ntot - 1;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) bq[uu % R::PD][q] = up[(q * R::NKC + kn) * 64];
+          for (int q = 0; q < 4; ++q) bq[uu][q] = bfrag(kn, q);
         }
       }
     }
@@ -614,7 +598,7 @@ int launch_fwd_fused_s(int ntiles, int steps, const void* X, int DP, int NKX, co
                        void* Zst, const void* Upack, void* Hout, void* Cout, hipStream_t st) {
   using R = RecCfg<T, H>;
   const size_t smem = ((size_t)2 * 32 * R::LDH + (size_t)2 * 32 * (NKX * R::KC + R::EPL)) * sizeof(T);
-  if (smem > 160 * 1024 || DP > FUSED_DPMAX || DP % R::EPL || NKX % 2 || NKX * R::KC < DP) return 1011;
+  if (smem > 160 * 1024 || DP > FUSED_DPMAX || DP % R::EPL || NKX % R::PD || NKX * R::KC < DP) return 1011;
   static size_t attr = 0;
   if (smem > attr) {
     hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_fused_kernel<T, H, SIGM>,
@@ -656,11 +640,11 @@ int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, c
   DJ_DISPATCH_TH(launch_bwd, ntiles, steps, Z, UTpack, C, dH, dZ, dbias, sigm, st)
 }
 
-// k-chunks of the fused input projection for a layer input of width D: ceil(D / KC) rounded up to even
+// k-chunks of the fused input projection for a layer input of width D: ceil(D / KC) rounded up to the ring depth
 int dj_lstm_fused_nkx(int dtype, int D) {
-  const int kc = dtype == DJ_F32 ? 8 : 16;
+  const int kc = dtype == DJ_F32 ? 8 : 16, pd = dtype == DJ_F32 ? 2 : 4;   // RecCfg::KC / RecCfg::PD
   int n = (D + kc - 1) / kc;
-  return (n + 1) / 2 * 2;
+  return (n + pd - 1) / pd * pd;
 }
 int dj_launch_lstm_pack_w(int dtype, int H, const float* W, int D, int NKX, void* out, hipStream_t st) {
   DJ_DISPATCH_TH(launch_pack_w, W, D, NKX, out, st)
