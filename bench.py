@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0                              # HBM3E, same guide
 
 
 def category_flops(cfg, B, T, N):
@@ -47,6 +48,31 @@ def category_flops(cfg, B, T, N):
         "gemm_xw": xw - fx_t - fx_n, "gemm_dx": xw, "gemm_dw": xw + rec_t + rec_n, "lstm_fwd_time": rec_t + fx_t,
         "lstm_bwd_time": rec_t, "lstm_fwd_note": rec_n + fx_n, "lstm_bwd_note": rec_n,
     }
+
+
+def category_bytes(cfg, B, T, N, esize):
+    """ALGORITHMIC HBM bytes per training step of the same categories: activations only (weights
+    stay in L2), esize bytes per element.  Per row of an LSTM layer with input width D and H units:
+    forward reads x (D) and writes the BPTT stash z (4H), h (H), c (H); the unfused variant reads
+    and rewrites z instead of reading x; backward reads z (4H), c (H), dh (H) and writes dz (4H);
+    dW/dU read dz (4H), x (D), h (H); dX reads dz (4H) and writes dx (D)."""
+    Ht, Hn = cfg.time_axis_units, cfg.note_axis_units
+    rows = B * T * N
+    F = 1 + cfg.octave + 1 + cfg.octave_units + cfg.notes_per_bar
+    t_in = [F] + [Ht] * (cfg.time_axis_layers - 1)
+    n_in = [Ht + cfg.note_units] + [Hn] * (cfg.note_axis_layers - 1)
+    out = {k: 0 for k in ("gemm_xw", "gemm_dx", "gemm_dw", "lstm_fwd_time", "lstm_bwd_time", "lstm_fwd_note",
+                          "lstm_bwd_note")}
+    for axis, H, dims in (("time", Ht, t_in), ("note", Hn, n_in)):
+        for d in dims:
+            fused = d <= 2 * H
+            out["lstm_fwd_" + axis] += rows * esize * ((d + 6 * H) if fused else 10 * H)
+            if not fused:
+                out["gemm_xw"] += rows * esize * (d + 4 * H)
+            out["lstm_bwd_" + axis] += rows * esize * 10 * H
+            out["gemm_dw"] += rows * esize * (5 * H + d)
+            out["gemm_dx"] += rows * esize * (4 * H + d)
+    return out
 
 
 def launches_per_step(cfg):
@@ -200,7 +226,7 @@ def main():
         elapsed = float(t.cpu()[0])
 
     kernels = {}
-    roof = None
+    roof = roof_all = None
     if not args.no_profile:
         ncat = lib.dj_profile_category_count()
         for c in range(ncat):
@@ -212,7 +238,10 @@ def main():
         lps = launches_per_step(cfg)
         dom = max(fl, key=lambda k: kernels.get(k, 0.0))
         ms = kernels[dom]
-        achieved = fl[dom] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        by = category_bytes(cfg, B, T, N, 2 if args.dtype == "bf16" else 4)
+        sec = ms * 1e-3
+        tflops = fl[dom] / sec / 1e12 if ms > 0 else 0.0
+        gbs = by[dom] / sec / 1e9 if ms > 0 else 0.0
         traffic, tsrc = None, None
         try:                                            # HBM bytes per launch of that kernel from the committed PMC passes
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -220,11 +249,23 @@ def main():
                 traffic, tsrc = pm[dom], "profiles/pmc_traffic.json: " + pm["source"]
         except Exception:
             pass
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype],
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
-                "traffic_source": tsrc,
-                "launches_per_step": lps[dom], "avg_launch_ms": round(ms / lps[dom], 4),
-                "flops_per_launch": fl[dom] / lps[dom]}
+        # the roof that binds is the one with the larger lower-bound time for this kernel
+        t_mfma, t_hbm = fl[dom] / (PEAK_TFLOPS[args.dtype] * 1e12), by[dom] / (PEAK_HBM_GBS * 1e9)
+        if t_hbm >= t_mfma:
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 4)}
+        else:
+            roof = {"bound": "mfma", "kernel": dom, "achieved": round(tflops, 2), "peak": PEAK_TFLOPS[args.dtype],
+                    "unit": "TFLOP/s", "frac": round(tflops / PEAK_TFLOPS[args.dtype], 4)}
+        roof.update({"traffic": traffic, "traffic_source": tsrc, "launches_per_step": lps[dom],
+                     "avg_launch_ms": round(ms / lps[dom], 4), "bytes_per_launch": by[dom] / lps[dom],
+                     "flops_per_launch": fl[dom] / lps[dom],
+                     "mfma_tflops": round(tflops, 2), "mfma_frac": round(tflops / PEAK_TFLOPS[args.dtype], 4),
+                     "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)})
+        roof_all = {k: {"ms": kernels.get(k, 0.0),
+                        "tflops": round(fl[k] / (kernels[k] * 1e-3) / 1e12, 1) if kernels.get(k) else None,
+                        "gbs": round(by[k] / (kernels[k] * 1e-3) / 1e9, 1) if kernels.get(k) else None}
+                    for k in fl}
 
     if rank == 0:
         value = world * B * T * N * args.steps / elapsed
@@ -241,7 +282,7 @@ def main():
                        "global_batch": B * world, "seq_len": T, "num_notes": N, "parallelism": f"dp{world}"},
             "model_tflops_per_s": round(flops_step * world * args.steps / elapsed / 1e12, 2),
             "final_loss": round(final_loss, 5),
-            "roofline": roof, "kernel_ms_per_step": kernels,
+            "roofline": roof, "kernel_ms_per_step": kernels, "kernel_rates": roof_all,
         }
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, T, N, args.cpu_sample, pin, pdr)

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libdeepj_hip.so")
+LIB_PATH = os.environ.get("DEEPJ_LIB") or os.path.join(HERE, "lib", "libdeepj_hip.so")   # DEEPJ_LIB: A/B kernel builds
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
 

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdeepj_hip.so")
-SOURCES = ["dj_gemm.hip", "dj_lstm.hip", "dj_elem.hip", "dj_gen.hip", "dj_api.hip"]
+SOURCES = ["dj_gemm.hip", "dj_lstm.hip", "dj_step.hip", "dj_elem.hip", "dj_gen.hip", "dj_api.hip"]
 
 
 def _hipcc():

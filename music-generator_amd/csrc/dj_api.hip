@@ -67,11 +67,15 @@ struct Plan {
   int64_t w_Wt_n[MAXL], w_Wc_n[MAXL], w_Uf_n[MAXL], w_Ub_n[MAXL];
   int64_t w_X_t[MAXL], w_Z_t[MAXL], w_H_t[MAXL], w_C_t[MAXL];
   int64_t w_X_n[MAXL], w_Z_n[MAXL], w_H_n[MAXL], w_C_n[MAXL];
-  int64_t w_dH_t, w_dX_t, w_dH_n, w_dX_n, w_featin, w_dZ_t, w_dZ_n, w_zero, w_Xcol, w_Ycol;
+  int64_t w_dH_t, w_dX_t, w_dH_n, w_dX_n, w_featin, w_dZ_t, w_dZ_n, w_zero, w_Xcol, w_Ycol, w_step;
   int64_t ws_bytes;
 };
 
 inline int64_t up8(int64_t v) { return (v + 7) / 8 * 8; }
+
+// The persistent one-CU-per-sequence-tile recurrent kernels (dj_lstm.hip) exist for the reference's
+// layer widths; any other width runs the per-step GEMM + gate path (dj_step.hip).
+inline bool rec_persistent(int H) { return H == 128 || H == 256; }
 
 int make_plan(const dj_config* cfg, Plan& p) {
   if (!cfg) return 1100;
@@ -83,7 +87,7 @@ int make_plan(const dj_config* cfg, Plan& p) {
   if (p.B < 1 || p.T < 1 || p.N < 1 || p.S < 1 || p.NB < 1) return 1101;
   if (cfg->octave_units != 64 || cfg->note_units != 3 || cfg->octave < 1) return 1102;
   if (p.SU < 1 || p.SU > 64) return 1103;
-  if ((p.Ht != 128 && p.Ht != 256) || (p.Hn != 128 && p.Hn != 256)) return 1104;
+  if (p.Ht < 32 || p.Ht > 2048 || (p.Ht % 32) || p.Hn < 32 || p.Hn > 2048 || (p.Hn % 32)) return 1104;
   if (p.Lt < 1 || p.Lt > MAXL || p.Ln < 1 || p.Ln > MAXL) return 1105;
   if (cfg->dtype != DJ_F32 && cfg->dtype != DJ_BF16) return 1106;
   if (cfg->input_dropout < 0 || cfg->input_dropout >= 1 || cfg->dropout < 0 || cfg->dropout >= 1) return 1107;
@@ -149,6 +153,13 @@ int make_plan(const dj_config* cfg, Plan& p) {
   p.w_Xcol = wtake(p.Mt * 80 * p.esz);       // im2col view of the (dropped-out) notes, conv-kernel tap order
   p.w_Ycol = wtake(p.Mt * 64 * p.esz);       // tanh(conv) stash, overwritten by its gradient in BPTT
   p.w_zero = wtake(256);                      // a zero line (h_{-1} rows of the fused weight-gradient GEMM)
+  {                                           // fp32 scratch of the per-step path (layers with H not 128/256)
+    int64_t fl = 0;
+    if (!rec_persistent(p.Ht)) fl = dj_lstm_step_scratch_floats(p.Ht, p.tilesT);
+    if (!rec_persistent(p.Hn) && dj_lstm_step_scratch_floats(p.Hn, p.tilesN) > fl)
+      fl = dj_lstm_step_scratch_floats(p.Hn, p.tilesN);
+    p.w_step = wtake(fl * 4);
+  }
   p.ws_bytes = w;
   return 0;
 }
@@ -180,7 +191,7 @@ struct Ctx {
 // Fuse x*W into the recurrent kernel when its extra L2 weight stream (D x 4H) is no larger than
 // twice the recurrent one (H x 4H); wider inputs (note layer 0: D = 259 vs H = 128) are cheaper as
 // a separate GEMM (measured: fused +1.25 ms on the note axis vs 1.24 ms of GEMMs saved).
-inline bool fuse_xw(const LstmP& L) { return L.D <= 2 * L.H; }
+inline bool fuse_xw(const LstmP& L) { return rec_persistent(L.H) && L.D <= 2 * L.H; }
 
 // weight conversion/packing for one LSTM layer
 int prep_layer(const Ctx& c, const LstmP& L, int64_t wWt, int64_t wWc, int64_t wUf, int64_t wUb, bool need_bwd) {
@@ -190,7 +201,12 @@ int prep_layer(const Ctx& c, const LstmP& L, int64_t wWt, int64_t wWc, int64_t w
     RUN(dj_launch_lstm_pack_w(dt, L.H, c.P + L.W, L.D, dj_lstm_fused_nkx(dt, L.D), c.at(wWt), c.st));
   else              // k-contiguous Bt operand of the separate x*W GEMM
     RUN(dj_launch_cvt_transpose(dt, c.P + L.W, L.D, 4 * L.H, c.at(wWt), L.DP, c.st));
-  RUN(dj_launch_lstm_pack(dt, L.H, c.P + L.U, c.at(wUf), need_bwd ? c.at(wUb) : nullptr, c.st));
+  if (rec_persistent(L.H)) {
+    RUN(dj_launch_lstm_pack(dt, L.H, c.P + L.U, c.at(wUf), need_bwd ? c.at(wUb) : nullptr, c.st));
+  } else {          // per-step path: U^T [4H, H] for r = h U, and U [H, 4H] in the operand dtype for dh = dz U^T
+    RUN(dj_launch_cvt_transpose(dt, c.P + L.U, L.H, 4 * L.H, c.at(wUf), L.H, c.st));
+    if (need_bwd && dt != DJ_F32) RUN(dj_launch_cvt_copy(dt, c.P + L.U, (int64_t)L.H * 4 * L.H, c.at(wUb), c.st));
+  }
   if (need_bwd && dt != DJ_F32) RUN(dj_launch_cvt_copy(dt, c.P + L.W, (int64_t)L.D * 4 * L.H, c.at(wWc), c.st));
   return 0;
 }
@@ -221,10 +237,15 @@ int lstm_layer_fwd(const Ctx& c, const LstmP& L, int64_t tiles, int steps, int64
   }
   {
     ProfScope ps(PC_GEMM_XW, c.st);
-    RUN(dj_launch_gemm_nt(dt, (int)M, 4 * L.H, L.DP, c.at(wX), L.DP, c.at(wWt), L.DP, c.at(wZ), 4 * L.H, 2,
-                          c.P + L.b, c.st));
+    RUN(dj_launch_gemm_nt(dt, (int)M, 4 * L.H, L.DP, c.at(wX), L.DP, c.at(wWt), L.DP, c.at(wZ), 4 * L.H,
+                          rec_persistent(L.H) ? 2 : 0, c.P + L.b, c.st));
   }
   ProfScope ps(is_note ? PC_LSTM_FWD_NOTE : PC_LSTM_FWD_TIME, c.st);
+  if (!rec_persistent(L.H)) {
+    RUN(dj_launch_lstm_step_fwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUf), c.at(wH),
+                                c.train ? c.at(wC) : nullptr, c.at<float>(c.p.w_step), c.p.c.recurrent_sigmoid, c.st));
+    return 0;
+  }
   RUN(dj_launch_lstm_fwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUf), c.at(wH), c.train ? c.at(wC) : nullptr,
                          c.p.c.recurrent_sigmoid, c.train ? 1 : 0, c.st));
   return 0;
@@ -318,8 +339,14 @@ int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int st
   const int dt = c.p.c.dtype;
   {
     ProfScope ps(is_note ? PC_LSTM_BWD_NOTE : PC_LSTM_BWD_TIME, c.st);
-    RUN(dj_launch_lstm_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUb), c.at(wC), c.at(wdH), c.at(wdZ), G + L.b,
-                           c.p.c.recurrent_sigmoid, c.st));
+    if (rec_persistent(L.H)) {
+      RUN(dj_launch_lstm_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUb), c.at(wC), c.at(wdH), c.at(wdZ), G + L.b,
+                             c.p.c.recurrent_sigmoid, c.st));
+    } else {
+      const void* Uc = dt == DJ_F32 ? (const void*)(c.P + L.U) : (const void*)c.at(wUb);
+      RUN(dj_launch_lstm_step_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), Uc, c.at(wC), c.at(wdH), c.at(wdZ), G + L.b,
+                                  c.at<float>(c.p.w_step), c.p.c.recurrent_sigmoid, c.st));
+    }
   }
   {
     ProfScope ps(PC_GEMM_DW, c.st);

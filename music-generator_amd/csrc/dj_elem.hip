@@ -43,32 +43,40 @@ __global__ void dense_small_kernel(const float* __restrict__ A, int M, int K, co
   for (int k = 0; k < K; ++k) s += A[(int64_t)m * K + k] * W[(int64_t)k * N + n];
   C[idx] = act_tanh ? dj_tanh(s) : s;
 }
-// dA[m,k] (+)= sum_n dC[m,n] * W[k,n].  Block = 8 rows; W^T staged in LDS ([n][K], conflict-free
-// across k), the 8 dC rows too; thread (k, row pair).
+// dA[m,k] (+)= sum_n dC[m,n] * W[k,n].  Block = 8 rows; n runs in chunks of NC columns: W^T chunk
+// staged in LDS ([n][K], conflict-free across k), the 8 dC rows too; thread (k, row pair).
+constexpr int DSBX_NC = 320;
 __global__ __launch_bounds__(256) void dense_small_bwd_x_kernel(const float* __restrict__ dC, int M, int N,
                                                                 const float* __restrict__ W, int K,
                                                                 float* __restrict__ dA, int accumulate) {
   extern __shared__ float sm[];
-  float* wt = sm;               // [N][K]
-  float* dc = sm + N * K;       // [8][N]
+  const int NC = N < DSBX_NC ? N : DSBX_NC;
+  float* wt = sm;               // [NC][K]
+  float* dc = sm + NC * K;      // [8][NC]
   const int tid = threadIdx.x, m0 = blockIdx.x * 8;
-  for (int i = tid; i < N * K; i += 256) {
-    int k = i / N, n = i % N;   // coalesced read of W[k][n]
-    wt[n * K + k] = W[i];
-  }
-  for (int i = tid; i < 8 * N; i += 256) {
-    int r = i / N, n = i % N;
-    dc[i] = (m0 + r < M) ? dC[(int64_t)(m0 + r) * N + n] : 0.f;
-  }
-  __syncthreads();
   const int k = tid % 64, rp = tid / 64;   // rows 2*rp, 2*rp+1
-  if (k >= K) return;
   float s0 = 0.f, s1 = 0.f;
-  for (int n = 0; n < N; ++n) {
-    float w = wt[n * K + k];
-    s0 += dc[(2 * rp) * N + n] * w;
-    s1 += dc[(2 * rp + 1) * N + n] * w;
+  for (int n0 = 0; n0 < N; n0 += NC) {
+    const int nc = N - n0 < NC ? N - n0 : NC;
+    if (n0) __syncthreads();
+    for (int i = tid; i < nc * K; i += 256) {
+      int kk = i / nc, n = i % nc;   // coalesced read of W[kk][n0 + n]
+      wt[n * K + kk] = W[(int64_t)kk * N + n0 + n];
+    }
+    for (int i = tid; i < 8 * nc; i += 256) {
+      int r = i / nc, n = i % nc;
+      dc[r * NC + n] = (m0 + r < M) ? dC[(int64_t)(m0 + r) * N + n0 + n] : 0.f;
+    }
+    __syncthreads();
+    if (k < K) {
+      for (int n = 0; n < nc; ++n) {
+        float w = wt[n * K + k];
+        s0 += dc[(2 * rp) * NC + n] * w;
+        s1 += dc[(2 * rp + 1) * NC + n] * w;
+      }
+    }
   }
+  if (k >= K) return;
   int m = m0 + 2 * rp;
   if (m < M) dA[(int64_t)m * K + k] = accumulate ? dA[(int64_t)m * K + k] + s0 : s0;
   if (m + 1 < M) dA[(int64_t)(m + 1) * K + k] = accumulate ? dA[(int64_t)(m + 1) * K + k] + s1 : s1;
@@ -373,6 +381,132 @@ __device__ __forceinline__ float bce_clip(float t, float p, float& pc, bool& inr
   return fmaxf(l, 0.f) - l * t + log1pf(expf(-fabsf(l)));
 }
 
+// Per-row head math shared by both kernels: returns dl0..dl2 (already scaled) and the loss term.
+__device__ __forceinline__ void head_row_loss(const HeadArgs& a, int64_t rr, float p0, float p1, float l2, float& dl0,
+                                              float& dl1, float& dl2, float& Lv) {
+  const float t0 = a.target[rr * 3], t1 = a.target[rr * 3 + 1], t2 = a.target[rr * 3 + 2];
+  const float played = t0;
+  float pc;
+  bool inr;
+  Lv = bce_clip(t0, p0, pc, inr);
+  dl0 = inr ? (p0 - t0) : 0.f;
+  const float pe = played * p1 + (1.f - played) * t1;
+  Lv += bce_clip(t1, pe, pc, inr);
+  dl1 = inr ? (pc - t1) / (pc * (1.f - pc)) * played * p1 * (1.f - p1) : 0.f;
+  const float ve = played * l2 + (1.f - played) * t2;
+  const float diff = t2 - ve;
+  Lv += diff * diff;
+  dl2 = -2.f * diff * played;
+  dl0 *= a.inv_count;
+  dl1 *= a.inv_count;
+  dl2 *= a.inv_count;
+}
+
+// Any Hd (multiple of 8, up to 64*8*CPL): one wave per note row, lane owns chunks lane + 64*j of 8 units.
+template <typename T, int CPL>
+__global__ __launch_bounds__(256) void head_loss_wide_kernel(HeadArgs a, const T* __restrict__ Hn, T* __restrict__ dH) {
+  const int lane = threadIdx.x & 63, HD = a.Hd, nch = HD >> 3;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  float w0[CPL][8], w1[CPL][8], w2[CPL][8], g0[CPL][8], g1[CPL][8], g2[CPL][8];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int ch = lane + 64 * j;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int d = ch * 8 + e;
+      w0[j][e] = ch < nch ? a.Wn[d * 2] : 0.f;
+      w1[j][e] = ch < nch ? a.Wn[d * 2 + 1] : 0.f;
+      w2[j][e] = ch < nch ? a.Wv[d] : 0.f;
+      g0[j][e] = g1[j][e] = g2[j][e] = 0.f;
+    }
+  }
+  const float b0 = a.bn[0], b1 = a.bn[1], b2 = a.bv[0];
+  float gb0 = 0.f, gb1 = 0.f, gb2 = 0.f, lsum = 0.f;
+  const int64_t rows = (int64_t)a.B * a.T * a.N;
+  for (int64_t rr = wave; rr < rows; rr += nwaves) {
+    const int n = rr % a.N, bt = rr / a.N, t = bt % a.T, b = bt / a.T;
+    const int64_t row = dj_row_na(b, t, n, a.T, a.N);
+    const uint32_t rk = dj_rowkey(a.d_out, (uint32_t)rr);
+    float x[CPL][8], kp[CPL][8];
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int ch = lane + 64 * j;
+      if (ch < nch) {
+        load8(Hn + row * HD + ch * 8, x[j]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          kp[j][e] = dj_keep(a.d_out, rk, ch * 8 + e);
+          x[j][e] *= kp[j][e];
+          l0 += x[j][e] * w0[j][e];
+          l1 += x[j][e] * w1[j][e];
+          l2 += x[j][e] * w2[j][e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[j][e] = kp[j][e] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+      l0 += __shfl_xor(l0, sft);
+      l1 += __shfl_xor(l1, sft);
+      l2 += __shfl_xor(l2, sft);
+    }
+    l0 += b0;
+    l1 += b1;
+    l2 += b2;
+    const float p0 = dj_sigmoid(l0), p1 = dj_sigmoid(l1);
+    if (a.out && lane == 0) {
+      a.out[rr * 3] = p0;
+      a.out[rr * 3 + 1] = p1;
+      a.out[rr * 3 + 2] = l2;
+    }
+    if (!a.target) continue;
+    float dl0, dl1, dl2, Lv;
+    head_row_loss(a, rr, p0, p1, l2, dl0, dl1, dl2, Lv);
+    if (lane == 0) {
+      lsum += Lv;
+      gb0 += dl0;
+      gb1 += dl1;
+      gb2 += dl2;
+    }
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const int ch = lane + 64 * j;
+      float dh[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        g0[j][e] += x[j][e] * dl0;
+        g1[j][e] += x[j][e] * dl1;
+        g2[j][e] += x[j][e] * dl2;
+        dh[e] = (dl0 * w0[j][e] + dl1 * w1[j][e] + dl2 * w2[j][e]) * kp[j][e];
+      }
+      if (dH && ch < nch) store8(dH + row * HD + ch * 8, dh);
+    }
+  }
+  if (!a.target) return;
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    const int ch = lane + 64 * j;
+    if (ch >= nch) continue;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int d = ch * 8 + e;
+      atomicAdd(a.dWn + d * 2, g0[j][e]);
+      atomicAdd(a.dWn + d * 2 + 1, g1[j][e]);
+      atomicAdd(a.dWv + d, g2[j][e]);
+    }
+  }
+  if (lane == 0) {
+    atomicAdd(a.dbn, gb0);
+    atomicAdd(a.dbn + 1, gb1);
+    atomicAdd(a.dbv, gb2);
+    if (a.loss) atomicAdd(a.loss, lsum * a.inv_count);
+  }
+}
+
 // HD/8 lanes per note row (each lane 8 hidden units, one 16-byte load), 64/(HD/8) rows per wave.
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void head_loss_kernel(HeadArgs a, const T* __restrict__ Hn, T* __restrict__ dH) {
@@ -575,7 +709,8 @@ int dj_launch_dense_small(const float* A, int M, int K, const float* W, const fl
 int dj_launch_dense_small_bwd_x(const float* dC, int M, int N, const float* W, int K, float* dA, int accumulate,
                                 hipStream_t st) {
   if (K > 64) return 1020;
-  const size_t smb = ((size_t)N * K + 8 * (size_t)N) * sizeof(float);
+  const int NC = N < DSBX_NC ? N : DSBX_NC;
+  const size_t smb = ((size_t)NC * K + 8 * (size_t)NC) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)dense_small_bwd_x_kernel,
@@ -662,7 +797,22 @@ int dj_launch_head(int dtype, const void* ha, const void* Hn, void* dH, hipStrea
                   hipLaunchKernelGGL((head_loss_kernel<bf16_t, 256>), dim3(grid), dim3(256), 0, st, a,
                                      (const bf16_t*)Hn, (bf16_t*)dH))
   } else {
-    return 1024;
+    // generic width: one wave per row; a small persistent grid keeps the closing weight-gradient atomics cheap
+    if (a.Hd % 8 || a.Hd > 2048) return 1024;
+    const int g2 = (int)((rows + 3) / 4 < 512 ? (rows + 3) / 4 : 512);
+#define DJ_HEAD_WIDE(CPL)                                                                                              \
+  DJ_T_DISPATCH(hipLaunchKernelGGL((head_loss_wide_kernel<float, CPL>), dim3(g2), dim3(256), 0, st, a,                 \
+                                   (const float*)Hn, (float*)dH),                                                      \
+                hipLaunchKernelGGL((head_loss_wide_kernel<bf16_t, CPL>), dim3(g2), dim3(256), 0, st, a,                \
+                                   (const bf16_t*)Hn, (bf16_t*)dH))
+    if (a.Hd <= 512) {
+      DJ_HEAD_WIDE(1)
+    } else if (a.Hd <= 1024) {
+      DJ_HEAD_WIDE(2)
+    } else {
+      DJ_HEAD_WIDE(4)
+    }
+#undef DJ_HEAD_WIDE
   }
   return (int)hipGetLastError();
 }

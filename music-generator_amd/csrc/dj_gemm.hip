@@ -49,10 +49,17 @@ __device__ __forceinline__ void mma_tile(const T* As, const T* Bs, f32x16 (&acc)
 }
 
 // ------------------------------------------------------------------ NT
+// Row-block stride (a_rbs / c_rbs, in 32-row blocks; 1 = dense): virtual row v lives at physical
+// row ((v >> 5) * rbs) * 32 + (v & 31).  With rbs = steps and the base pointer advanced to step t
+// this addresses "all sequences at step t" of a sequence-tiled activation buffer (dj_common.h
+// dj_row), which is what the per-step recurrent GEMMs of the generic-H LSTM path multiply.
+__device__ __forceinline__ int64_t rbs_row(int v, int rbs) { return (((int64_t)(v >> 5) * rbs) << 5) + (v & 31); }
+
 template <typename T, typename TC>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const T* __restrict__ A, int lda,
                                                       const T* __restrict__ Bt, int ldb, TC* __restrict__ C, int ldc,
-                                                      const float* __restrict__ bias, int ntn, int c_frag) {
+                                                      const float* __restrict__ bias, int ntn, int c_frag, int a_rbs,
+                                                      int c_rbs) {
   using G = GemmCfg<T>;
   __shared__ __attribute__((aligned(16))) T As[128 * G::LDT];
   __shared__ __attribute__((aligned(16))) T Bs[128 * G::LDT];
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const
       int row = vid >> 3, kv = (vid & 7) * G::EPL;
       uint4 z = make_uint4(0, 0, 0, 0);
       bool kin = (k0 + kv) < K;
-      ra[i] = (kin && (m0 + row) < M) ? ldg16(A + (int64_t)(m0 + row) * lda + k0 + kv) : z;
+      ra[i] = (kin && (m0 + row) < M) ? ldg16(A + rbs_row(m0 + row, a_rbs) * lda + k0 + kv) : z;
       rb[i] = (kin && (n0 + row) < N) ? ldg16(Bt + (int64_t)(n0 + row) * ldb + k0 + kv) : z;
     }
   };
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(int M, int N, int K, const
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         int row = m0 + wr * 64 + i * 32 + dj_crow(r, lane);
-        if (row < M) C[(int64_t)row * ldc + col] = dj_from_f32<TC>(acc[i][j][r] + bv);
+        if (row < M) C[rbs_row(row, c_rbs) * ldc + col] = dj_from_f32<TC>(acc[i][j][r] + bv);
       }
     }
 }
@@ -623,7 +630,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
                                                                int lda, const bf16_t* __restrict__ Bt, int ldb,
                                                                TC* __restrict__ C, int ldc,
                                                                const float* __restrict__ bias, int ntn, int ntm,
-                                                               int c_frag, int xcd_map) {
+                                                               int c_frag, int xcd_map, int a_rbs, int c_rbs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
@@ -657,7 +664,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
     for (int i = 0; i < 4; ++i) {
       const int piece = w * 4 + i, row = piece * 8 + rsub;
       const int kk = k0 + ((cp ^ ((row >> 1) & 7)) << 3);
-      const bf16_t* src = (m0 + row < M && kk < K) ? A + (int64_t)(m0 + row) * lda + kk : zl;
+      const bf16_t* src = (m0 + row < M && kk < K) ? A + rbs_row(m0 + row, a_rbs) * lda + kk : zl;
       glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(sa) + piece * 1024));
     }
 #pragma unroll
@@ -726,7 +733,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
                 const int row = rowb + dj_crow(r, lane);
-                if (row < M) C[(int64_t)row * ldc + col] = dj_from_f32<TC>(acc[i][j][r] + bv);
+                if (row < M) C[rbs_row(row, c_rbs) * ldc + col] = dj_from_f32<TC>(acc[i][j][r] + bv);
               }
             }
           }
@@ -741,7 +748,13 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
 // ------------------------------------------------------------------ launchers (internal C++ API)
 int dj_launch_gemm_nt(int dtype, int M, int N, int K, const void* A, int lda, const void* Bt, int ldb, void* C, int ldc,
                       int c_mode, const float* bias, hipStream_t st) {
+  return dj_launch_gemm_nt_rbs(dtype, M, N, K, A, lda, 1, Bt, ldb, C, ldc, 1, c_mode, bias, st);
+}
+
+int dj_launch_gemm_nt_rbs(int dtype, int M, int N, int K, const void* A, int lda, int a_rbs, const void* Bt, int ldb,
+                          void* C, int ldc, int c_rbs, int c_mode, const float* bias, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (a_rbs < 1 || c_rbs < 1 || (c_mode == 2 && c_rbs != 1)) return 1006;
   const int epl = dtype == DJ_F32 ? 4 : 8;
   if ((K % epl) || (lda % epl) || (ldb % epl)) return 1001;
   const int c_is_f32 = c_mode == 1, c_frag = c_mode == 2;
@@ -773,18 +786,18 @@ int dj_launch_gemm_nt(int dtype, int M, int N, int K, const void* A, int lda, co
     }
     if (c_is_f32)
       hipLaunchKernelGGL(gemm_nt_bf16_dma_kernel<float>, dim3(grid2), dim3(512), smem, st, M, N, K, (const bf16_t*)A,
-                         lda, (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn2, ntm2, c_frag, xcd_map);
+                         lda, (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn2, ntm2, c_frag, xcd_map, a_rbs, c_rbs);
     else
       hipLaunchKernelGGL(gemm_nt_bf16_dma_kernel<bf16_t>, dim3(grid2), dim3(512), smem, st, M, N, K,
                          (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn2, ntm2, c_frag,
-                         xcd_map);
+                         xcd_map, a_rbs, c_rbs);
     return (int)hipGetLastError();
   }
   // fp32 (parity mode): register-staged 128 x 128 kernel on v_mfma_f32_32x32x2_f32
   int ntn = (N + 127) / 128, ntm = (M + 127) / 128;
   dim3 grid((unsigned)(ntn * (int64_t)ntm)), block(256);
   hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, block, 0, st, M, N, K, (const float*)A, lda,
-                     (const float*)Bt, ldb, (float*)C, ldc, bias, ntn, c_frag);
+                     (const float*)Bt, ldb, (float*)C, ldc, bias, ntn, c_frag, a_rbs, c_rbs);
   return (int)hipGetLastError();
 }
 

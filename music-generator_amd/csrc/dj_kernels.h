@@ -52,6 +52,9 @@ struct NadamArgs {
 // dj_gemm.hip
 int dj_launch_gemm_nt(int dtype, int M, int N, int K, const void* A, int lda, const void* Bt, int ldb, void* C, int ldc,
                       int c_mode, const float* bias, hipStream_t st);
+// same with row-block strides on A and C (dj_gemm.hip rbs_row): per-step views of sequence-tiled buffers
+int dj_launch_gemm_nt_rbs(int dtype, int M, int N, int K, const void* A, int lda, int a_rbs, const void* Bt, int ldb,
+                          void* C, int ldc, int c_rbs, int c_mode, const float* bias, hipStream_t st);
 int dj_launch_gemm_tn(int dtype, int64_t M, int Ka, int ka_valid, int N, const void* A, int lda, const void* B, int ldb, float* C,
                       int ldc, int a_shift, int steps, hipStream_t st);
 int dj_launch_lstm_wgrad(int dtype, int64_t M, int steps, const void* X, int DP, int D, const void* Hs, int H,
@@ -67,6 +70,12 @@ int dj_launch_lstm_pack_w(int dtype, int H, const float* W, int D, int NKX, void
 int dj_launch_lstm_fwd_fused(int dtype, int H, int ntiles, int steps, const void* X, int DP, int NKX,
                              const void* Wpack, const float* bias, void* Zst, const void* Upack, void* Hout,
                              void* Cout, int sigm, hipStream_t st);
+// dj_step.hip -- generic-H path (one GEMM + gate launch per recurrence step)
+int64_t dj_lstm_step_scratch_floats(int H, int64_t ntiles);
+int dj_launch_lstm_step_fwd(int dtype, int H, int ntiles, int steps, void* Z, const void* Ut, void* Hs, void* Cs,
+                            float* scratch, int sigm, hipStream_t st);
+int dj_launch_lstm_step_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* Uc, const void* Cs,
+                            const void* dH, void* dZ, float* dbias, float* scratch, int sigm, hipStream_t st);
 // dj_elem.hip
 int dj_launch_dense_small(const float* A, int M, int K, const float* W, const float* b, float* C, int N, int act_tanh,
                           hipStream_t st);

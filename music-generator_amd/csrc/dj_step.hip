@@ -1,0 +1,226 @@
+// Generic-H LSTM path: one GEMM + one gate launch per recurrence step.
+//
+// The persistent recurrent kernels (dj_lstm.hip) keep a 32-sequence tile on one CU for the whole
+// recurrence and are instantiated for H = 128 / 256 (the reference's sizes, constants.py:72-73).
+// For wider layers (BASELINE "scaled model": 1024 units) the recurrent product of ONE step,
+// [all sequences, H] x [H, 4H], is already a chip-filling GEMM, so the recurrence is driven from
+// the host as `steps` x (GEMM + elementwise gate kernel) on the caller's stream:
+//
+//   forward  (Keras LSTM cell):  r_t = h_{t-1} U ; z_t = (x_t W + b) + r_t ;
+//            i,f,o = recurrent_act(z) ; g = tanh(z_c) ; c_t = f c_{t-1} + i g ; h_t = o tanh(c_t)
+//   backward (BPTT): dh_t = dH_t + dz_{t+1} U^T ; dz_t from (z_t, c_t, c_{t-1}, dc carry)
+//
+// Buffers are row-major in the sequence-tiled row order of dj_common.h (dj_row); "all sequences
+// at step t" is addressed with the row-block stride of dj_launch_gemm_nt_rbs.  The cell state and
+// its gradient are carried between launches in fp32 (as the persistent kernels carry them in
+// registers); z, c, h stashes have the operand dtype.
+#include "dj_common.h"
+#include "dj_kernels.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ void ld4(const T* p, float* x);
+template <> __device__ __forceinline__ void ld4<float>(const float* p, float* x) {
+  const float4 v = *(const float4*)p;
+  x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+}
+template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float* x) {
+  const uint2 v = *(const uint2*)p;
+  x[0] = __uint_as_float(v.x << 16); x[1] = __uint_as_float(v.x & 0xFFFF0000u);
+  x[2] = __uint_as_float(v.y << 16); x[3] = __uint_as_float(v.y & 0xFFFF0000u);
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, const float* x);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float* x) {
+  *(float4*)p = make_float4(x[0], x[1], x[2], x[3]);
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float* x) {
+  bf16_t t[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) t[e] = dj_from_f32<bf16_t>(x[e]);
+  *(uint2*)p = *(const uint2*)t;
+}
+
+__device__ __forceinline__ int64_t step_row(int v, int steps, int t) {
+  return (((int64_t)(v >> 5) * steps + t) << 5) + (v & 31);
+}
+
+// one thread = 4 consecutive units of one sequence
+template <typename T, bool SIGM>
+__global__ __launch_bounds__(256) void step_fwd_kernel(T* __restrict__ Z, const float* __restrict__ R,
+                                                       float* __restrict__ cst, T* __restrict__ Hs,
+                                                       T* __restrict__ Cs, int H, int nrows, int steps, int t) {
+  const int q = H >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)nrows * q) return;
+  const int v = (int)(idx / q), u = (int)(idx % q) * 4;
+  const int64_t pr = step_row(v, steps, t);
+  float z[4][4], c[4], hn[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) ld4<T>(Z + pr * 4 * H + g * H + u, z[g]);
+  if (t > 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float r[4];
+      ld4<float>(R + (int64_t)v * 4 * H + g * H + u, r);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) z[g][e] += r[e];
+    }
+    ld4<float>(cst + (int64_t)v * H + u, c);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c[e] = 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float ig = dj_ract<SIGM>(z[0][e]), fg = dj_ract<SIGM>(z[1][e]), gg = dj_tanh(z[2][e]),
+                og = dj_ract<SIGM>(z[3][e]);
+    c[e] = fg * c[e] + ig * gg;
+    hn[e] = og * dj_tanh(c[e]);
+  }
+  st4<float>(cst + (int64_t)v * H + u, c);
+  st4<T>(Hs + pr * H + u, hn);
+  if (Cs) {
+    st4<T>(Cs + pr * H + u, c);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) st4<T>(Z + pr * 4 * H + g * H + u, z[g]);   // pre-activation stash for BPTT
+  }
+}
+
+template <typename T, bool SIGM>
+__global__ __launch_bounds__(256) void step_bwd_kernel(const T* __restrict__ Z, const T* __restrict__ Cs,
+                                                       const T* __restrict__ dH, const float* __restrict__ Rb,
+                                                       float* __restrict__ dcs, T* __restrict__ dZ, int H, int nrows,
+                                                       int steps, int t) {
+  const int q = H >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)nrows * q) return;
+  const int v = (int)(idx / q), u = (int)(idx % q) * 4;
+  const int64_t pr = step_row(v, steps, t);
+  float z[4][4], ct[4], cp[4], dh[4], dcc[4], dz[4][4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) ld4<T>(Z + pr * 4 * H + g * H + u, z[g]);
+  ld4<T>(Cs + pr * H + u, ct);
+  ld4<T>(dH + pr * H + u, dh);
+  if (t > 0) {
+    ld4<T>(Cs + (pr - 32) * H + u, cp);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cp[e] = 0.f;
+  }
+  if (t < steps - 1) {
+    float r[4];
+    ld4<float>(Rb + (int64_t)v * H + u, r);
+    ld4<float>(dcs + (int64_t)v * H + u, dcc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dh[e] += r[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dcc[e] = 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float zi = z[0][e], zf = z[1][e], zg = z[2][e], zo = z[3][e];
+    const float ig = dj_ract<SIGM>(zi), fg = dj_ract<SIGM>(zf), gg = dj_tanh(zg), og = dj_ract<SIGM>(zo);
+    const float tc = dj_tanh(ct[e]);
+    const float dc = dcc[e] + dh[e] * og * (1.f - tc * tc);
+    dz[3][e] = dh[e] * tc * dj_ract_grad<SIGM>(zo, og);
+    dz[0][e] = dc * gg * dj_ract_grad<SIGM>(zi, ig);
+    dz[1][e] = dc * cp[e] * dj_ract_grad<SIGM>(zf, fg);
+    dz[2][e] = dc * ig * (1.f - gg * gg);
+    dcc[e] = dc * fg;
+  }
+  st4<float>(dcs + (int64_t)v * H + u, dcc);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) st4<T>(dZ + pr * 4 * H + g * H + u, dz[g]);
+}
+
+// out[c] += sum over rows of A[r, c]: 256 columns per workgroup column tile, rows split over gridDim.y
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, int64_t rows, int cols, int64_t rps,
+                                                     float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rps, r1 = r0 + rps < rows ? r0 + rps : rows;
+  float s = 0.f;
+  for (int64_t r = r0; r < r1; ++r) s += dj_to_f32(A[r * cols + c]);
+  atomicAdd(out + c, s);
+}
+
+template <typename T>
+int step_fwd_t(int H, int ntiles, int steps, void* Z, const void* Ut, void* Hs, void* Cs, float* R, float* cst,
+               int sigm, hipStream_t st) {
+  const int dtype = sizeof(T) == 4 ? DJ_F32 : DJ_BF16;
+  const int nrows = ntiles * 32;
+  const int64_t n = (int64_t)nrows * (H >> 2);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  for (int t = 0; t < steps; ++t) {
+    if (t > 0) {
+      // r_t = h_{t-1} U  (Bt = U^T [4H, H], k-contiguous)
+      int rc = dj_launch_gemm_nt_rbs(dtype, nrows, 4 * H, H, (const T*)Hs + (int64_t)(t - 1) * 32 * H, H, steps, Ut, H,
+                                     R, 4 * H, 1, 1, nullptr, st);
+      if (rc) return rc;
+    }
+    if (sigm)
+      hipLaunchKernelGGL((step_fwd_kernel<T, true>), grid, block, 0, st, (T*)Z, R, cst, (T*)Hs, (T*)Cs, H, nrows, steps, t);
+    else
+      hipLaunchKernelGGL((step_fwd_kernel<T, false>), grid, block, 0, st, (T*)Z, R, cst, (T*)Hs, (T*)Cs, H, nrows, steps, t);
+  }
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+int step_bwd_t(int H, int ntiles, int steps, const void* Z, const void* Uc, const void* Cs, const void* dH, void* dZ,
+               float* dbias, float* Rb, float* dcs, int sigm, hipStream_t st) {
+  const int dtype = sizeof(T) == 4 ? DJ_F32 : DJ_BF16;
+  const int nrows = ntiles * 32;
+  const int64_t n = (int64_t)nrows * (H >> 2);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  for (int t = steps - 1; t >= 0; --t) {
+    if (t < steps - 1) {
+      // recurrent part of dh_t = dz_{t+1} U^T  (Bt = U [H, 4H], k-contiguous)
+      int rc = dj_launch_gemm_nt_rbs(dtype, nrows, H, 4 * H, (const T*)dZ + (int64_t)(t + 1) * 32 * 4 * H, 4 * H, steps,
+                                     Uc, 4 * H, Rb, H, 1, 1, nullptr, st);
+      if (rc) return rc;
+    }
+    if (sigm)
+      hipLaunchKernelGGL((step_bwd_kernel<T, true>), grid, block, 0, st, (const T*)Z, (const T*)Cs, (const T*)dH, Rb, dcs,
+                         (T*)dZ, H, nrows, steps, t);
+    else
+      hipLaunchKernelGGL((step_bwd_kernel<T, false>), grid, block, 0, st, (const T*)Z, (const T*)Cs, (const T*)dH, Rb,
+                         dcs, (T*)dZ, H, nrows, steps, t);
+  }
+  if (dbias) {
+    const int64_t rows = (int64_t)nrows * steps;
+    int splits = (int)((rows + 511) / 512);
+    if (splits > 1024) splits = 1024;
+    const int64_t rps = (rows + splits - 1) / splits;
+    hipLaunchKernelGGL(colsum_kernel<T>, dim3((4 * H + 255) / 256, splits), dim3(256), 0, st, (const T*)dZ, rows, 4 * H,
+                       rps, dbias);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// float scratch the step path needs for `ntiles` sequence tiles of width H: r/rb [rows, 4H] + carry [rows, H]
+int64_t dj_lstm_step_scratch_floats(int H, int64_t ntiles) { return ntiles * 32 * 5 * (int64_t)H; }
+
+int dj_launch_lstm_step_fwd(int dtype, int H, int ntiles, int steps, void* Z, const void* Ut, void* Hs, void* Cs,
+                            float* scratch, int sigm, hipStream_t st) {
+  if (ntiles <= 0 || steps <= 0) return 0;
+  if (H < 32 || (H % 32)) return 1012;
+  float* R = scratch;
+  float* cst = scratch + (int64_t)ntiles * 32 * 4 * H;
+  return dtype == DJ_F32 ? step_fwd_t<float>(H, ntiles, steps, Z, Ut, Hs, Cs, R, cst, sigm, st)
+                         : step_fwd_t<bf16_t>(H, ntiles, steps, Z, Ut, Hs, Cs, R, cst, sigm, st);
+}
+
+int dj_launch_lstm_step_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* Uc, const void* Cs,
+                            const void* dH, void* dZ, float* dbias, float* scratch, int sigm, hipStream_t st) {
+  if (ntiles <= 0 || steps <= 0) return 0;
+  if (H < 32 || (H % 32)) return 1012;
+  float* Rb = scratch;
+  float* dcs = scratch + (int64_t)ntiles * 32 * 4 * H;
+  return dtype == DJ_F32 ? step_bwd_t<float>(H, ntiles, steps, Z, Uc, Cs, dH, dZ, dbias, Rb, dcs, sigm, st)
+                         : step_bwd_t<bf16_t>(H, ntiles, steps, Z, Uc, Cs, dH, dZ, dbias, Rb, dcs, sigm, st);
+}

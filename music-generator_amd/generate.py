@@ -102,6 +102,8 @@ def _fused_engine(models, n_pieces):
     shared = getattr(models[1], "_s", None)
     if shared is None or getattr(shared.backend, "name", "") != "hip":
         return None
+    if shared.cfg.note_axis_units > 256 or shared.cfg.time_axis_units + 3 > 512:
+        return None                                # wider than the single-workgroup sampler (dj_gen.hip): predict() loop
     return shared, shared.engine(n_pieces, SEQ_LEN, train=False)
 
 

@@ -54,6 +54,11 @@ CASES = [
     ("sigmoid_gates", dict(recurrent_activation="sigmoid", time_axis_units=128), 2, 4, 0.0, 0.0),
     ("three_layers", dict(time_axis_layers=3, note_axis_layers=1, time_axis_units=128, note_axis_units=256), 2, 4,
      0.0, 0.5),
+    # widths without a persistent recurrent kernel run the per-step GEMM + gate path (dj_step.hip)
+    ("scaled_3x1024", dict(time_axis_layers=3, note_axis_layers=3, time_axis_units=1024, note_axis_units=1024,
+                           num_notes=12), 2, 4, 0.2, 0.5),
+    ("mixed_512_96", dict(time_axis_units=512, note_axis_units=96, num_notes=24), 3, 5, 0.0, 0.5),
+    ("step_time_persistent_note", dict(time_axis_units=64, note_axis_units=128, num_notes=40), 2, 6, 0.2, 0.0),
 ]
 
 
@@ -79,9 +84,11 @@ def test_train_step_fp32_parity(gpu_device, name, kw, B, T, pin, pdr):
     assert worst < 2e-3, sorted(rows, key=lambda r: -r[1])[:6]
 
 
-def test_train_step_bf16_close(gpu_device):
+@pytest.mark.parametrize("kw", [dict(), dict(time_axis_units=512, note_axis_units=512, num_notes=24)],
+                         ids=["ref_dims", "step_path_512"])
+def test_train_step_bf16_close(gpu_device, kw):
     T, B = 8, 2
-    ocfg, dcfg = _cfgs(time_steps=T, dtype="bf16")
+    ocfg, dcfg = _cfgs(time_steps=T, dtype="bf16", **kw)
     params = O.init_params(ocfg, seed=11)
     flat = O.flatten_params(ocfg, params)
     batch = O.synthetic_batch(ocfg, B, seed=3, T=T)
