@@ -162,6 +162,8 @@ def main():
     ap.add_argument("--notes", type=int, default=128)
     ap.add_argument("--cpu-sample", type=int, default=2, help="sequences in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--dropout", type=float, nargs=2, default=None, metavar=("INPUT", "HIDDEN"),
+                    help="override the reference's dropout rates 0.2 0.5 (experiments only; the metric uses the defaults)")
     ap.add_argument("--gen-steps", type=int, default=32, help="generated time steps for the secondary metric (0 = skip)")
     args = ap.parse_args()
 
@@ -186,7 +188,7 @@ def main():
     from music_generator_amd.engine import DeepJConfig, Engine, Nadam, init_params_numpy
 
     B, T, N = args.batch, args.time_steps, args.notes
-    pin, pdr = 0.2, 0.5                                  # model.py:128 defaults
+    pin, pdr = args.dropout or (0.2, 0.5)                # model.py:128 defaults
     cfg = DeepJConfig(num_notes=N, time_steps=T, dtype=args.dtype)
     eng = Engine(cfg, B, T, device=dev, input_dropout=pin, dropout=pdr)
     P = torch.from_numpy(init_params_numpy(cfg, seed=1234)).to(dev)     # replicated weights
@@ -277,7 +279,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"biaxial-LSTM train step, batch {B}/GPU x {T} steps x {N} notes "
-                                   f"(BASELINE configs[1]), 2x256 time-axis + 2x128 note-axis LSTM, dropout 0.2/0.5, "
+                                   f"(BASELINE configs[1]), 2x256 time-axis + 2x128 note-axis LSTM, dropout {pin}/{pdr}, "
                                    f"Nadam; random-init weights",
                        "global_batch": B * world, "seq_len": T, "num_notes": N, "parallelism": f"dp{world}"},
             "model_tflops_per_s": round(flops_step * world * args.steps / elapsed / 1e12, 2),

@@ -281,50 +281,51 @@ __global__ __launch_bounds__(256) void feature_bwd_kernel(FeatArgs a, const T* _
 // ------------------------------------------------------------------ inter-layer glue
 
 // x_next = concat[drop(h), shift(drop(chosen))] + drop(tanh-style)   (model.py:85,77-82 / 101-117)
+// One workgroup per (b,t); thread = (8-column chunk, note group), notes strided by the group count:
+// no per-element index division, 16-byte accesses, the style row is read once per thread.
 template <typename T>
-__global__ void glue_fwd_kernel(GlueArgs a, const T* __restrict__ Hin, T* __restrict__ X) {
-  const int chunks = a.DP / 8;
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)a.B * a.T * a.N * chunks) return;
-  const int ch = idx % chunks;
-  const uint32_t r = (uint32_t)(idx / chunks);
-  const int n = r % a.N, bt = r / a.N, t = bt % a.T, b = bt / a.T;
-  const int64_t rin = a.in_na ? dj_row_na(b, t, n, a.T, a.N) : dj_row_ta(b, t, n, a.T, a.N);
-  const int64_t rout = a.out_na ? dj_row_na(b, t, n, a.T, a.N) : dj_row_ta(b, t, n, a.T, a.N);
-  const uint32_t ko = dj_rowkey(a.d_out, r), ks = dj_rowkey(a.d_style, r);
+__global__ __launch_bounds__(256) void glue_fwd_kernel(GlueArgs a, const T* __restrict__ Hin, T* __restrict__ X) {
+  const int bt = blockIdx.x, t = bt % a.T, b = bt / a.T;
+  const int chunks = a.DP / 8, groups = 256 / chunks;
+  const int ch = threadIdx.x % chunks, grp = threadIdx.x / chunks;
+  if (grp >= groups) return;
   const int d0 = ch * 8;
-  float v[8];
-  if (d0 + 8 <= a.Hd) {                      // whole chunk comes from the producing layer's h
-    load8(Hin + rin * a.Hd + d0, v);
+  const bool whole_h = d0 + 8 <= a.Hd;
+  float spv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= dj_keep(a.d_out, ko, d0 + e);
-  } else {
+  for (int e = 0; e < 8; ++e) spv[e] = (a.sp && d0 + e < a.D) ? a.sp[(int64_t)bt * a.D + d0 + e] : 0.f;
+  for (int n = grp; n < a.N; n += groups) {
+    const uint32_t r = (uint32_t)bt * a.N + n;
+    const int64_t rin = a.in_na ? dj_row_na(b, t, n, a.T, a.N) : dj_row_ta(b, t, n, a.T, a.N);
+    const int64_t rout = a.out_na ? dj_row_na(b, t, n, a.T, a.N) : dj_row_ta(b, t, n, a.T, a.N);
+    const uint32_t ko = dj_rowkey(a.d_out, r), ks = dj_rowkey(a.d_style, r);
+    float v[8];
+    if (whole_h) {                             // whole chunk comes from the producing layer's h
+      load8(Hin + rin * a.Hd + d0, v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int d = d0 + e;
-      v[e] = 0.f;
-      if (d < a.Hd)
-        v[e] = dj_to_f32(Hin[rin * a.Hd + d]) * dj_keep(a.d_out, ko, d);
-      else if (a.chosen && d < a.Hd + 3 && n > 0)
-        v[e] = a.chosen[(int64_t)(r - 1) * 3 + (d - a.Hd)] *
-               dj_keep(a.d_chosen, dj_rowkey(a.d_chosen, r - 1), d - a.Hd);
-    }
-  }
-  if (a.sp) {
-    if (d0 + 8 <= a.D) {
-      const float* sp = a.sp + (int64_t)bt * a.D + d0;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += sp[e] * dj_keep(a.d_style, ks, d0 + e);
+      for (int e = 0; e < 8; ++e) v[e] *= dj_keep(a.d_out, ko, d0 + e);
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (d0 + e < a.D) v[e] += a.sp[(int64_t)bt * a.D + d0 + e] * dj_keep(a.d_style, ks, d0 + e);
+      for (int e = 0; e < 8; ++e) {
+        const int d = d0 + e;
+        v[e] = 0.f;
+        if (d < a.Hd)
+          v[e] = dj_to_f32(Hin[rin * a.Hd + d]) * dj_keep(a.d_out, ko, d);
+        else if (a.chosen && d < a.Hd + 3 && n > 0)
+          v[e] = a.chosen[(int64_t)(r - 1) * 3 + (d - a.Hd)] *
+                 dj_keep(a.d_chosen, dj_rowkey(a.d_chosen, r - 1), d - a.Hd);
+      }
     }
-  }
+    if (a.sp) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e)
-    if (d0 + e >= a.D) v[e] = 0.f;
-  store8(X + rout * a.DP + d0, v);
+      for (int e = 0; e < 8; ++e)
+        if (d0 + e < a.D) v[e] += spv[e] * dj_keep(a.d_style, ks, d0 + e);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (d0 + e >= a.D) v[e] = 0.f;
+    store8(X + rout * a.DP + d0, v);
+  }
 }
 
 // backward: dH = dX * keep_out ; dpre[bt,d] = (sum_n dX * keep_style) * (1 - sp^2)
@@ -764,11 +765,10 @@ int dj_launch_feature_bwd(int dtype, const void* fa, const void* dX, void* Ycol,
 }
 int dj_launch_glue_fwd(int dtype, const void* ga, const void* Hin, void* X, hipStream_t st) {
   const GlueArgs& a = *(const GlueArgs*)ga;
-  if (a.DP % 8) return 1023;
-  int64_t n = (int64_t)a.B * a.T * a.N * (a.DP / 8);
-  DJ_T_DISPATCH(hipLaunchKernelGGL(glue_fwd_kernel<float>, dim3(nblk(n)), dim3(256), 0, st, a, (const float*)Hin,
+  if (a.DP % 8 || a.DP > 2048) return 1023;
+  DJ_T_DISPATCH(hipLaunchKernelGGL(glue_fwd_kernel<float>, dim3(a.B * a.T), dim3(256), 0, st, a, (const float*)Hin,
                                    (float*)X),
-                hipLaunchKernelGGL(glue_fwd_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, st, a, (const bf16_t*)Hin,
+                hipLaunchKernelGGL(glue_fwd_kernel<bf16_t>, dim3(a.B * a.T), dim3(256), 0, st, a, (const bf16_t*)Hin,
                                    (bf16_t*)X))
   return (int)hipGetLastError();
 }
