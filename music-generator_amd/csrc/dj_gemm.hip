@@ -743,6 +743,168 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
   }
 }
 
+
+// ------------------------------------------------------------------ NT, bf16, 256 x 256 tiles
+// Same contract as the kernel above for outputs at least 129 columns wide: one A panel pass covers
+// 256 output columns (half the operand bytes per MFMA of the 256 x 128 tiling), 8 waves as 2 x 4,
+// each 128 x 64 (8 accumulator blocks).  BK = 32, 4-stage LDS ring (4 x 32 KiB) filled by LDS-DMA
+// three stages ahead.  LDS rows are 64 B (32 bf16); 16-byte chunk c of row r lives at chunk
+// c ^ ((r>>2)&3), applied on the DMA source address: a ds_read_b128 wavefront phase (16 lanes =
+// 16 rows) then touches every bank exactly once.  Tile order: the 32 workgroups of one XCD walk
+// (m-tile, n-tile) pairs n-fastest, so the n-tiles of one A panel run side by side on ONE L2.
+constexpr int NT3_BM = 256, NT3_BN = 256, NT3_BK = 32, NT3_NS = 4;
+constexpr int NT3_ABYTES = NT3_BM * NT3_BK * 2, NT3_BBYTES = NT3_BN * NT3_BK * 2, NT3_STAGE = NT3_ABYTES + NT3_BBYTES;
+
+// Row-major output (CFRAG = false) multiplies with the operands swapped, so a lane's accumulator
+// block holds C^T: 4 consecutive output columns of ONE row per register quad, stored as one 8-byte
+// (bf16) / 16-byte (f32) vector -- 32 stores per lane and tile instead of 128 scalar ones.
+__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
+  *(uint2*)p = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+}
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+  *(float4*)p = make_float4(a, b, c, d);
+}
+
+template <typename TC, bool CFRAG>
+__global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, int K, const bf16_t* __restrict__ A,
+                                                                int lda, const bf16_t* __restrict__ Bt, int ldb,
+                                                                TC* __restrict__ C, int ldc,
+                                                                const float* __restrict__ bias, int ntn, int ntm,
+                                                                int a_rbs, int c_rbs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 2, wc = w & 3;
+  const int nk = (K + NT3_BK - 1) / NT3_BK;
+  // this workgroup's tiles: q = slot, slot + slots, ... over the (m-tile, n-tile) pairs of its XCD
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = (int)(gridDim.x >> 3);
+  const int mt_xcd = ntm > xcd ? (ntm - xcd + 7) / 8 : 0;       // m-tiles xcd, xcd+8, ...
+  const int q_total = mt_xcd * ntn;
+  const int my_tiles = slot < q_total ? (q_total - slot + slots - 1) / slots : 0;
+  const int nstages = my_tiles * nk;
+  const bf16_t* zl = (const bf16_t*)dj_zero_line;
+
+  auto tile_of = [&](int tl, int& m0, int& n0) {
+    const int q = slot + tl * slots;
+    m0 = (xcd + 8 * (q / ntn)) * NT3_BM;
+    n0 = (q % ntn) * NT3_BN;
+  };
+  auto issue = [&](int s) {
+    const int tl = s / nk, kt = s - tl * nk;
+    int m0, n0;
+    tile_of(tl, m0, n0);
+    const int k0 = kt * NT3_BK;
+    unsigned char* sa = smem + (s % NT3_NS) * NT3_STAGE;
+    unsigned char* sb = sa + NT3_ABYTES;
+    const int rsub = lane >> 2, cp = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = w * 2 + i, row = piece * 16 + rsub;
+      const int kk = k0 + ((cp ^ ((row >> 2) & 3)) << 3);
+      const bf16_t* src = (m0 + row < M && kk < K) ? A + rbs_row(m0 + row, a_rbs) * lda + kk : zl;
+      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(sa) + piece * 1024));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = w * 2 + i, row = piece * 16 + rsub;
+      const int kk = k0 + ((cp ^ ((row >> 2) & 3)) << 3);
+      const bf16_t* src = (n0 + row < N && kk < K) ? Bt + (int64_t)(n0 + row) * ldb + kk : zl;
+      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(sb) + piece * 1024));
+    }
+  };
+
+  f32x16 acc[4][2];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  zero_acc();
+
+  if (nstages > 0) issue(0);
+  if (nstages > 1) issue(1);
+  if (nstages > 2) issue(2);
+  for (int s = 0; s < nstages; ++s) {
+    if (s + 2 < nstages)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (s + 1 < nstages)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + 3 < nstages) issue(s + 3);
+    const unsigned char* sa = smem + (s % NT3_NS) * NT3_STAGE;
+    const unsigned char* sb = sa + NT3_ABYTES;
+#pragma unroll
+    for (int kc = 0; kc < NT3_BK / 16; ++kc) {
+      bf16x8 fa[4], fb[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra = wr * 128 + i * 32 + l31;
+        fa[i] = *(const bf16x8*)(sa + ra * 64 + (((2 * kc + h) ^ ((ra >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rb = wc * 64 + j * 32 + l31;
+        fb[j] = *(const bf16x8*)(sb + rb * 64 + (((2 * kc + h) ^ ((rb >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (CFRAG)
+            dj_mfma(acc[i][j], fa[i], fb[j]);
+          else
+            dj_mfma(acc[i][j], fb[j], fa[i]);      // C^T block: lane <-> output row, registers <-> columns
+        }
+    }
+    const int tl = s / nk, kt = s - tl * nk;
+    if (kt == nk - 1) {       // tile finished: epilogue (the next tiles' DMA is already in flight)
+      int m0, n0;
+      tile_of(tl, m0, n0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int colb = n0 + wc * 64 + j * 32, rowb = m0 + wr * 128 + i * 32;
+          if constexpr (CFRAG) {
+            const int col = colb + l31;
+            if (col < N && rowb < M) {
+              const float bv = bias ? bias[col] : 0.f;
+              float x[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) x[r] = acc[i][j][r] + bv;
+              store_frag(C + (((int64_t)(rowb >> 5) * (N >> 5) + (colb >> 5)) * 64 + lane) * 16, x);
+            }
+          } else {
+            const int row = rowb + l31;
+            if (row < M && colb < N) {
+              TC* crow = C + rbs_row(row, c_rbs) * ldc;
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int col = colb + 8 * g + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  v[e] = acc[i][j][4 * g + e] + ((bias && col + e < N) ? bias[col + e] : 0.f);
+                if (col + 4 <= N) {
+                  store4(crow + col, v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e)
+                    if (col + e < N) crow[col + e] = dj_from_f32<TC>(v[e]);
+                }
+              }
+            }
+          }
+        }
+      zero_acc();
+    }
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ launchers (internal C++ API)
@@ -759,6 +921,44 @@ int dj_launch_gemm_nt_rbs(int dtype, int M, int N, int K, const void* A, int lda
   if ((K % epl) || (lda % epl) || (ldb % epl)) return 1001;
   const int c_is_f32 = c_mode == 1, c_frag = c_mode == 2;
   if (c_frag && ((M % 32) || (N % 32))) return 1004;
+  if (dtype == DJ_BF16 && N > 128) {
+    // wide outputs: 256 x 256 tiles; a remainder of at most 128 columns goes to the 256 x 128 kernel
+    const int rem = N % NT3_BN;
+    if (rem > 0 && rem <= 128 && N > NT3_BN && !c_frag) {
+      const int Nw = N - rem;
+      const size_t cesz = c_is_f32 ? 4 : 2;
+      int rc = dj_launch_gemm_nt_rbs(dtype, M, Nw, K, A, lda, a_rbs, Bt, ldb, C, ldc, c_rbs, c_mode, bias, st);
+      if (rc) return rc;
+      return dj_launch_gemm_nt_rbs(dtype, M, rem, K, A, lda, a_rbs, (const bf16_t*)Bt + (int64_t)Nw * ldb, ldb,
+                                   (char*)C + Nw * cesz, ldc, c_rbs, c_mode, bias ? bias + Nw : nullptr, st);
+    }
+    const int ntn3 = (N + NT3_BN - 1) / NT3_BN, ntm3 = (M + NT3_BM - 1) / NT3_BM;
+    int grid3 = 256;
+    if ((int64_t)ntn3 * ntm3 < 256) grid3 = ((ntn3 * ntm3 + 7) / 8) * 8;   // whole XCD rounds (blockIdx & 7 = XCD)
+    const size_t smem = (size_t)NT3_NS * NT3_STAGE;
+    static bool attr3_done = false;
+    if (!attr3_done) {
+      const void* fns[3] = {(const void*)gemm_nt_bf16_wide_kernel<bf16_t, false>,
+                            (const void*)gemm_nt_bf16_wide_kernel<float, false>,
+                            (const void*)gemm_nt_bf16_wide_kernel<bf16_t, true>};
+      for (const void* fn : fns) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+      }
+      attr3_done = true;
+    }
+    if (ldc % 4) return 1007;
+    if (c_frag)
+      hipLaunchKernelGGL((gemm_nt_bf16_wide_kernel<bf16_t, true>), dim3(grid3), dim3(512), smem, st, M, N, K,
+                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs);
+    else if (c_is_f32)
+      hipLaunchKernelGGL((gemm_nt_bf16_wide_kernel<float, false>), dim3(grid3), dim3(512), smem, st, M, N, K,
+                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs);
+    else
+      hipLaunchKernelGGL((gemm_nt_bf16_wide_kernel<bf16_t, false>), dim3(grid3), dim3(512), smem, st, M, N, K,
+                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs);
+    return (int)hipGetLastError();
+  }
   if (dtype == DJ_BF16) {
     const int ntn2 = (N + NT2_BN - 1) / NT2_BN, ntm2 = (M + NT2_BM - 1) / NT2_BM;
     // persistent grid: one workgroup per CU.  XCD-aware schedule when there is enough work:

@@ -79,7 +79,8 @@ def test_dropout_mask_matches_oracle(gpu_device):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (96, 94, 96), (768, 1024, 96), (160, 259, 512), (1024, 512, 264)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (96, 94, 96), (768, 1024, 96), (160, 259, 512), (1024, 512, 264),
+                                   (4100, 264, 512), (300, 200, 1024), (2304, 640, 40), (70000, 256, 96)])
 def test_gemm_nt(gpu_device, dtype, M, N, K):
     L, lib = _lib()
     g = torch.Generator().manual_seed(M * 7 + N)
