@@ -625,12 +625,22 @@ __device__ uint4 dj_zero_line[4];     // 64 zero bytes: DMA source for out-of-ra
 constexpr int NT2_BM = 256, NT2_BN = 128, NT2_BK = 64, NT2_NS = 3;
 constexpr int NT2_ABYTES = NT2_BM * NT2_BK * 2, NT2_BBYTES = NT2_BN * NT2_BK * 2, NT2_STAGE = NT2_ABYTES + NT2_BBYTES;
 
-template <typename TC>
+// Row-major output (CFRAG = false) multiplies with the operands swapped, so a lane's accumulator
+// block holds C^T: 4 consecutive output columns of ONE row per register quad, stored as one 8-byte
+// (bf16) / 16-byte (f32) vector instead of four scalar stores.
+__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
+  *(uint2*)p = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+}
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+  *(float4*)p = make_float4(a, b, c, d);
+}
+
+template <typename TC, bool CFRAG>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int K, const bf16_t* __restrict__ A,
                                                                int lda, const bf16_t* __restrict__ Bt, int ldb,
                                                                TC* __restrict__ C, int ldc,
                                                                const float* __restrict__ bias, int ntn, int ntm,
-                                                               int c_frag, int xcd_map, int a_rbs, int c_rbs) {
+                                                               int xcd_map, int a_rbs, int c_rbs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
@@ -710,7 +720,12 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) dj_mfma(acc[i][j], fa[i], fb[j]);
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (CFRAG)
+            dj_mfma(acc[i][j], fa[i], fb[j]);
+          else
+            dj_mfma(acc[i][j], fb[j], fa[i]);      // C^T block: lane <-> output row, registers <-> columns
+        }
     }
     const int tl = s / nk, kt = s - tl * nk;
     if (kt == nk - 1) {       // tile finished: epilogue (the next tiles' DMA is already in flight)
@@ -719,21 +734,34 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int col = n0 + wc * 64 + j * 32 + l31;
-          const int rowb = m0 + wr * 64 + i * 32;
-          if (col < N && rowb < M) {
-            const float bv = bias ? bias[col] : 0.f;
-            if (c_frag) {
+          const int colb = n0 + wc * 64 + j * 32, rowb = m0 + wr * 64 + i * 32;
+          if constexpr (CFRAG) {
+            const int col = colb + l31;
+            if (col < N && rowb < M) {
+              const float bv = bias ? bias[col] : 0.f;
               float x[16];
 #pragma unroll
               for (int r = 0; r < 16; ++r) x[r] = acc[i][j][r] + bv;
-              const int64_t rb = rowb >> 5, cb = (n0 + wc * 64 + j * 32) >> 5;
-              store_frag(C + ((rb * (N >> 5) + cb) * 64 + lane) * 16, x);
-            } else {
+              store_frag(C + (((int64_t)(rowb >> 5) * (N >> 5) + (colb >> 5)) * 64 + lane) * 16, x);
+            }
+          } else {
+            const int row = rowb + l31;
+            if (row < M && colb < N) {
+              TC* crow = C + rbs_row(row, c_rbs) * ldc;
 #pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const int row = rowb + dj_crow(r, lane);
-                if (row < M) C[rbs_row(row, c_rbs) * ldc + col] = dj_from_f32<TC>(acc[i][j][r] + bv);
+              for (int g = 0; g < 4; ++g) {
+                const int col = colb + 8 * g + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  v[e] = acc[i][j][4 * g + e] + ((bias && col + e < N) ? bias[col + e] : 0.f);
+                if (col + 4 <= N) {
+                  store4(crow + col, v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e)
+                    if (col + e < N) crow[col + e] = dj_from_f32<TC>(v[e]);
+                }
               }
             }
           }
@@ -755,15 +783,6 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
 constexpr int NT3_BM = 256, NT3_BN = 256, NT3_BK = 32, NT3_NS = 4;
 constexpr int NT3_ABYTES = NT3_BM * NT3_BK * 2, NT3_BBYTES = NT3_BN * NT3_BK * 2, NT3_STAGE = NT3_ABYTES + NT3_BBYTES;
 
-// Row-major output (CFRAG = false) multiplies with the operands swapped, so a lane's accumulator
-// block holds C^T: 4 consecutive output columns of ONE row per register quad, stored as one 8-byte
-// (bf16) / 16-byte (f32) vector -- 32 stores per lane and tile instead of 128 scalar ones.
-__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
-  *(uint2*)p = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
-}
-__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
-  *(float4*)p = make_float4(a, b, c, d);
-}
 
 template <typename TC, bool CFRAG>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, int K, const bf16_t* __restrict__ A,
@@ -976,21 +995,28 @@ int dj_launch_gemm_nt_rbs(int dtype, int M, int N, int K, const void* A, int lda
     const size_t smem = (size_t)NT2_NS * NT2_STAGE;
     static bool attr_done = false;
     if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_dma_kernel<bf16_t>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)gemm_nt_bf16_dma_kernel<float>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-      if (e != hipSuccess) return (int)e;
+      const void* fns[3] = {(const void*)gemm_nt_bf16_dma_kernel<bf16_t, false>,
+                            (const void*)gemm_nt_bf16_dma_kernel<float, false>,
+                            (const void*)gemm_nt_bf16_dma_kernel<bf16_t, true>};
+      for (const void* fn : fns) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+      }
       attr_done = true;
     }
-    if (c_is_f32)
-      hipLaunchKernelGGL(gemm_nt_bf16_dma_kernel<float>, dim3(grid2), dim3(512), smem, st, M, N, K, (const bf16_t*)A,
-                         lda, (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn2, ntm2, c_frag, xcd_map, a_rbs, c_rbs);
+    if (ldc % 4) return 1007;
+    if (c_frag)
+      hipLaunchKernelGGL((gemm_nt_bf16_dma_kernel<bf16_t, true>), dim3(grid2), dim3(512), smem, st, M, N, K,
+                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn2, ntm2, xcd_map,
+                         a_rbs, c_rbs);
+    else if (c_is_f32)
+      hipLaunchKernelGGL((gemm_nt_bf16_dma_kernel<float, false>), dim3(grid2), dim3(512), smem, st, M, N, K,
+                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn2, ntm2, xcd_map,
+                         a_rbs, c_rbs);
     else
-      hipLaunchKernelGGL(gemm_nt_bf16_dma_kernel<bf16_t>, dim3(grid2), dim3(512), smem, st, M, N, K,
-                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn2, ntm2, c_frag,
-                         xcd_map, a_rbs, c_rbs);
+      hipLaunchKernelGGL((gemm_nt_bf16_dma_kernel<bf16_t, false>), dim3(grid2), dim3(512), smem, st, M, N, K,
+                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn2, ntm2, xcd_map,
+                         a_rbs, c_rbs);
     return (int)hipGetLastError();
   }
   // fp32 (parity mode): register-staged 128 x 128 kernel on v_mfma_f32_32x32x2_f32
