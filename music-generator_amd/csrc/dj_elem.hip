@@ -51,8 +51,9 @@ __global__ __launch_bounds__(256) void dense_small_bwd_x_kernel(const float* __r
                                                                 float* __restrict__ dA, int accumulate) {
   extern __shared__ float sm[];
   const int NC = N < DSBX_NC ? N : DSBX_NC;
-  float* wt = sm;               // [NC][K]
-  float* dc = sm + NC * K;      // [8][NC]
+  const int KP = K + 1;         // padded row: the transposing store and the k-parallel read are conflict-free
+  float* wt = sm;               // [NC][KP]
+  float* dc = sm + NC * KP;     // [8][NC]
   const int tid = threadIdx.x, m0 = blockIdx.x * 8;
   const int k = tid % 64, rp = tid / 64;   // rows 2*rp, 2*rp+1
   float s0 = 0.f, s1 = 0.f;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void dense_small_bwd_x_kernel(const float* __r
     if (n0) __syncthreads();
     for (int i = tid; i < nc * K; i += 256) {
       int kk = i / nc, n = i % nc;   // coalesced read of W[kk][n0 + n]
-      wt[n * K + kk] = W[(int64_t)kk * N + n0 + n];
+      wt[n * KP + kk] = W[(int64_t)kk * N + n0 + n];
     }
     for (int i = tid; i < 8 * nc; i += 256) {
       int r = i / nc, n = i % nc;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void dense_small_bwd_x_kernel(const float* __r
     __syncthreads();
     if (k < K) {
       for (int n = 0; n < nc; ++n) {
-        float w = wt[n * K + k];
+        float w = wt[n * KP + k];
         s0 += dc[(2 * rp) * NC + n] * w;
         s1 += dc[(2 * rp + 1) * NC + n] * w;
       }
@@ -711,7 +712,7 @@ int dj_launch_dense_small_bwd_x(const float* dC, int M, int N, const float* W, i
                                 hipStream_t st) {
   if (K > 64) return 1020;
   const int NC = N < DSBX_NC ? N : DSBX_NC;
-  const size_t smb = ((size_t)NC * K + 8 * (size_t)NC) * sizeof(float);
+  const size_t smb = ((size_t)NC * (K + 1) + 8 * (size_t)NC) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)dense_small_bwd_x_kernel,
