@@ -6,6 +6,7 @@
 // Model.predict (generate.py:108,114).
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -52,6 +53,7 @@ struct LstmP {          // parameter offsets (floats) of one LSTM layer + its st
   int64_t dW, db;       // style Dense kernel [SU, D], bias [D]
   int64_t W, U, b;      // LSTM kernel [D,4H], recurrent_kernel [H,4H], bias [4H]
   int D, DP, H;
+  int64_t tiles;        // sequence tiles of this layer's axis (32 sequences each)
 };
 
 struct Plan {
@@ -108,13 +110,13 @@ int make_plan(const dj_config* cfg, Plan& p) {
   p.p_conv_W = take(24 * 3 * 64); p.p_conv_b = take(64);
   for (int l = 0; l < p.Lt; ++l) {
     LstmP& L = p.tl[l];
-    L.D = l == 0 ? p.F : p.Ht; L.DP = (int)up8(L.D); L.H = p.Ht;
+    L.D = l == 0 ? p.F : p.Ht; L.DP = (int)up8(L.D); L.H = p.Ht; L.tiles = p.tilesT;
     L.dW = take((int64_t)p.SU * L.D); L.db = take(L.D);
     L.W = take((int64_t)L.D * 4 * L.H); L.U = take((int64_t)L.H * 4 * L.H); L.b = take(4 * L.H);
   }
   for (int l = 0; l < p.Ln; ++l) {
     LstmP& L = p.nl[l];
-    L.D = l == 0 ? p.Ht + 3 : p.Hn; L.DP = (int)up8(L.D); L.H = p.Hn;
+    L.D = l == 0 ? p.Ht + 3 : p.Hn; L.DP = (int)up8(L.D); L.H = p.Hn; L.tiles = p.tilesN;
     L.dW = take((int64_t)p.SU * L.D); L.db = take(L.D);
     L.W = take((int64_t)L.D * 4 * L.H); L.U = take((int64_t)L.H * 4 * L.H); L.b = take(4 * L.H);
   }
@@ -190,8 +192,15 @@ struct Ctx {
 
 // Fuse x*W into the recurrent kernel when its extra L2 weight stream (D x 4H) is no larger than
 // twice the recurrent one (H x 4H); wider inputs (note layer 0: D = 259 vs H = 128) are cheaper as
-// a separate GEMM (measured: fused +1.25 ms on the note axis vs 1.24 ms of GEMMs saved).
-inline bool fuse_xw(const LstmP& L) { return rec_persistent(L.H) && L.D <= 2 * L.H; }
+// a separate GEMM (measured: fused +1.25 ms on the note axis vs 1.24 ms of GEMMs saved).  With few
+// sequence tiles (generation: 5) the chip is idle anyway and the recurrence is a pure latency chain:
+// there the projection stays a separate (parallel) GEMM and the chain carries h*U only.
+// DEEPJ_FUSE_XW_MIN_TILES overrides the tile threshold (tests run the fused kernel on small shapes with it).
+inline bool fuse_xw(const LstmP& L) {
+  const char* e = getenv("DEEPJ_FUSE_XW_MIN_TILES");
+  const int64_t min_tiles = e ? atoll(e) : 128;
+  return rec_persistent(L.H) && L.D <= 2 * L.H && L.tiles >= min_tiles;
+}
 
 // weight conversion/packing for one LSTM layer
 int prep_layer(const Ctx& c, const LstmP& L, int64_t wWt, int64_t wWc, int64_t wUf, int64_t wUb, bool need_bwd) {

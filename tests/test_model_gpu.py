@@ -62,8 +62,17 @@ CASES = [
 ]
 
 
+@pytest.fixture(params=["default", "fused_xw"])
+def xw_mode(request, monkeypatch):
+    """The library fuses x*W into the recurrent kernel only from 128 sequence tiles up (the BASELINE
+    shape); DEEPJ_FUSE_XW_MIN_TILES=1 makes the small parity shapes take that kernel too."""
+    if request.param == "fused_xw":
+        monkeypatch.setenv("DEEPJ_FUSE_XW_MIN_TILES", "1")
+    return request.param
+
+
 @pytest.mark.parametrize("name,kw,B,T,pin,pdr", CASES, ids=[c[0] for c in CASES])
-def test_train_step_fp32_parity(gpu_device, name, kw, B, T, pin, pdr):
+def test_train_step_fp32_parity(gpu_device, xw_mode, name, kw, B, T, pin, pdr):
     ocfg, dcfg = _cfgs(time_steps=T, **kw)
     params = O.init_params(ocfg, seed=11)
     # perturb biases so that every bias gradient path is exercised with non-trivial values
@@ -86,7 +95,7 @@ def test_train_step_fp32_parity(gpu_device, name, kw, B, T, pin, pdr):
 
 @pytest.mark.parametrize("kw", [dict(), dict(time_axis_units=512, note_axis_units=512, num_notes=24)],
                          ids=["ref_dims", "step_path_512"])
-def test_train_step_bf16_close(gpu_device, kw):
+def test_train_step_bf16_close(gpu_device, xw_mode, kw):
     T, B = 8, 2
     ocfg, dcfg = _cfgs(time_steps=T, dtype="bf16", **kw)
     params = O.init_params(ocfg, seed=11)
