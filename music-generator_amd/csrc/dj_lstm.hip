@@ -295,26 +295,31 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
   // X tile staging: NVX 16-byte vectors per tile, up to NVMAX per thread
   constexpr int NVMAX = (32 * FUSED_DPMAX / R::EPL + R::NT - 1) / R::NT;
   const int vpr = DP / R::EPL, nvx = 32 * vpr;
-  uint4 xr[NVMAX];
+  // The staged vectors travel by value (struct return / argument): as a loop-carried array written
+  // through a by-reference lambda they were kept in scratch memory, and the scratch store right
+  // behind the prefetch made every step wait for its HBM loads.
+  struct XRegs { uint4 v[NVMAX]; };
   auto x_load = [&](int64_t rb) {
+    XRegs r;
 #pragma unroll
     for (int i = 0; i < NVMAX; ++i) {
       const int v = tid + i * R::NT;
-      if (v < nvx) xr[i] = *(const uint4*)(X + (rb * 32 + v / vpr) * DP + (v % vpr) * R::EPL);
+      r.v[i] = v < nvx ? *(const uint4*)(X + (rb * 32 + v / vpr) * DP + (v % vpr) * R::EPL) : make_uint4(0, 0, 0, 0);
     }
+    return r;
   };
-  auto x_store = [&](T* xs) {
+  auto x_store = [&](T* xs, const XRegs r) {
 #pragma unroll
     for (int i = 0; i < NVMAX; ++i) {
       const int v = tid + i * R::NT;
-      if (v < nvx) *(uint4*)(xs + (v / vpr) * LDX + (v % vpr) * R::EPL) = xr[i];
+      if (v < nvx) *(uint4*)(xs + (v / vpr) * LDX + (v % vpr) * R::EPL) = r.v[i];
     }
   };
   // zero both X buffers once (k-tail columns DP..NKX*KC stay zero), then stage X[0]
   for (int i = tid; i < 2 * 32 * LDX * (int)sizeof(T) / 16; i += R::NT) ((uint4*)xs0)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
-  x_load(tile * steps);
-  x_store(xs0);
+  XRegs xr = x_load(tile * steps);
+  x_store(xs0, xr);
   lds_barrier();
 
   int cur = 0;
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
       }
     }
     // next X tile: issued after the weight streams of this step (in-order vmcnt), lands under the gate math
-    if (t + 1 < steps) x_load(rb + 1);
+    xr = x_load(t + 1 < steps ? rb + 1 : rb);
     T* hn = hs0 + (cur ^ 1) * 32 * R::LDH;
     const int u = w * R::UW + l31;
     float cv[16];
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
         store_frag(zaddr(rb, g), zv);
       }
     }
-    if (t + 1 < steps) x_store(xs0 + ((t + 1) & 1) * 32 * LDX);
+    if (t + 1 < steps) x_store(xs0 + ((t + 1) & 1) * 32 * LDX, xr);
     lds_barrier();
     constexpr int VPR = H / R::EPL;
 #pragma unroll
@@ -420,28 +425,42 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
   };
   auto caddr = [&](int64_t rb, int j) { return C + ((rb * R::NCBH + (w * R::UW + j * 32) / 32) * 64 + lane) * 16; };
 
-  // dH tile (32 x H, row-major): each thread stages NV 16-byte vectors
+  // dH tile (32 x H, row-major): each thread stages NV (2 or 4) 16-byte vectors.  They are named
+  // scalars on purpose: as a loop-carried array written through a lambda they were kept in scratch
+  // memory, and the scratch store right behind the prefetch made every step wait for its HBM loads.
   constexpr int VPR = H / R::EPL, NV = 32 * VPR / R::NT;
-  uint4 dhreg[NV];
-  auto dh_load = [&](int64_t rb) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      int v = tid + R::NT * i, row = v / VPR, cv = (v % VPR) * R::EPL;
-      dhreg[i] = *(const uint4*)(dH + (rb * 32 + row) * H + cv);
-    }
+  static_assert(NV == 2 || NV == 4, "dH staging assumes 2 or 4 vectors per thread");
+  uint4 dh0, dh1, dh2 = make_uint4(0, 0, 0, 0), dh3 = make_uint4(0, 0, 0, 0);
+  auto dh_ld = [&](int64_t rb, int i) {
+    const int v = tid + R::NT * i, row = v / VPR, cv = (v % VPR) * R::EPL;
+    return *(const uint4*)(dH + (rb * 32 + row) * H + cv);
   };
+  auto dh_st = [&](int i, uint4 val) {
+    const int v = tid + R::NT * i, row = v / VPR, cv = (v % VPR) * R::EPL;
+    *(uint4*)(dzs + row * R::LDH + cv) = val;
+  };
+#define DJ_DH_LOAD(rbv)          \
+  do {                           \
+    dh0 = dh_ld((rbv), 0);       \
+    dh1 = dh_ld((rbv), 1);       \
+    if constexpr (NV == 4) {     \
+      dh2 = dh_ld((rbv), 2);     \
+      dh3 = dh_ld((rbv), 3);     \
+    }                            \
+  } while (0)
   Frag16<T> cnext[R::NJ];   // c_t of the step being processed (loaded as c_{t-1} one step earlier)
-  dh_load(tile * steps + steps - 1);
+  DJ_DH_LOAD(tile * steps + steps - 1);
 #pragma unroll
   for (int j = 0; j < R::NJ; ++j) cnext[j].load(caddr(tile * steps + steps - 1, j));
 
   for (int t = steps - 1; t >= 0; --t) {
     const int64_t rb = tile * steps + t;
     // stage dH_t into LDS, then pick it up in accumulator layout
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      int v = tid + R::NT * i, row = v / VPR, cv = (v % VPR) * R::EPL;
-      *(uint4*)(dzs + row * R::LDH + cv) = dhreg[i];
+    dh_st(0, dh0);
+    dh_st(1, dh1);
+    if constexpr (NV == 4) {
+      dh_st(2, dh2);
+      dh_st(3, dh3);
     }
     Frag16<T> zf[4][R::NJ], cprev[R::NJ];
 #pragma unroll
@@ -452,7 +471,7 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
       }
       if (t > 0) cprev[j].load(caddr(rb - 1, j));
     }
-    if (t > 0) dh_load(rb - 1);
+    if (t > 0) DJ_DH_LOAD(rb - 1);
     lds_barrier();
     float dhv[R::NJ][16];
 #pragma unroll
@@ -542,6 +561,8 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
       }
   }
 }
+
+#undef DJ_DH_LOAD
 
 template <typename T, int H> int launch_pack(const float* U, void* fwd, void* bwd, hipStream_t st) {
   int n = H * 4 * H;
