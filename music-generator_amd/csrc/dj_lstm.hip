@@ -25,6 +25,13 @@
 //    glue kernels) and go through LDS for wide coalesced rows.
 #include "dj_kernels.h"
 
+#ifdef DJ_EXP_STAMP
+__device__ unsigned long long dj_stamps[2][8][1024];   // [kernel fwd/bwd][phase][step]
+#define DJ_STAMP(K, P, T) do { if (blockIdx.x == 17 && threadIdx.x == 0) dj_stamps[K][P][T] = __builtin_readcyclecounter(); } while (0)
+extern "C" int dj_debug_stamps(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dj_stamps), sizeof(dj_stamps)); }
+#else
+#define DJ_STAMP(K, P, T)
+#endif
 namespace {
 
 template <typename T, int H> struct RecCfg {
@@ -326,6 +333,7 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
   for (int t = 0; t < steps; ++t) {
     const int64_t rb = tile * steps + t;
     const T* xs = xs0 + (t & 1) * 32 * LDX;
+    DJ_STAMP(0, 0, t);
     f32x16 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -357,6 +365,7 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
         }
       }
     }
+    DJ_STAMP(0, 1, t);
     // next X tile: issued after the weight streams of this step (in-order vmcnt), lands under the gate math
     xr = x_load(t + 1 < steps ? rb + 1 : rb);
     T* hn = hs0 + (cur ^ 1) * 32 * R::LDH;
@@ -371,6 +380,7 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
       cv[r] = cn;
       hn[dj_crow(r, lane) * R::LDH + u] = dj_from_f32<T>(og * dj_tanh(cn));
     }
+    DJ_STAMP(0, 2, t);
     if (Cout) store_frag(caddr(rb), cv);
     if (Zst) {
 #pragma unroll
@@ -381,14 +391,18 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
         store_frag(zaddr(rb, g), zv);
       }
     }
+    DJ_STAMP(0, 3, t);
     if (t + 1 < steps) x_store(xs0 + ((t + 1) & 1) * 32 * LDX, xr);
+    DJ_STAMP(0, 4, t);
     lds_barrier();
+    DJ_STAMP(0, 5, t);
     constexpr int VPR = H / R::EPL;
 #pragma unroll
     for (int v = tid; v < 32 * VPR; v += R::NT) {
       int row = v / VPR, cvv = (v % VPR) * R::EPL;
       *(uint4*)(Hout + (rb * 32 + row) * H + cvv) = *(const uint4*)(hn + row * R::LDH + cvv);
     }
+    DJ_STAMP(0, 6, t);
     cur ^= 1;
   }
 }
@@ -455,6 +469,7 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
 
   for (int t = steps - 1; t >= 0; --t) {
     const int64_t rb = tile * steps + t;
+    DJ_STAMP(1, 0, t);
     // stage dH_t into LDS, then pick it up in accumulator layout
     dh_st(0, dh0);
     dh_st(1, dh1);
@@ -472,7 +487,9 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
       if (t > 0) cprev[j].load(caddr(rb - 1, j));
     }
     if (t > 0) DJ_DH_LOAD(rb - 1);
+    DJ_STAMP(1, 1, t);
     lds_barrier();
+    DJ_STAMP(1, 2, t);
     float dhv[R::NJ][16];
 #pragma unroll
     for (int j = 0; j < R::NJ; ++j)
@@ -480,6 +497,7 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
       for (int r = 0; r < 16; ++r)
         dhv[j][r] = dj_to_f32(dzs[dj_crow(r, lane) * R::LDH + w * R::UW + j * 32 + l31]) + acc[j][r];
     lds_barrier();
+    DJ_STAMP(1, 3, t);
 #pragma unroll
     for (int j = 0; j < R::NJ; ++j) {
       const int u = w * R::UW + j * 32 + l31;
@@ -514,7 +532,9 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
       }
       if (t > 0) cnext[j].copy_from(cprev[j]);
     }
+    DJ_STAMP(1, 4, t);
     lds_barrier();
+    DJ_STAMP(1, 5, t);
     // dz_t tile -> global row-major, coalesced
     constexpr int VPRZ = 4 * H / R::EPL;
 #pragma unroll 4
@@ -522,6 +542,7 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
       int row = v / VPRZ, cv = (v % VPRZ) * R::EPL;
       *(uint4*)(dZ + (rb * 32 + row) * (4 * H) + cv) = *(const uint4*)(dzs + row * R::LDZ + cv);
     }
+    DJ_STAMP(1, 6, t);
     if (t > 0) {
       // dh_{t-1} (recurrent part) = dz_t [32 x 4H] * U^T [4H x H]; this wave's H/4 output units
 #pragma unroll
@@ -548,6 +569,7 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
         }
       }
     }
+    DJ_STAMP(1, 7, t);
     lds_barrier();
   }
   if (dbias) {
