@@ -449,9 +449,13 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
     const int v = tid + R::NT * i, row = v / VPR, cv = (v % VPR) * R::EPL;
     return *(const uint4*)(dH + (rb * 32 + row) * H + cv);
   };
+  // bf16: the dH staging tile has its own LDS region, which saves two of the four barriers per step;
+  // f32 (LDS budget) aliases it on the first rows of dzs
+  constexpr bool SPLIT = R::HOIST;
+  T* dhs = SPLIT ? dzs + 32 * R::LDZ : dzs;
   auto dh_st = [&](int i, uint4 val) {
     const int v = tid + R::NT * i, row = v / VPR, cv = (v % VPR) * R::EPL;
-    *(uint4*)(dzs + row * R::LDH + cv) = val;
+    *(uint4*)(dhs + row * R::LDH + cv) = val;
   };
 #define DJ_DH_LOAD(rbv)          \
   do {                           \
@@ -495,8 +499,8 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
     for (int j = 0; j < R::NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        dhv[j][r] = dj_to_f32(dzs[dj_crow(r, lane) * R::LDH + w * R::UW + j * 32 + l31]) + acc[j][r];
-    lds_barrier();
+        dhv[j][r] = dj_to_f32(dhs[dj_crow(r, lane) * R::LDH + w * R::UW + j * 32 + l31]) + acc[j][r];
+    if constexpr (!SPLIT) lds_barrier();
     DJ_STAMP(1, 3, t);
 #pragma unroll
     for (int j = 0; j < R::NJ; ++j) {
@@ -570,7 +574,8 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
       }
     }
     DJ_STAMP(1, 7, t);
-    lds_barrier();
+    // (SPLIT) the next step's first barrier already orders this step's dzs reads before its gate writes
+    if constexpr (!SPLIT) lds_barrier();
   }
   if (dbias) {
 #pragma unroll
@@ -608,7 +613,7 @@ template <typename T, int H>
 int launch_bwd(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
                float* dbias, int sigm, hipStream_t st) {
   using R = RecCfg<T, H>;
-  size_t smem = (size_t)32 * R::LDZ * sizeof(T);
+  size_t smem = (size_t)32 * (R::LDZ + (R::HOIST ? R::LDH : 0)) * sizeof(T);
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_kernel<T, H, false>,
