@@ -132,7 +132,7 @@ int make_plan(const dj_config* cfg, Plan& p) {
   for (int l = 0; l < p.Lt; ++l) {
     const LstmP& L = p.tl[l];
     p.w_sp_t[l] = wtake(p.BT * L.D * 4); p.w_dpre_t[l] = wtake(p.BT * L.D * 4);
-    p.w_Wt_t[l] = wtake((int64_t)4 * L.H * (L.DP + 64) * p.esz); p.w_Wc_t[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
+    p.w_Wt_t[l] = wtake((int64_t)4 * L.H * (L.DP + 128) * p.esz); p.w_Wc_t[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
     p.w_Uf_t[l] = wtake((int64_t)L.H * 4 * L.H * p.esz); p.w_Ub_t[l] = wtake((int64_t)L.H * 4 * L.H * p.esz);
     p.w_X_t[l] = wtake(p.Mt * L.DP * p.esz); p.w_Z_t[l] = wtake(p.Mt * 4 * L.H * p.esz);
     p.w_H_t[l] = wtake(p.Mt * L.H * p.esz); p.w_C_t[l] = wtake(p.Mt * L.H * p.esz);
@@ -141,7 +141,7 @@ int make_plan(const dj_config* cfg, Plan& p) {
   for (int l = 0; l < p.Ln; ++l) {
     const LstmP& L = p.nl[l];
     p.w_sp_n[l] = wtake(p.BT * L.D * 4); p.w_dpre_n[l] = wtake(p.BT * L.D * 4);
-    p.w_Wt_n[l] = wtake((int64_t)4 * L.H * (L.DP + 64) * p.esz); p.w_Wc_n[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
+    p.w_Wt_n[l] = wtake((int64_t)4 * L.H * (L.DP + 128) * p.esz); p.w_Wc_n[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
     p.w_Uf_n[l] = wtake((int64_t)L.H * 4 * L.H * p.esz); p.w_Ub_n[l] = wtake((int64_t)L.H * 4 * L.H * p.esz);
     p.w_X_n[l] = wtake(p.Mn * L.DP * p.esz); p.w_Z_n[l] = wtake(p.Mn * 4 * L.H * p.esz);
     p.w_H_n[l] = wtake(p.Mn * L.H * p.esz); p.w_C_n[l] = wtake(p.Mn * L.H * p.esz);
@@ -207,7 +207,7 @@ int prep_layer(const Ctx& c, const LstmP& L, int64_t wWt, int64_t wWc, int64_t w
   const int dt = c.p.c.dtype;
   ProfScope ps(PC_PREP, c.st);
   if (fuse_xw(L))   // input kernel W as MFMA B fragments for the fused x*W inside the recurrent kernel
-    RUN(dj_launch_lstm_pack_w(dt, L.H, c.P + L.W, L.D, dj_lstm_fused_nkx(dt, L.D), c.at(wWt), c.st));
+    RUN(dj_launch_lstm_pack_w(dt, L.H, c.P + L.W, L.D, dj_lstm_fused_nkx(dt, L.H, L.D), c.at(wWt), c.st));
   else              // k-contiguous Bt operand of the separate x*W GEMM
     RUN(dj_launch_cvt_transpose(dt, c.P + L.W, L.D, 4 * L.H, c.at(wWt), L.DP, c.st));
   if (rec_persistent(L.H)) {
@@ -239,7 +239,7 @@ int lstm_layer_fwd(const Ctx& c, const LstmP& L, int64_t tiles, int steps, int64
   if (fuse_xw(L)) {
     // z = x W + h U + b in one persistent kernel (Z receives the pre-activation stash when training)
     ProfScope ps(is_note ? PC_LSTM_FWD_NOTE : PC_LSTM_FWD_TIME, c.st);
-    RUN(dj_launch_lstm_fwd_fused(dt, L.H, (int)tiles, steps, c.at(wX), L.DP, dj_lstm_fused_nkx(dt, L.D), c.at(wWt),
+    RUN(dj_launch_lstm_fwd_fused(dt, L.H, (int)tiles, steps, c.at(wX), L.DP, dj_lstm_fused_nkx(dt, L.H, L.D), c.at(wWt),
                                  c.P + L.b, c.train ? c.at(wZ) : nullptr, c.at(wUf), c.at(wH),
                                  c.train ? c.at(wC) : nullptr, c.p.c.recurrent_sigmoid, c.st));
     return 0;
@@ -660,13 +660,13 @@ int32_t dj_generate_step_resident(const dj_config* cfg, const float* params, voi
 }
 
 int32_t dj_lstm_pack_w(int32_t dtype, int32_t H, const float* W, int32_t D, void* wpack, void* stream) {
-  return dj_launch_lstm_pack_w(dtype, H, W, D, dj_lstm_fused_nkx(dtype, D), wpack, (hipStream_t)stream);
+  return dj_launch_lstm_pack_w(dtype, H, W, D, dj_lstm_fused_nkx(dtype, H, D), wpack, (hipStream_t)stream);
 }
 int32_t dj_lstm_fwd_fused(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* X, int32_t DP,
                           int32_t D, const void* wpack, const float* bias, void* Zstash, const void* upack_fwd,
                           void* Hout, void* Cout, int32_t sigm, void* stream) {
   if (D > DP) return 1232;
-  return dj_launch_lstm_fwd_fused(dtype, H, ntiles, steps, X, DP, dj_lstm_fused_nkx(dtype, D), wpack, bias, Zstash,
+  return dj_launch_lstm_fwd_fused(dtype, H, ntiles, steps, X, DP, dj_lstm_fused_nkx(dtype, H, D), wpack, bias, Zstash,
                                   upack_fwd, Hout, Cout, sigm, (hipStream_t)stream);
 }
 

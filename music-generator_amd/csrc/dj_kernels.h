@@ -65,7 +65,7 @@ int dj_launch_lstm_fwd(int dtype, int H, int ntiles, int steps, void* Z, const v
                        int sigm, int store_z, hipStream_t st);
 int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* UTpack, const void* C,
                        const void* dH, void* dZ, float* dbias, int sigm, hipStream_t st);
-int dj_lstm_fused_nkx(int dtype, int D);
+int dj_lstm_fused_nkx(int dtype, int H, int D);
 int dj_launch_lstm_pack_w(int dtype, int H, const float* W, int D, int NKX, void* out, hipStream_t st);
 int dj_launch_lstm_fwd_fused(int dtype, int H, int ntiles, int steps, const void* X, int DP, int NKX,
                              const void* Wpack, const float* bias, void* Zst, const void* Upack, void* Hout,

@@ -27,7 +27,10 @@
 
 #ifdef DJ_EXP_STAMP
 __device__ unsigned long long dj_stamps[2][8][1024];   // [kernel fwd/bwd][phase][step]
-#define DJ_STAMP(K, P, T) do { if (blockIdx.x == 17 && threadIdx.x == 0) dj_stamps[K][P][T] = __builtin_readcyclecounter(); } while (0)
+#ifndef DJ_EXP_STAMP_H
+#define DJ_EXP_STAMP_H 256
+#endif
+#define DJ_STAMP(K, P, T) do { if (H == DJ_EXP_STAMP_H && blockIdx.x == 17 && threadIdx.x == 0) dj_stamps[K][P][T] = __builtin_readcyclecounter(); } while (0)
 extern "C" int dj_debug_stamps(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dj_stamps), sizeof(dj_stamps)); }
 #else
 #define DJ_STAMP(K, P, T)
@@ -48,12 +51,27 @@ template <typename T, int H> struct RecCfg {
   static constexpr int NCB = 4 * H / 32;  // 32-col blocks of Z
   static constexpr int NCBH = H / 32;     // 32-col blocks of C
   static constexpr int VPT = 16 / EPL;    // 16-byte vectors per 16-register fragment (bf16: 2, f32: 4)
-  static constexpr int PD = sizeof(T) == 2 ? 4 : 2;   // U prefetch depth in k-chunks
-  static constexpr int UNR = 4;           // k-chunks per unrolled body (multiple of PD)
+#ifndef DJ_EXP_PD128
+#define DJ_EXP_PD128 4
+#endif
+  // weight-fragment prefetch depth in k-chunks (H = 128 runs one wave per SIMD: registers to spare)
+  static constexpr int PD = sizeof(T) == 2 ? (H == 128 ? DJ_EXP_PD128 : 4) : 2;
+  static constexpr int UNR = PD > 4 ? PD : 4;   // k-chunks per unrolled body (multiple of PD)
   // BPTT product: one MFMA per k-chunk and wave, so the ring must be deeper to cover L2 latency
   // (measured: PD 2 left the 64-iteration loop latency-bound at 9.3 us/step)
-  static constexpr int PDB = sizeof(T) == 2 ? 8 : 4, UNRB = 8;
+#ifndef DJ_EXP_PDB128
+#define DJ_EXP_PDB128 8
+#endif
+  static constexpr int PDB = sizeof(T) == 2 ? (H == 128 ? DJ_EXP_PDB128 : 8) : 4;
+  static constexpr int UNRB = PDB > 8 ? PDB : 8;
   static constexpr bool HOIST = sizeof(T) == 2;   // prefetch Z fragments a step ahead (register budget)
+#ifndef DJ_EXP_STATB
+#define DJ_EXP_STATB 1
+#endif
+  // H = 128 in bf16: a wave's whole U^T slice (4H x 32 units = 32 KB = 128 registers per lane) stays in
+  // registers for the whole BPTT sweep -- one wave per SIMD has the register file for it -- so the
+  // recurrence streams no weights at all
+  static constexpr bool STATB = sizeof(T) == 2 && H == 128 && DJ_EXP_STATB;
 };
 
 // raw workgroup barrier: waits for this wave's LDS traffic only, so global prefetches
@@ -434,6 +452,12 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
     for (int g = 0; g < 4; ++g) dbs[g][j] = 0.f;
   }
   const Frag* up = (const Frag*)UTpack + (int64_t)w * R::NJ * R::NKCB * 64 + lane;
+  Frag ub[R::STATB ? R::NKCB : 1];
+  if constexpr (R::STATB) {
+    static_assert(R::NJ == 1, "stationary U^T assumes one column tile per wave");
+#pragma unroll
+    for (int kc = 0; kc < R::NKCB; ++kc) ub[kc] = up[kc * 64];
+  }
   auto zaddr = [&](int64_t rb, int g, int j) {
     return Z + ((rb * R::NCB + (g * H + w * R::UW + j * 32) / 32) * 64 + lane) * 16;
   };
@@ -554,6 +578,13 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
       const T* ap = dzs + l31 * R::LDZ;
+      if constexpr (R::STATB) {
+#pragma unroll
+        for (int kc = 0; kc < R::NKCB; ++kc) {
+          Frag a = dj_lds_frag(ap + kc * R::KC, h);
+          dj_mfma(acc[0], a, ub[kc]);
+        }
+      } else {
       Frag bq[R::PDB][R::NJ];
 #pragma unroll
       for (int p = 0; p < R::PDB; ++p)
@@ -571,6 +602,7 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
 #pragma unroll
           for (int j = 0; j < R::NJ; ++j) bq[u % R::PDB][j] = up[(j * R::NKCB + kn) * 64];
         }
+      }
       }
     }
     DJ_STAMP(1, 7, t);
@@ -689,8 +721,9 @@ int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, c
 }
 
 // k-chunks of the fused input projection for a layer input of width D: ceil(D / KC) rounded up to the ring depth
-int dj_lstm_fused_nkx(int dtype, int D) {
-  const int kc = dtype == DJ_F32 ? 8 : 16, pd = dtype == DJ_F32 ? 2 : 4;   // RecCfg::KC / RecCfg::PD
+int dj_lstm_fused_nkx(int dtype, int H, int D) {
+  const int kc = dtype == DJ_F32 ? 8 : 16;                                           // RecCfg::KC
+  const int pd = dtype == DJ_F32 ? 2 : (H == 128 ? RecCfg<bf16_t, 128>::PD : 4);      // RecCfg::PD
   int n = (D + kc - 1) / kc;
   return (n + pd - 1) / pd * pd;
 }

@@ -274,7 +274,7 @@ def test_lstm_fwd_fused_input_projection(gpu_device, dtype, H, S, Ls, D):
     R = xrows.shape[0]
     Xd = _op(xrows, dtype).to(gpu_device)
     esz = 2 if dtype == "bf16" else 4
-    wpack = torch.zeros(4 * H * (DP + 64) * esz, dtype=torch.uint8, device=gpu_device)
+    wpack = torch.zeros(4 * H * (DP + 128) * esz, dtype=torch.uint8, device=gpu_device)
     upf = torch.empty(H * 4 * H * esz, dtype=torch.uint8, device=gpu_device)
     L.check(lib.dj_lstm_pack_w(DT[dtype], H, L.ptr(W.contiguous().to(gpu_device)), D, L.ptr(wpack), _st()), "packw")
     L.check(lib.dj_lstm_pack(DT[dtype], H, L.ptr(U.to(gpu_device)), L.ptr(upf), None, _st()), "pack")
