@@ -143,19 +143,25 @@ constexpr int XCOL_LD = 80;                                        // 72 taps pa
 // x0[b,n,t,:] = concat[pos, class, bins, drop(tanh(conv)), drop(beat)] + drop(tanh-style)  (model.py:56-82)
 // Training additionally stashes Ycol = tanh(conv) [rows,64] and the im2col view Xcol [rows,80]
 // (72 taps in conv-kernel order k*3+c, zero padded) so BPTT gets dWc from an MFMA TN GEMM.
+// One (b,t) at a time per workgroup, notes in chunks of FEAT_NC: the X rows of a chunk are assembled in
+// LDS ([FEAT_NC][FP]) and leave with 16-byte stores; the per-row dropout keys are hashed once per note.
+constexpr int FEAT_NC = 128;
 template <typename T>
 __global__ __launch_bounds__(256) void feature_fwd_kernel(FeatArgs a, T* __restrict__ X, T* __restrict__ Xcol,
                                                           T* __restrict__ Ycol) {
-  extern __shared__ float sm[];
-  const int NQ = ((a.N + 3) / 4 + 3) / 4 * 4;   // notes per thread-group, multiple of 4
-  const int XR = NQ * 4 + CONV_K + 3;           // padded note rows in LDS
-  float* xin = sm;                              // [XR][3]
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  const int XR = (a.N + 3) / 4 * 4 + CONV_K + 3;          // padded note rows of the dropped-out input
+  float* xin = (float*)fsm;                                // [XR][3]
+  uint32_t* rkc = (uint32_t*)(xin + XR * 3);               // [N] conv-dropout row keys
+  uint32_t* rks = rkc + a.N;                               // [N] style-dropout row keys
+  T* xrow = (T*)(fsm + ((size_t)(XR * 3 + 2 * a.N) * 4 + 15) / 16 * 16);   // [FEAT_NC][FP]
   const int tid = threadIdx.x, o = tid & 63, ng = tid >> 6;
   float wreg[CONV_K * CONV_C];
 #pragma unroll
   for (int i = 0; i < CONV_K * CONV_C; ++i) wreg[i] = a.Wc[i * CONV_O + o];
   const float bo = a.bc[o];
   const int conv_col0 = 2 + a.octave;           // 14
+  const int nrest = a.FP - CONV_O, vpr = a.FP / 8;
 
   for (int bt = blockIdx.x; bt < a.B * a.T; bt += gridDim.x) {
     const int b = bt / a.T, t = bt % a.T;
@@ -169,63 +175,85 @@ __global__ __launch_bounds__(256) void feature_fwd_kernel(FeatArgs a, T* __restr
       }
       xin[i] = v;
     }
+    for (int n = tid; n < a.N; n += 256) {
+      const uint32_t r = (uint32_t)bt * a.N + n;
+      rkc[n] = dj_rowkey(a.d_conv, r);
+      rks[n] = dj_rowkey(a.d_style, r);
+    }
     __syncthreads();
-    // octave conv: thread (o, ng) -> notes [ng*NQ, (ng+1)*NQ) in groups of 4
-    for (int nb = ng * NQ; nb < (ng + 1) * NQ && nb < a.N; nb += 4) {
-      float acc[4] = {bo, bo, bo, bo};
+    const float spo = a.sp0[(int64_t)bt * a.F + conv_col0 + o];
+    for (int n0 = 0; n0 < a.N; n0 += FEAT_NC) {
+      const int nc = a.N - n0 < FEAT_NC ? a.N - n0 : FEAT_NC;
+      // octave conv: thread (o, ng) -> notes n0 + [ng*32, ng*32+32) in groups of 4
+      for (int nb = n0 + ng * (FEAT_NC / 4); nb < n0 + (ng + 1) * (FEAT_NC / 4) && nb < n0 + nc; nb += 4) {
+        float acc[4] = {bo, bo, bo, bo};
 #pragma unroll
-      for (int kk = 0; kk < CONV_K + 3; ++kk)
+        for (int kk = 0; kk < CONV_K + 3; ++kk)
 #pragma unroll
-        for (int c = 0; c < CONV_C; ++c) {
-          float xv = xin[(nb + kk) * 3 + c];
+          for (int c = 0; c < CONV_C; ++c) {
+            float xv = xin[(nb + kk) * 3 + c];
 #pragma unroll
-          for (int dn = 0; dn < 4; ++dn) {
-            int k = kk - dn;
-            if (k >= 0 && k < CONV_K) acc[dn] += xv * wreg[k * CONV_C + c];
+            for (int dn = 0; dn < 4; ++dn) {
+              int k = kk - dn;
+              if (k >= 0 && k < CONV_K) acc[dn] += xv * wreg[k * CONV_C + c];
+            }
+          }
+#pragma unroll
+        for (int dn = 0; dn < 4; ++dn) {
+          const int n = nb + dn;
+          if (n < a.N) {
+            const float y = dj_tanh(acc[dn]);
+            const float v = y * dj_keep(a.d_conv, rkc[n], o) + spo * dj_keep(a.d_style, rks[n], conv_col0 + o);
+            xrow[(n - n0) * a.FP + conv_col0 + o] = dj_from_f32<T>(v);
+            if (Ycol) Ycol[dj_row_ta(b, t, n, a.T, a.N) * CONV_O + o] = dj_from_f32<T>(y);
           }
         }
-#pragma unroll
-      for (int dn = 0; dn < 4; ++dn) {
-        int n = nb + dn;
-        if (n < a.N) {
-          uint32_t r = (uint32_t)bt * a.N + n;
-          int col = conv_col0 + o;
-          const float y = dj_tanh(acc[dn]);
-          const int64_t row = dj_row_ta(b, t, n, a.T, a.N);
-          float v = y * dj_keep(a.d_conv, dj_rowkey(a.d_conv, r), o);
-          v += a.sp0[(int64_t)bt * a.F + col] * dj_keep(a.d_style, dj_rowkey(a.d_style, r), col);
-          X[row * a.FP + col] = dj_from_f32<T>(v);
-          if (Ycol) Ycol[row * CONV_O + o] = dj_from_f32<T>(y);
+      }
+      // the remaining columns: [0, 14) and [14+64, FP)
+      for (int i = tid; i < nc * nrest; i += 256) {
+        const int nl = i / nrest, q = i - nl * nrest, n = n0 + nl;
+        const int col = q < conv_col0 ? q : q + CONV_O;
+        float v = 0.f;
+        if (col == 0) {
+          v = (float)n / (float)a.N;                               // model.py:22-30
+        } else if (col <= a.octave) {
+          v = ((n % a.octave) == col - 1) ? 1.f : 0.f;             // model.py:32-41
+        } else if (col == a.octave + 1) {                          // model.py:43-49 raw-reshape quirk
+          int64_t f = (int64_t)bt * a.N + n, bT = (int64_t)a.B * a.T;
+          v = a.bins[((f / bT) % a.octave) * bT + (f % bT)];
+        } else if (col < a.F) {                                    // beat, model.py:66
+          int j = col - conv_col0 - CONV_O;
+          v = a.beat[(int64_t)bt * a.NB + j] * dj_keep(a.d_beat, dj_rowkey(a.d_beat, bt), j);
+        }
+        if (col < a.F) v += a.sp0[(int64_t)bt * a.F + col] * dj_keep(a.d_style, rks[n], col);
+        xrow[nl * a.FP + col] = dj_from_f32<T>(v);
+      }
+      __syncthreads();
+      // rows out: FP/8 16-byte vectors per note row
+      for (int i = tid; i < nc * vpr; i += 256) {
+        const int nl = i / vpr, cv = (i - nl * vpr) * 8;
+        const T* src = xrow + nl * a.FP + cv;
+        T* dst = X + dj_row_ta(b, t, n0 + nl, a.T, a.N) * a.FP + cv;
+        if constexpr (sizeof(T) == 2) {
+          *(uint4*)dst = *(const uint4*)src;
+        } else {
+          ((uint4*)dst)[0] = ((const uint4*)src)[0];
+          ((uint4*)dst)[1] = ((const uint4*)src)[1];
         }
       }
-    }
-    // the remaining columns: [0, 14) and [14+64, FP)
-    const int nrest = a.FP - CONV_O;
-    for (int i = tid; i < a.N * nrest; i += 256) {
-      int n = i / nrest, q = i % nrest;
-      int col = q < conv_col0 ? q : q + CONV_O;
-      uint32_t r = (uint32_t)bt * a.N + n;
-      float v = 0.f;
-      if (col == 0) {
-        v = (float)n / (float)a.N;                               // model.py:22-30
-      } else if (col <= a.octave) {
-        v = ((n % a.octave) == col - 1) ? 1.f : 0.f;             // model.py:32-41
-      } else if (col == a.octave + 1) {                          // model.py:43-49 raw-reshape quirk
-        int64_t f = (int64_t)r, bT = (int64_t)a.B * a.T;
-        v = a.bins[((f / bT) % a.octave) * bT + (f % bT)];
-      } else if (col < a.F) {                                    // beat, model.py:66
-        int j = col - conv_col0 - CONV_O;
-        v = a.beat[(int64_t)bt * a.NB + j] * dj_keep(a.d_beat, dj_rowkey(a.d_beat, bt), j);
+      if (Xcol) {                                                 // im2col rows: XCOL_LD/8 vectors per note
+        for (int i = tid; i < nc * (XCOL_LD / 8); i += 256) {
+          const int nl = i / (XCOL_LD / 8), q0 = (i % (XCOL_LD / 8)) * 8, n = n0 + nl;
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int q = q0 + e;
+            v[e] = q < CONV_K * CONV_C ? xin[(n + q / CONV_C) * 3 + q % CONV_C] : 0.f;
+          }
+          store8(Xcol + dj_row_ta(b, t, n, a.T, a.N) * XCOL_LD + q0, v);
+        }
       }
-      if (col < a.F) v += a.sp0[(int64_t)bt * a.F + col] * dj_keep(a.d_style, dj_rowkey(a.d_style, r), col);
-      X[dj_row_ta(b, t, n, a.T, a.N) * a.FP + col] = dj_from_f32<T>(v);
-    }
-    if (Xcol) {
-      for (int i = tid; i < a.N * XCOL_LD; i += 256) {
-        const int n = i / XCOL_LD, q = i % XCOL_LD;
-        const float v = q < CONV_K * CONV_C ? xin[(n + q / CONV_C) * 3 + q % CONV_C] : 0.f;
-        Xcol[dj_row_ta(b, t, n, a.T, a.N) * XCOL_LD + q] = dj_from_f32<T>(v);
-      }
+      __syncthreads();
     }
   }
 }
@@ -738,18 +766,18 @@ int dj_launch_bins(const float* notes, float* bins, int B, int T, int N, int oct
                      dn);
   return (int)hipGetLastError();
 }
-static size_t feat_smem(int N) {
-  int NQ = ((N + 3) / 4 + 3) / 4 * 4;
-  int XR = NQ * 4 + CONV_K + 3;
-  return (size_t)(XR * 3 + 256) * sizeof(float);
+static size_t feat_smem(int N, int FP, size_t esz) {
+  const int XR = (N + 3) / 4 * 4 + CONV_K + 3;
+  return ((size_t)(XR * 3 + 2 * N) * 4 + 15) / 16 * 16 + (size_t)FEAT_NC * FP * esz;
 }
 int dj_launch_feature_fwd(int dtype, const void* fa, void* X, void* Xcol, void* Ycol, hipStream_t st) {
   const FeatArgs& a = *(const FeatArgs*)fa;
   if (a.FP - CONV_O > 64 || a.FP % 8) return 1021;
   int grid = a.B * a.T < 2048 ? a.B * a.T : 2048;
-  DJ_T_DISPATCH(hipLaunchKernelGGL(feature_fwd_kernel<float>, dim3(grid), dim3(256), feat_smem(a.N), st, a, (float*)X,
-                                   (float*)Xcol, (float*)Ycol),
-                hipLaunchKernelGGL(feature_fwd_kernel<bf16_t>, dim3(grid), dim3(256), feat_smem(a.N), st, a,
+  if (feat_smem(a.N, a.FP, 4) > 64 * 1024) return 1027;
+  DJ_T_DISPATCH(hipLaunchKernelGGL(feature_fwd_kernel<float>, dim3(grid), dim3(256), feat_smem(a.N, a.FP, 4), st, a,
+                                   (float*)X, (float*)Xcol, (float*)Ycol),
+                hipLaunchKernelGGL(feature_fwd_kernel<bf16_t>, dim3(grid), dim3(256), feat_smem(a.N, a.FP, 2), st, a,
                                    (bf16_t*)X, (bf16_t*)Xcol, (bf16_t*)Ycol))
   return (int)hipGetLastError();
 }
