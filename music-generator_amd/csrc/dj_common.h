@@ -93,7 +93,7 @@ __device__ __forceinline__ float dj_tanh(float x) {
 __device__ __forceinline__ float dj_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // Keras hard_sigmoid = clip(0.2x + 0.5, 0, 1)
 __device__ __forceinline__ float dj_hsig(float x) { return fminf(fmaxf(0.2f * x + 0.5f, 0.0f), 1.0f); }
-__device__ __forceinline__ float dj_hsig_grad(float x) { return (x > -2.5f && x < 2.5f) ? 0.2f : 0.0f; }
+__device__ __forceinline__ float dj_hsig_grad(float x) { return fabsf(x) < 2.5f ? 0.2f : 0.0f; }   // -2.5 < x < 2.5
 template <bool SIGM> __device__ __forceinline__ float dj_ract(float x) {
   if constexpr (SIGM) return dj_sigmoid(x);
   return dj_hsig(x);
