@@ -275,3 +275,60 @@ def test_resident_graph_generation_matches_stepwise(gpu_device, monkeypatch):
     np.testing.assert_array_equal(res, stp)
     np.testing.assert_array_equal(pos_res, pos_stp)
     assert 0 < res[..., 0].sum() < res[..., 0].size              # some notes, some silence
+
+
+def test_full_size_properties(gpu_device, monkeypatch):
+    """BASELINE shape (B64 x T128 x N128), where the CPU oracle is out of reach: size-independent
+    properties instead.  (1) The fp32 gradient is the derivative of the fp32 loss: central
+    difference along a random direction, dropout masks fixed by the seed.  (2) The two forward
+    structures (x*W fused into the recurrence / separate GEMM) agree in fp32.  (3) bf16 agrees with
+    fp32 at bf16 tolerance.  (4) The forward is bitwise reproducible."""
+    from music_generator_amd.data import synthetic_batch
+    from music_generator_amd.engine import DeepJConfig, Engine, init_params_numpy
+    B, T, N, seed = 64, 128, 128, 7
+    batch = [torch.from_numpy(a).to(gpu_device) for a in synthetic_batch(N, T, B, seed=0)]
+    cfg32 = DeepJConfig(num_notes=N, time_steps=T, dtype="f32")
+    P0 = torch.from_numpy(init_params_numpy(cfg32, seed=1234)).to(gpu_device)
+
+    def run(cfg, P, fuse_min_tiles=None):
+        if fuse_min_tiles is not None:
+            monkeypatch.setenv("DEEPJ_FUSE_XW_MIN_TILES", str(fuse_min_tiles))
+        else:
+            monkeypatch.delenv("DEEPJ_FUSE_XW_MIN_TILES", raising=False)
+        eng = Engine(cfg, B, T, device=gpu_device, input_dropout=0.2, dropout=0.5)
+        G = torch.empty_like(P)
+        out = torch.empty((B, T, N, 3), dtype=torch.float32, device=gpu_device)
+        loss = eng.train_fwd_bwd(P, G, *batch, seed=seed, out=out)
+        torch.cuda.synchronize()
+        res = float(loss.cpu()[0]), out.clone(), G.clone()
+        del eng
+        torch.cuda.empty_cache()
+        return res
+
+    l0, out0, g0 = run(cfg32, P0)
+    assert np.isfinite(l0) and bool(torch.isfinite(g0).all())
+    # (4) reproducible forward
+    l0b, out0b, _ = run(cfg32, P0)
+    assert torch.equal(out0, out0b)
+    # (1) directional derivative (fp64 accumulation of g.d; eps sized for fp32 loss rounding)
+    gen = torch.Generator(device=gpu_device).manual_seed(3)
+    d = torch.randn(P0.shape, device=gpu_device, generator=gen)
+    d = d / d.norm()
+    eps = 2e-2
+    lp, _, _ = run(cfg32, P0 + eps * d)
+    lm, _, _ = run(cfg32, P0 - eps * d)
+    fd = (lp - lm) / (2 * eps)
+    gd = float((g0.double() * d.double()).sum())
+    assert abs(fd - gd) <= 2e-2 * max(abs(gd), 1e-3), (fd, gd)
+    # (2) unfused forward structure (threshold above the 256 tiles of this shape)
+    l1, out1, g1 = run(cfg32, P0, fuse_min_tiles=100000)
+    torch.testing.assert_close(out1, out0, rtol=1e-3, atol=1e-5)
+    assert abs(l1 - l0) <= 1e-5 * max(1.0, abs(l0))
+    assert float((g1 - g0).abs().max()) <= 2e-3 * float(g0.abs().max())
+    # (3) bf16 against fp32
+    cfg16 = DeepJConfig(num_notes=N, time_steps=T, dtype="bf16")
+    l2, out2, g2 = run(cfg16, P0)
+    assert abs(l2 - l0) <= 2e-2 * max(1.0, abs(l0))
+    assert float((out2 - out0).abs().max()) <= 5e-2
+    cos = float((g2.double() * g0.double()).sum() / (g2.double().norm() * g0.double().norm()))
+    assert cos > 0.99, cos
