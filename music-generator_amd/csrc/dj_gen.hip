@@ -88,10 +88,34 @@ __global__ void gen_zx0_kernel(GenArgs a, const T* __restrict__ Htime) {
   a.zx0[((int64_t)g * a.N + n) * ldw + col] = s;
 }
 
+// z[g] += sum_k x[g][k] * w[k * ldw]  for one gate column: the weight column is streamed from L2 with
+// 32 loads in flight per thread (the chain of 48 notes x Ln layers is pure latency: at 8 in flight the
+// sampler took 4.3 ms per time step), x comes from LDS as 16-byte broadcasts.  K is a multiple of 32.
+__device__ __forceinline__ void gen_dot(float (&z)[GEN_MAXG], const float* __restrict__ w, int ldw,
+                                        const float* __restrict__ x, int K, int G) {
+#pragma unroll 1
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    float wv[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) wv[i] = w[(int64_t)(k0 + i) * ldw];
+#pragma unroll
+    for (int g = 0; g < GEN_MAXG; ++g)
+      if (g < G) {
+        float s = z[g];
+#pragma unroll
+        for (int i = 0; i < 32; i += 4) {
+          const float4 xv = *(const float4*)(x + g * K + k0 + i);
+          s += xv.x * wv[i] + xv.y * wv[i + 1] + xv.z * wv[i + 2] + xv.w * wv[i + 3];
+        }
+        z[g] = s;
+      }
+  }
+}
+
 // one workgroup, 4*Hn threads (one per gate column)
 template <bool SIGM>
 __global__ void gen_sample_kernel(GenArgs a) {
-  extern __shared__ float sm[];
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int Hn = a.Hn, G = a.G, C4 = 4 * Hn;
   float* hs = sm;                          // [Ln][G][Hn]
   float* cs = hs + a.Ln * G * Hn;          // [Ln][G][Hn]
@@ -124,25 +148,12 @@ __global__ void gen_sample_kernel(GenArgs a) {
             z[g] = s;
           }
       } else {
-        const float* Wl = a.P + a.W[l];
         const float bl = a.P[a.b[l] + col];
 #pragma unroll
         for (int g = 0; g < GEN_MAXG; ++g) z[g] = bl;
-#pragma unroll 8
-        for (int k = 0; k < Hn; ++k) {
-          const float wv = Wl[(int64_t)k * C4 + col];
-#pragma unroll
-          for (int g = 0; g < GEN_MAXG; ++g)
-            if (g < G) z[g] += xs[g * Hn + k] * wv;
-        }
+        gen_dot(z, a.P + a.W[l] + col, C4, xs, Hn, G);
       }
-#pragma unroll 8
-      for (int k = 0; k < Hn; ++k) {
-        const float uv = U[(int64_t)k * C4 + col];
-#pragma unroll
-        for (int g = 0; g < GEN_MAXG; ++g)
-          if (g < G) z[g] += hl[g * Hn + k] * uv;
-      }
+      gen_dot(z, U + col, C4, hl, Hn, G);
 #pragma unroll
       for (int g = 0; g < GEN_MAXG; ++g)
         if (g < G) zb[g * C4 + col] = z[g];
@@ -270,7 +281,7 @@ int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int
                              int64_t style_stride,
                              float* scratch, const double* uniforms, const float* temperature, float* next_notes,
                              int* draws_used, void* state, float* results, int sigm, hipStream_t st) {
-  if (G < 1 || G > GEN_MAXG || Ln < 1 || Ln > 4 || 4 * Hn > 1024 || Ht + 3 > 512 || SU > 64) return 1300;
+  if (G < 1 || G > GEN_MAXG || Ln < 1 || Ln > 4 || 4 * Hn > 1024 || (Hn % 32) || Ht + 3 > 512 || SU > 64) return 1300;
   GenArgs a;
   a.G = G; a.N = N; a.Hn = Hn; a.Ht = Ht; a.Ln = Ln; a.S = S; a.SU = SU; a.T = T; a.P = P;
   a.p_style_W = offs[0]; a.p_style_b = offs[1]; a.p_nd_W = offs[2]; a.p_nd_b = offs[3]; a.p_vd_W = offs[4];
