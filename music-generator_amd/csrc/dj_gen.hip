@@ -113,8 +113,8 @@ __device__ __forceinline__ void gen_dot(float (&z)[GEN_MAXG], const float* __res
 }
 
 // one workgroup, 4*Hn threads (one per gate column)
-template <bool SIGM>
-__global__ void gen_sample_kernel(GenArgs a) {
+template <bool SIGM, int MAXT>
+__global__ __launch_bounds__(MAXT) void gen_sample_kernel(GenArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int Hn = a.Hn, G = a.G, C4 = 4 * Hn;
   float* hs = sm;                          // [Ln][G][Hn]
@@ -304,9 +304,13 @@ int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int
   else
     hipLaunchKernelGGL(gen_zx0_kernel<bf16_t>, gz, dim3(256), 0, st, a, (const bf16_t*)Htime);
   const size_t smem = ((size_t)2 * Ln * G * Hn + (size_t)G * 4 * Hn + (size_t)G * Hn + 8 * G) * sizeof(float);
-  if (sigm)
-    hipLaunchKernelGGL(gen_sample_kernel<true>, dim3(1), dim3(4 * Hn), smem, st, a);
-  else
-    hipLaunchKernelGGL(gen_sample_kernel<false>, dim3(1), dim3(4 * Hn), smem, st, a);
+  // up to 512 threads (Hn <= 128) the sampler may use 256 VGPRs
+#define DJ_GEN_LAUNCH(S, MT) hipLaunchKernelGGL((gen_sample_kernel<S, MT>), dim3(1), dim3(4 * Hn), smem, st, a)
+  if (4 * Hn <= 512) {
+    if (sigm) DJ_GEN_LAUNCH(true, 512); else DJ_GEN_LAUNCH(false, 512);
+  } else {
+    if (sigm) DJ_GEN_LAUNCH(true, 1024); else DJ_GEN_LAUNCH(false, 1024);
+  }
+#undef DJ_GEN_LAUNCH
   return (int)hipGetLastError();
 }
