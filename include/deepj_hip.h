@@ -69,6 +69,13 @@ int32_t dj_workspace_init(const dj_config* cfg, void* workspace, int64_t workspa
 int32_t dj_train_fwd_bwd(const dj_config* cfg, const float* params, float* grads, const float* notes,
                          const float* chosen, const float* beat, const float* style, const float* target, float* out,
                          float* loss, void* workspace, int64_t workspace_bytes, uint64_t seed, void* stream);
+/* Same, micro-batch form: with accumulate != 0 the gradients of this call are ADDED to `grads` (gradient
+ * accumulation over micro-batches, e.g. the scaled model's global batch as 2 x 64 sequences); `loss` is this
+ * call's mean.  Scale by 1/micro-batches in dj_nadam_step (grad_scale), as for data-parallel ranks. */
+int32_t dj_train_fwd_bwd_acc(const dj_config* cfg, const float* params, float* grads, const float* notes,
+                             const float* chosen, const float* beat, const float* style, const float* target,
+                             float* out, float* loss, void* workspace, int64_t workspace_bytes, uint64_t seed,
+                             int32_t accumulate, void* stream);
 
 /* Keras-2 Nadam update (model.py:152 optimizer='nadam'): one fused pass over the flat
  * vectors.  step_t is 1-based; m_schedule_host is read and updated on the host.

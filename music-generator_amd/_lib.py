@@ -35,6 +35,8 @@ _SIGS = {
     "dj_workspace_init": (C.c_int32, [C.POINTER(DjConfig), _P, C.c_int64, _P]),
     "dj_train_fwd_bwd": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64,
                                      C.c_uint64, _P]),
+    "dj_train_fwd_bwd_acc": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64,
+                                     C.c_uint64, C.c_int32, _P]),
     "dj_nadam_step": (C.c_int32, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_float, C.c_float,
                                   C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "dj_predict": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),

@@ -450,6 +450,14 @@ int32_t dj_workspace_init(const dj_config* cfg, void* ws, int64_t bytes, void* s
 int32_t dj_train_fwd_bwd(const dj_config* cfg, const float* params, float* grads, const float* notes,
                          const float* chosen, const float* beat, const float* style, const float* target, float* out,
                          float* loss, void* ws, int64_t ws_bytes, uint64_t seed, void* stream) {
+  return dj_train_fwd_bwd_acc(cfg, params, grads, notes, chosen, beat, style, target, out, loss, ws, ws_bytes, seed, 0,
+                              stream);
+}
+
+int32_t dj_train_fwd_bwd_acc(const dj_config* cfg, const float* params, float* grads, const float* notes,
+                             const float* chosen, const float* beat, const float* style, const float* target,
+                             float* out, float* loss, void* ws, int64_t ws_bytes, uint64_t seed, int32_t accumulate,
+                             void* stream) {
   Plan p;
   RUN(make_plan(cfg, p));
   RUN(check_ws(p, ws, ws_bytes));
@@ -457,7 +465,7 @@ int32_t dj_train_fwd_bwd(const dj_config* cfg, const float* params, float* grads
   Ctx c{p, params, (char*)ws, (hipStream_t)stream, true, seed};
   const int dt = p.c.dtype;
   float* G = grads;
-  DJ_CHECK(hipMemsetAsync(G, 0, p.nparams * sizeof(float), c.st));
+  if (!accumulate) DJ_CHECK(hipMemsetAsync(G, 0, p.nparams * sizeof(float), c.st));   // every gradient kernel adds into G
   DJ_CHECK(hipMemsetAsync(loss, 0, sizeof(float), c.st));
   for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], true));
   for (int l = 0; l < p.Ln; ++l) RUN(prep_layer(c, p.nl[l], p.w_Wt_n[l], p.w_Wc_n[l], p.w_Uf_n[l], p.w_Ub_n[l], true));

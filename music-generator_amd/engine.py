@@ -155,19 +155,21 @@ class Engine:
         if tuple(t.shape) != tuple(shape):
             raise ValueError(f"{what}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
 
-    def train_fwd_bwd(self, params, grads, notes, chosen, beat, style, target, seed=0, out=None):
+    def train_fwd_bwd(self, params, grads, notes, chosen, beat, style, target, seed=0, out=None, accumulate=False):
         """Forward + BPTT.  All arguments are device fp32 tensors; returns the loss
-        tensor (device, shape [1]); grads is overwritten."""
+        tensor (device, shape [1]); grads is overwritten, or added to when `accumulate`
+        (gradient accumulation over micro-batches)."""
         s3, sb, ss = self._shapes()
         for t, sh, nm in ((notes, s3, "notes"), (chosen, s3, "chosen"), (target, s3, "target"),
                           (beat, sb, "beat"), (style, ss, "style")):
             self._check(t, sh, nm)
         assert params.numel() == self.nparams and grads.numel() == self.nparams
         with torch.cuda.device(self.device):
-            rc = self.lib.dj_train_fwd_bwd(C.byref(self.c), _lib.ptr(params), _lib.ptr(grads), _lib.ptr(notes),
-                                           _lib.ptr(chosen), _lib.ptr(beat), _lib.ptr(style), _lib.ptr(target),
-                                           _lib.ptr(out), _lib.ptr(self.loss), self.ws_ptr, self.ws_bytes,
-                                           C.c_uint64(int(seed) & (2 ** 64 - 1)), _stream_ptr())
+            rc = self.lib.dj_train_fwd_bwd_acc(C.byref(self.c), _lib.ptr(params), _lib.ptr(grads), _lib.ptr(notes),
+                                               _lib.ptr(chosen), _lib.ptr(beat), _lib.ptr(style), _lib.ptr(target),
+                                               _lib.ptr(out), _lib.ptr(self.loss), self.ws_ptr, self.ws_bytes,
+                                               C.c_uint64(int(seed) & (2 ** 64 - 1)), 1 if accumulate else 0,
+                                               _stream_ptr())
         _lib.check(rc, "dj_train_fwd_bwd")
         return self.loss
 

@@ -332,3 +332,24 @@ def test_full_size_properties(gpu_device, monkeypatch):
     assert float((out2 - out0).abs().max()) <= 5e-2
     cos = float((g2.double() * g0.double()).sum() / (g2.double().norm() * g0.double().norm()))
     assert cos > 0.99, cos
+
+
+def test_gradient_accumulation_over_micro_batches(gpu_device):
+    """dj_train_fwd_bwd_acc: the gradients of a second micro-batch are added to the first's
+    (every gradient kernel accumulates), which is how a global batch larger than one workspace runs."""
+    from music_generator_amd.engine import Engine
+    T, B = 6, 2
+    ocfg, dcfg = _cfgs(time_steps=T, num_notes=24)
+    flat = O.flatten_params(ocfg, O.init_params(ocfg, seed=4))
+    P = torch.from_numpy(flat).to(gpu_device)
+    eng = Engine(dcfg, B, T, device=gpu_device, input_dropout=0.2, dropout=0.5)
+    mb = [[torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(gpu_device)
+           for a in O.synthetic_batch(ocfg, B, seed=s, T=T)] for s in (1, 2)]
+    g1, g2, gacc = torch.empty_like(P), torch.empty_like(P), torch.empty_like(P)
+    l1 = float(eng.train_fwd_bwd(P, g1, *mb[0], seed=11).cpu()[0])
+    l2 = float(eng.train_fwd_bwd(P, g2, *mb[1], seed=12).cpu()[0])
+    la = float(eng.train_fwd_bwd(P, gacc, *mb[0], seed=11).cpu()[0])
+    lb = float(eng.train_fwd_bwd(P, gacc, *mb[1], seed=12, accumulate=True).cpu()[0])
+    assert la == pytest.approx(l1, rel=1e-6) and lb == pytest.approx(l2, rel=1e-6)
+    ref = (g1 + g2).cpu().numpy()
+    np.testing.assert_allclose(gacc.cpu().numpy(), ref, rtol=1e-4, atol=1e-6 * float(np.abs(ref).max()))

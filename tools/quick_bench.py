@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from music_generator_amd.engine import DeepJConfig, Engine, Nadam, param_count, init_params_numpy
 
-def run(dtype, B=64, T=128, N=128, steps=3, pin=0.2, pdr=0.5, **kw):
+def run(dtype, B=64, T=128, N=128, steps=3, pin=0.2, pdr=0.5, micro=1, **kw):
     dev = torch.device("cuda:0")
     cfg = DeepJConfig(num_notes=N, time_steps=T, dtype=dtype, **kw)
     eng = Engine(cfg, B, T, device=dev, input_dropout=pin, dropout=pdr)
@@ -24,17 +24,19 @@ def run(dtype, B=64, T=128, N=128, steps=3, pin=0.2, pdr=0.5, **kw):
     for it in range(steps + 1):
         if it == 1:
             torch.cuda.synchronize(); t0 = time.time()
-        loss = eng.train_fwd_bwd(P, G, notes, target, beat, style, target, seed=it)
-        opt.step(P, G)
+        for m in range(micro):                      # micro-batches: gradients accumulate, one optimizer step
+            loss = eng.train_fwd_bwd(P, G, notes, target, beat, style, target, seed=it * micro + m, accumulate=m > 0)
+        opt.step(P, G, grad_scale=1.0 / micro)
         losses.append(loss.clone())
     torch.cuda.synchronize(); dt = (time.time() - t0) / steps
-    print(f"[{dtype}] B={B} T={T} N={N}: {dt*1e3:.2f} ms/step, {B*T*N/dt/1e6:.2f} M note-steps/s, "
+    print(f"[{dtype}] B={B}x{micro} T={T} N={N}: {dt*1e3:.2f} ms/step, {micro*B*T*N/dt/1e6:.2f} M note-steps/s, "
           f"losses {[round(float(l), 5) for l in losses]}", flush=True)
 
 if __name__ == "__main__":
     if sys.argv[1:2] == ["scaled"]:      # BASELINE configs[4] family: 3 x 1024 units per axis; B, T from argv
         B, T = int(sys.argv[2]), int(sys.argv[3])
-        run("bf16", B=B, T=T, N=128, steps=2, time_axis_units=1024, note_axis_units=1024, time_axis_layers=3,
+        micro = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+        run("bf16", B=B, T=T, N=128, steps=2, micro=micro, time_axis_units=1024, note_axis_units=1024, time_axis_layers=3,
             note_axis_layers=3)
         sys.exit(0)
     for dt in sys.argv[1:] or ["f32", "bf16"]:
