@@ -61,6 +61,31 @@ class HipBackend:
     def numpy(self, t):
         return t.detach().cpu().numpy()
 
+    def resident(self, arrays):
+        """Upload whole training arrays to HBM once (fp32) so that fit() slices batches on the device
+        instead of gathering, converting and copying ~75 MB of float64 per batch on the host.  Returns a
+        list of device tensors (identical arrays share one tensor), or None when the set exceeds
+        DEEPJ_RESIDENT_GB (default 64; an MI355X has 288 GB)."""
+        t = self.torch
+        cap = float(os.environ.get("DEEPJ_RESIDENT_GB", "64")) * 2 ** 30
+        uniq = {}
+        for a in arrays:
+            uniq.setdefault(id(a), a)
+        if sum(a.size * 4 for a in uniq.values()) > cap:
+            return None
+        dev = {}
+        for k, a in uniq.items():
+            out = t.empty(a.shape, dtype=t.float32, device=self.device)
+            step = max(1, (256 << 20) // max(1, a[0].size * 4))          # ~256 MB host staging at a time
+            for i in range(0, a.shape[0], step):
+                out[i:i + step] = t.as_tensor(np.ascontiguousarray(a[i:i + step], dtype=np.float32)).to(self.device)
+            dev[k] = out
+        return [dev[id(a)] for a in arrays]
+
+    def take(self, tensors, ids):
+        idx = self.torch.as_tensor(np.ascontiguousarray(ids, dtype=np.int64)).to(self.device)
+        return [x.index_select(0, idx) for x in tensors]
+
     def engine(self, cfg, batch, time_steps, input_dropout, dropout):
         from .engine import Engine
         return Engine(cfg, batch, time_steps, device=self.device, input_dropout=input_dropout, dropout=dropout)
@@ -261,8 +286,16 @@ class TrainableModel(Model):
         With torch.distributed initialised, every rank passes ITS shard and the
         gradients are summed over ranks weighted by shard size (one all-reduce)."""
         s, be = self._s, self._s.backend
-        notes, chosen, beat, style = [np.asarray(a) for a in x]
-        target = np.asarray(y[0] if isinstance(y, (list, tuple)) else y) if y is not None else chosen
+        return self._train_step([np.asarray(a) for a in x],
+                                np.asarray(y[0] if isinstance(y, (list, tuple)) else y) if y is not None else None)
+
+    def _train_step(self, x, target, on_device=False):
+        """x = [notes, chosen, beat, style] (+ target) as host arrays, or as device fp32 tensors when
+        `on_device` (fit() with a device-resident data set)."""
+        s, be = self._s, self._s.backend
+        notes, chosen, beat, style = x
+        if target is None:
+            target = chosen
         B, T = notes.shape[0], notes.shape[1]
         eng = s.engine(B, T, train=True)
         if s.grads is None:
@@ -273,7 +306,7 @@ class TrainableModel(Model):
         rank = dist.get_rank() if dist else 0
         world = dist.get_world_size() if dist else 1
         seed = (s.seed * 1000003 + s.step * world + rank) & 0xFFFFFFFF
-        t = [be.tensor(a) for a in (notes, chosen, beat, style, target)]
+        t = [notes, chosen, beat, style, target] if on_device else [be.tensor(a) for a in (notes, chosen, beat, style, target)]
         loss = eng.train_fwd_bwd(s.params, s.grads, *t, seed=seed)
         weight = float(B)
         if dist:
@@ -333,6 +366,8 @@ class TrainableModel(Model):
         rank = dist.get_rank() if dist else 0
         world = dist.get_world_size() if dist else 1
         index = np.arange(n)
+        be = self._s.backend
+        resident = be.resident(x + [target]) if hasattr(be, "resident") else None      # whole data set in HBM
         for epoch in range(initial_epoch, epochs):
             _call(callbacks, "on_epoch_begin", epoch, {})
             if shuffle:
@@ -350,7 +385,11 @@ class TrainableModel(Model):
                         mine = ids[:1]
                 else:
                     mine = ids
-                loss = self.train_on_batch([a[mine] for a in x], target[mine])
+                if resident is not None:
+                    dev = be.take(resident, mine)
+                    loss = self._train_step(dev[:4], dev[4], on_device=True)
+                else:
+                    loss = self.train_on_batch([a[mine] for a in x], target[mine])
                 tot += loss * len(ids)
                 seen += len(ids)
                 _call(callbacks, "on_batch_end", bi, {"batch": bi, "size": len(ids), "loss": loss})
