@@ -490,10 +490,36 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
       dh3 = dh_ld((rbv), 3);     \
     }                            \
   } while (0)
+#ifndef DJ_EXP_TAILPF
+#define DJ_EXP_TAILPF 1
+#endif
+  // TAILPF (bf16, H = 128 with the stationary U^T): the stash of step t-1 (z_{t-1}, c_{t-2}, dH_{t-1}) is
+  // requested at the start of step t's dz U^T product -- there is no weight stream it could delay, and
+  // the product, the barriers and the dH staging are its head start (-0.22 ms on the note axis).  With
+  // a streamed U^T (H = 256) the same requests issued after the last fragment load made the step
+  // slower (+0.16 ms), so that kernel keeps requesting its stash at the top of the step.
+  constexpr bool TAILPF = R::HOIST && R::STATB && DJ_EXP_TAILPF;
   Frag16<T> cnext[R::NJ];   // c_t of the step being processed (loaded as c_{t-1} one step earlier)
+  Frag16<T> zf[4][R::NJ], cprev[R::NJ];
   DJ_DH_LOAD(tile * steps + steps - 1);
 #pragma unroll
-  for (int j = 0; j < R::NJ; ++j) cnext[j].load(caddr(tile * steps + steps - 1, j));
+  for (int j = 0; j < R::NJ; ++j) {
+    cnext[j].load(caddr(tile * steps + steps - 1, j));
+    if constexpr (TAILPF) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) zf[g][j].load(zaddr(tile * steps + steps - 1, g, j));
+      if (steps > 1) cprev[j].load(caddr(tile * steps + steps - 2, j));
+    }
+  }
+  // stash requests of step t-1, issued from inside step t
+  auto stash_prefetch = [&](int64_t rb, int t) {
+#pragma unroll
+    for (int j = 0; j < R::NJ; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) zf[g][j].load(zaddr(rb - 1, g, j));
+      if (t > 1) cprev[j].load(caddr(rb - 2, j));
+    }
+  };
 
   for (int t = steps - 1; t >= 0; --t) {
     const int64_t rb = tile * steps + t;
@@ -505,16 +531,17 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
       dh_st(2, dh2);
       dh_st(3, dh3);
     }
-    Frag16<T> zf[4][R::NJ], cprev[R::NJ];
+    if constexpr (!TAILPF) {
 #pragma unroll
-    for (int j = 0; j < R::NJ; ++j) {
-      if constexpr (R::HOIST) {
+      for (int j = 0; j < R::NJ; ++j) {
+        if constexpr (R::HOIST) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) zf[g][j].load(zaddr(rb, g, j));
+          for (int g = 0; g < 4; ++g) zf[g][j].load(zaddr(rb, g, j));
+        }
+        if (t > 0) cprev[j].load(caddr(rb - 1, j));
       }
-      if (t > 0) cprev[j].load(caddr(rb - 1, j));
+      if (t > 0) DJ_DH_LOAD(rb - 1);
     }
-    if (t > 0) DJ_DH_LOAD(rb - 1);
     DJ_STAMP(1, 1, t);
     lds_barrier();
     DJ_STAMP(1, 2, t);
@@ -579,30 +606,48 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
       const T* ap = dzs + l31 * R::LDZ;
       if constexpr (R::STATB) {
+        if constexpr (TAILPF) {        // no weight stream to stay behind: the whole product is head start
+          stash_prefetch(rb, t);
+          DJ_DH_LOAD(rb - 1);
+        }
 #pragma unroll
         for (int kc = 0; kc < R::NKCB; ++kc) {
           Frag a = dj_lds_frag(ap + kc * R::KC, h);
           dj_mfma(acc[0], a, ub[kc]);
         }
       } else {
-      Frag bq[R::PDB][R::NJ];
+        Frag bq[R::PDB][R::NJ];
 #pragma unroll
-      for (int p = 0; p < R::PDB; ++p)
+        for (int p = 0; p < R::PDB; ++p)
 #pragma unroll
-        for (int j = 0; j < R::NJ; ++j) bq[p][j] = up[(j * R::NKCB + p) * 64];
+          for (int j = 0; j < R::NJ; ++j) bq[p][j] = up[(j * R::NKCB + p) * 64];
+        static_assert(R::UNRB % R::PDB == 0 && R::NKCB % R::UNRB == 0, "ring / unroll geometry");
+        // all blocks but the last refill the ring; the last block only drains it
+        constexpr int KMAIN = TAILPF ? R::NKCB - R::UNRB : R::NKCB;
 #pragma unroll 1
-      for (int kc0 = 0; kc0 < R::NKCB; kc0 += R::UNRB) {
+        for (int kc0 = 0; kc0 < KMAIN; kc0 += R::UNRB) {
 #pragma unroll
-        for (int u = 0; u < R::UNRB; ++u) {
-          const int kc = kc0 + u;
-          Frag a = dj_lds_frag(ap + kc * R::KC, h);
+          for (int u = 0; u < R::UNRB; ++u) {
+            const int kc = kc0 + u;
+            Frag a = dj_lds_frag(ap + kc * R::KC, h);
 #pragma unroll
-          for (int j = 0; j < R::NJ; ++j) dj_mfma(acc[j], a, bq[u % R::PDB][j]);
-          const int kn = (kc + R::PDB < R::NKCB) ? kc + R::PDB : R::NKCB - 1;
+            for (int j = 0; j < R::NJ; ++j) dj_mfma(acc[j], a, bq[u % R::PDB][j]);
+            const int kn = (kc + R::PDB < R::NKCB) ? kc + R::PDB : R::NKCB - 1;
 #pragma unroll
-          for (int j = 0; j < R::NJ; ++j) bq[u % R::PDB][j] = up[(j * R::NKCB + kn) * 64];
+            for (int j = 0; j < R::NJ; ++j) bq[u % R::PDB][j] = up[(j * R::NKCB + kn) * 64];
+          }
         }
-      }
+        if constexpr (TAILPF) {
+          static_assert(R::UNRB == R::PDB, "the drained block must be exactly the ring");
+          stash_prefetch(rb, t);       // every U^T fragment has been requested: the stash of step t-1 goes next
+          DJ_DH_LOAD(rb - 1);
+#pragma unroll
+          for (int u = 0; u < R::UNRB; ++u) {
+            Frag a = dj_lds_frag(ap + (KMAIN + u) * R::KC, h);
+#pragma unroll
+            for (int j = 0; j < R::NJ; ++j) dj_mfma(acc[j], a, bq[u % R::PDB][j]);
+          }
+        }
       }
     }
     DJ_STAMP(1, 7, t);
