@@ -54,6 +54,7 @@ struct LstmP {          // parameter offsets (floats) of one LSTM layer + its st
   int64_t W, U, b;      // LSTM kernel [D,4H], recurrent_kernel [H,4H], bias [4H]
   int D, DP, H;
   int64_t tiles;        // sequence tiles of this layer's axis (32 sequences each)
+  int dtype;            // operand dtype of the plan (DJ_F32 / DJ_BF16)
 };
 
 struct Plan {
@@ -110,13 +111,13 @@ int make_plan(const dj_config* cfg, Plan& p) {
   p.p_conv_W = take(24 * 3 * 64); p.p_conv_b = take(64);
   for (int l = 0; l < p.Lt; ++l) {
     LstmP& L = p.tl[l];
-    L.D = l == 0 ? p.F : p.Ht; L.DP = (int)up8(L.D); L.H = p.Ht; L.tiles = p.tilesT;
+    L.D = l == 0 ? p.F : p.Ht; L.DP = (int)up8(L.D); L.H = p.Ht; L.tiles = p.tilesT; L.dtype = cfg->dtype;
     L.dW = take((int64_t)p.SU * L.D); L.db = take(L.D);
     L.W = take((int64_t)L.D * 4 * L.H); L.U = take((int64_t)L.H * 4 * L.H); L.b = take(4 * L.H);
   }
   for (int l = 0; l < p.Ln; ++l) {
     LstmP& L = p.nl[l];
-    L.D = l == 0 ? p.Ht + 3 : p.Hn; L.DP = (int)up8(L.D); L.H = p.Hn; L.tiles = p.tilesN;
+    L.D = l == 0 ? p.Ht + 3 : p.Hn; L.DP = (int)up8(L.D); L.H = p.Hn; L.tiles = p.tilesN; L.dtype = cfg->dtype;
     L.dW = take((int64_t)p.SU * L.D); L.db = take(L.D);
     L.W = take((int64_t)L.D * 4 * L.H); L.U = take((int64_t)L.H * 4 * L.H); L.b = take(4 * L.H);
   }
@@ -199,7 +200,9 @@ struct Ctx {
 inline bool fuse_xw(const LstmP& L) {
   const char* e = getenv("DEEPJ_FUSE_XW_MIN_TILES");
   const int64_t min_tiles = e ? atoll(e) : 128;
-  return rec_persistent(L.H) && L.D <= 2 * L.H && L.tiles >= min_tiles;
+  // H = 128 in bf16 keeps W and U in registers, which holds inputs up to H columns
+  const int dmax = (L.H == 128 && L.dtype == DJ_BF16) ? L.H : 2 * L.H;
+  return rec_persistent(L.H) && L.D <= dmax && L.tiles >= min_tiles;
 }
 
 // weight conversion/packing for one LSTM layer

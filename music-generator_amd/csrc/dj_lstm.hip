@@ -72,6 +72,11 @@ template <typename T, int H> struct RecCfg {
   // registers for the whole BPTT sweep -- one wave per SIMD has the register file for it -- so the
   // recurrence streams no weights at all
   static constexpr bool STATB = sizeof(T) == 2 && H == 128 && DJ_EXP_STATB;
+#ifndef DJ_EXP_STATF
+#define DJ_EXP_STATF 1
+#endif
+  // same for the forward kernels: U (and W when the input is at most 128 wide) as 128 registers each
+  static constexpr bool STATF = sizeof(T) == 2 && H == 128 && DJ_EXP_STATF;
 };
 
 // raw workgroup barrier: waits for this wave's LDS traffic only, so global prefetches
@@ -177,6 +182,14 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_kernel(T* __restrict__ Z, cons
   };
   auto caddr = [&](int64_t rb, int j) { return Cout + ((rb * R::NCBH + (w * R::UW + j * 32) / 32) * 64 + lane) * 16; };
 
+  Frag uf[R::STATF ? R::NKC : 1][4];
+  if constexpr (R::STATF) {
+    static_assert(R::NJ == 1, "stationary U assumes one column tile per gate and wave");
+#pragma unroll
+    for (int kc = 0; kc < R::NKC; ++kc)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) uf[kc][q] = up[(q * R::NKC + kc) * 64];
+  }
   Frag16<T> zin[4][R::NJ];
   if constexpr (R::HOIST) {
 #pragma unroll
@@ -210,7 +223,17 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_kernel(T* __restrict__ Z, cons
           for (int j = 0; j < R::NJ; ++j) zin[g][j].load(zaddr(rb + 1, g, j));
       }
     }
-    if (t > 0) {
+    if constexpr (R::STATF) {
+      if (t > 0) {
+        const T* hp = hs[cur] + l31 * R::LDH;
+#pragma unroll
+        for (int kc = 0; kc < R::NKC; ++kc) {
+          Frag a = dj_lds_frag(hp + kc * R::KC, h);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dj_mfma(acc[q][0], a, uf[kc][q]);
+        }
+      }
+    } else if (t > 0) {
       const T* hp = hs[cur] + l31 * R::LDH;
       Frag bq[R::PD][4 * R::NJ];
 #pragma unroll
@@ -314,11 +337,24 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
   for (int g = 0; g < 4; ++g) bv[g] = bias[g * H + w * R::UW + l31];
   const Frag* up = (const Frag*)Upack + (int64_t)w * 4 * R::NKC * 64 + lane;
   const Frag* wp = (const Frag*)Wpack + (int64_t)w * 4 * NKX * 64 + lane;
+  // stationary weights (bf16, H = 128): U always, W when its NKX k-chunks fit the same 8-chunk budget
+  constexpr int NKS = R::STATF ? R::NKC : 1;      // the launcher guarantees NKX == NKC for STATF builds
+  Frag uf[NKS][4], wf[NKS][4];
+  if constexpr (R::STATF) {
+#pragma unroll
+    for (int kc = 0; kc < NKS; ++kc)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uf[kc][q] = up[(q * R::NKC + kc) * 64];
+        wf[kc][q] = wp[(q * NKX + kc) * 64];
+      }
+  }
   auto zaddr = [&](int64_t rb, int g) { return Zst + ((rb * R::NCB + (g * H + w * R::UW) / 32) * 64 + lane) * 16; };
   auto caddr = [&](int64_t rb) { return Cout + ((rb * R::NCBH + (w * R::UW) / 32) * 64 + lane) * 16; };
 
   // X tile staging: NVX 16-byte vectors per tile, up to NVMAX per thread
-  constexpr int NVMAX = (32 * FUSED_DPMAX / R::EPL + R::NT - 1) / R::NT;
+  constexpr int DPMAX = R::STATF ? H : FUSED_DPMAX;       // stationary-weight builds take inputs up to H wide
+  constexpr int NVMAX = (32 * DPMAX / R::EPL + R::NT - 1) / R::NT;
   const int vpr = DP / R::EPL, nvx = 32 * vpr;
   // The staged vectors travel by value (struct return / argument): as a loop-carried array written
   // through a by-reference lambda they were kept in scratch memory, and the scratch store right
@@ -357,7 +393,24 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[g][r] = bv[g];
-    {   // one continuous fragment stream: NKX chunks of x_t * W, then (t > 0) NKC chunks of h_{t-1} * U
+    if constexpr (R::STATF) {   // both operand sets in registers: no weight traffic in the recurrence
+      const T* xp = xs + l31 * LDX;
+      const T* hp = hs0 + cur * 32 * R::LDH + l31 * R::LDH;
+#pragma unroll
+      for (int kc = 0; kc < NKS; ++kc) {
+        Frag a = dj_lds_frag(xp + kc * R::KC, h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dj_mfma(acc[q], a, wf[kc][q]);
+      }
+      if (t > 0) {
+#pragma unroll
+        for (int kc = 0; kc < NKS; ++kc) {
+          Frag a = dj_lds_frag(hp + kc * R::KC, h);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dj_mfma(acc[q], a, uf[kc][q]);
+        }
+      }
+    } else {   // one continuous fragment stream: NKX chunks of x_t * W, then (t > 0) NKC chunks of h_{t-1} * U
       const T* xp = xs + l31 * LDX;
       const T* hp = hs0 + cur * 32 * R::LDH + l31 * R::LDH;
       const int ntot = NKX + (t > 0 ? R::NKC : 0);          // NKX and NKC are multiples of PD
@@ -724,6 +777,7 @@ int launch_fwd_fused_s(int ntiles, int steps, const void* X, int DP, int NKX, co
   using R = RecCfg<T, H>;
   const size_t smem = ((size_t)2 * 32 * R::LDH + (size_t)2 * 32 * (NKX * R::KC + R::EPL)) * sizeof(T);
   if (smem > 160 * 1024 || DP > FUSED_DPMAX || DP % R::EPL || NKX % R::PD || NKX * R::KC < DP) return 1011;
+  if (R::STATF && (NKX != R::NKC || DP > H)) return 1014;    // stationary-weight build: input at most H wide
   static size_t attr = 0;
   if (smem > attr) {
     hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_fused_kernel<T, H, SIGM>,

@@ -251,7 +251,8 @@ def test_nadam_matches_oracle(gpu_device):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-@pytest.mark.parametrize("H,S,Ls,D", [(256, 64, 5, 94), (128, 40, 6, 259), (256, 32, 3, 256), (128, 96, 4, 128)])
+@pytest.mark.parametrize("H,S,Ls,D", [(256, 64, 5, 94), (128, 40, 6, 259), (256, 32, 3, 256), (128, 96, 4, 128),
+                                      (128, 40, 6, 90)])
 def test_lstm_fwd_fused_input_projection(gpu_device, dtype, H, S, Ls, D):
     """z = x W + h U + b inside the recurrent kernel (dj_lstm_fwd_fused) vs the restated cell."""
     L, lib = _lib()
@@ -281,8 +282,14 @@ def test_lstm_fwd_fused_input_projection(gpu_device, dtype, H, S, Ls, D):
     Zd = torch.zeros(R * 4 * H, dtype=Xd.dtype, device=gpu_device)
     Hd = torch.zeros(R, H, dtype=Xd.dtype, device=gpu_device)
     Cd = torch.zeros(R * H, dtype=Xd.dtype, device=gpu_device)
-    L.check(lib.dj_lstm_fwd_fused(DT[dtype], H, tiles, Ls, L.ptr(Xd), DP, D, L.ptr(wpack), L.ptr(b.to(gpu_device)),
-                                  L.ptr(Zd), L.ptr(upf), L.ptr(Hd), L.ptr(Cd), 0, _st()), "fwd_fused")
+    rc = lib.dj_lstm_fwd_fused(DT[dtype], H, tiles, Ls, L.ptr(Xd), DP, D, L.ptr(wpack), L.ptr(b.to(gpu_device)),
+                               L.ptr(Zd), L.ptr(upf), L.ptr(Hd), L.ptr(Cd), 0, _st())
+    if dtype == "bf16" and H == 128 and D > 128:
+        # the bf16 H = 128 build keeps W and U in registers and takes inputs up to H columns; wider inputs are
+        # refused (the library runs those layers as GEMM + recurrent kernel)
+        assert rc == 1014
+        return
+    L.check(rc, "fwd_fused")
     rt, at = _tol(dtype)
     torch.testing.assert_close(from_rows(Hd.float().cpu(), S, Ls), Href, rtol=rt, atol=at * 5)
     torch.testing.assert_close(from_rows(from_frag(Cd.float().cpu(), R, H), S, Ls), Cref, rtol=rt, atol=at * 5)
