@@ -167,7 +167,7 @@ int32_t dj_lstm_fwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, voi
  * z_t = x_t W + h_{t-1} U + b with X row-major [rows, DP] (D valid columns), W packed by
  * dj_lstm_pack_w (at most 4H * (roundup(D, 8) + 128) operand elements),
  * bias[4H] fp32.  Zstash (fragment-tiled, may be NULL) receives the pre-activations.  The bf16 build for
- * H = 128 keeps W and U in registers and accepts D <= 128 only (code 1014 otherwise). */
+ * H = 128 keeps U (and W for D <= 128) in registers. */
 int32_t dj_lstm_pack_w(int32_t dtype, int32_t H, const float* W, int32_t D, void* wpack, void* stream);
 int32_t dj_lstm_fwd_fused(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* X, int32_t DP,
                           int32_t D, const void* wpack, const float* bias, void* Zstash, const void* upack_fwd,

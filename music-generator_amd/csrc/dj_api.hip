@@ -200,8 +200,11 @@ struct Ctx {
 inline bool fuse_xw(const LstmP& L) {
   const char* e = getenv("DEEPJ_FUSE_XW_MIN_TILES");
   const int64_t min_tiles = e ? atoll(e) : 128;
-  // H = 128 in bf16 keeps W and U in registers, which holds inputs up to H columns
-  const int dmax = (L.H == 128 && L.dtype == DJ_BF16) ? L.H : 2 * L.H;
+  // H = 128 in bf16 keeps U (and W up to H columns) in registers: also the 259-wide note layer 0 is cheaper fused
+#ifndef DJ_EXP_DMAX128
+#define DJ_EXP_DMAX128 288
+#endif
+  const int dmax = (L.H == 128 && L.dtype == DJ_BF16) ? DJ_EXP_DMAX128 : 2 * L.H;
   return rec_persistent(L.H) && L.D <= dmax && L.tiles >= min_tiles;
 }
 

@@ -314,7 +314,9 @@ __global__ void pack_w_fwd_kernel(const float* __restrict__ W, int D, int NKX, T
 
 constexpr int FUSED_DPMAX = 288;   // widest layer input supported by the register prefetch (259 -> 264 here)
 
-template <typename T, int H, bool SIGM>
+// WSTAT (stationary-weight builds only): W is held in registers as well (inputs up to H wide); otherwise W
+// is streamed through an 8-deep fragment ring in front of the stationary U product.
+template <typename T, int H, bool SIGM, bool WSTAT>
 __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restrict__ X, int DP, int NKX,
                                                                const T* __restrict__ Wpack,
                                                                const float* __restrict__ bias, T* __restrict__ Zst,
@@ -338,22 +340,23 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
   const Frag* up = (const Frag*)Upack + (int64_t)w * 4 * R::NKC * 64 + lane;
   const Frag* wp = (const Frag*)Wpack + (int64_t)w * 4 * NKX * 64 + lane;
   // stationary weights (bf16, H = 128): U always, W when its NKX k-chunks fit the same 8-chunk budget
-  constexpr int NKS = R::STATF ? R::NKC : 1;      // the launcher guarantees NKX == NKC for STATF builds
-  Frag uf[NKS][4], wf[NKS][4];
+  constexpr int NKS = R::STATF ? R::NKC : 1;      // WSTAT: the launcher guarantees NKX == NKC
+  constexpr int NKW = (R::STATF && WSTAT) ? R::NKC : 1;
+  Frag uf[NKS][4], wf[NKW][4];
   if constexpr (R::STATF) {
 #pragma unroll
     for (int kc = 0; kc < NKS; ++kc)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         uf[kc][q] = up[(q * R::NKC + kc) * 64];
-        wf[kc][q] = wp[(q * NKX + kc) * 64];
+        if constexpr (WSTAT) wf[kc][q] = wp[(q * NKX + kc) * 64];
       }
   }
   auto zaddr = [&](int64_t rb, int g) { return Zst + ((rb * R::NCB + (g * H + w * R::UW) / 32) * 64 + lane) * 16; };
   auto caddr = [&](int64_t rb) { return Cout + ((rb * R::NCBH + (w * R::UW) / 32) * 64 + lane) * 16; };
 
   // X tile staging: NVX 16-byte vectors per tile, up to NVMAX per thread
-  constexpr int DPMAX = R::STATF ? H : FUSED_DPMAX;       // stationary-weight builds take inputs up to H wide
+  constexpr int DPMAX = (R::STATF && WSTAT) ? H : FUSED_DPMAX;   // WSTAT builds take inputs up to H wide
   constexpr int NVMAX = (32 * DPMAX / R::EPL + R::NT - 1) / R::NT;
   const int vpr = DP / R::EPL, nvx = 32 * vpr;
   // The staged vectors travel by value (struct return / argument): as a loop-carried array written
@@ -393,14 +396,36 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[g][r] = bv[g];
-    if constexpr (R::STATF) {   // both operand sets in registers: no weight traffic in the recurrence
+    if constexpr (R::STATF) {   // U (and W if WSTAT) in registers: little or no weight traffic in the recurrence
       const T* xp = xs + l31 * LDX;
       const T* hp = hs0 + cur * 32 * R::LDH + l31 * R::LDH;
+      if constexpr (WSTAT) {
 #pragma unroll
-      for (int kc = 0; kc < NKS; ++kc) {
-        Frag a = dj_lds_frag(xp + kc * R::KC, h);
+        for (int kc = 0; kc < NKS; ++kc) {
+          Frag a = dj_lds_frag(xp + kc * R::KC, h);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dj_mfma(acc[q], a, wf[kc][q]);
+          for (int q = 0; q < 4; ++q) dj_mfma(acc[q], a, wf[kc][q]);
+        }
+      } else {                  // wide input: W streamed, 8 fragments per gate in flight (NKX is a multiple of 8)
+        constexpr int PW = 8;
+        Frag bw[PW][4];
+#pragma unroll
+        for (int p = 0; p < PW; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bw[p][q] = wp[(q * NKX + p) * 64];
+#pragma unroll 1
+        for (int kc0 = 0; kc0 < NKX; kc0 += PW) {
+#pragma unroll
+          for (int uu = 0; uu < PW; ++uu) {
+            const int kc = kc0 + uu;
+            Frag a = dj_lds_frag(xp + kc * R::KC, h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dj_mfma(acc[q], a, bw[uu][q]);
+            const int kn = (kc + PW < NKX) ? kc + PW : NKX - 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bw[uu][q] = wp[(q * NKX + kn) * 64];
+          }
+        }
       }
       if (t > 0) {
 #pragma unroll
@@ -771,23 +796,34 @@ int launch_pack_w(const float* W, int D, int NKX, void* out, hipStream_t st) {
   hipLaunchKernelGGL((pack_w_fwd_kernel<T, H>), dim3((n + 255) / 256), dim3(256), 0, st, W, D, NKX, (T*)out);
   return (int)hipGetLastError();
 }
+template <typename T, int H, bool SIGM, bool WSTAT>
+int launch_fwd_fused_w(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
+                       void* Zst, const void* Upack, void* Hout, void* Cout, size_t smem, hipStream_t st) {
+  using R = RecCfg<T, H>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_fused_kernel<T, H, SIGM, WSTAT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((lstm_fwd_fused_kernel<T, H, SIGM, WSTAT>), dim3(ntiles), dim3(R::NT), smem, st, (const T*)X, DP,
+                     NKX, (const T*)Wpack, bias, (T*)Zst, (const T*)Upack, (T*)Hout, (T*)Cout, steps);
+  return (int)hipGetLastError();
+}
 template <typename T, int H, bool SIGM>
 int launch_fwd_fused_s(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
                        void* Zst, const void* Upack, void* Hout, void* Cout, hipStream_t st) {
   using R = RecCfg<T, H>;
   const size_t smem = ((size_t)2 * 32 * R::LDH + (size_t)2 * 32 * (NKX * R::KC + R::EPL)) * sizeof(T);
   if (smem > 160 * 1024 || DP > FUSED_DPMAX || DP % R::EPL || NKX % R::PD || NKX * R::KC < DP) return 1011;
-  if (R::STATF && (NKX != R::NKC || DP > H)) return 1014;    // stationary-weight build: input at most H wide
-  static size_t attr = 0;
-  if (smem > attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_fused_kernel<T, H, SIGM>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr = 160 * 1024;
+  if constexpr (R::STATF) {
+    // stationary-weight build: W in registers too when the input is at most H wide, else streamed 8 deep
+    if (NKX == R::NKC && DP <= H)
+      return launch_fwd_fused_w<T, H, SIGM, true>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, st);
+    if (NKX % 8) return 1014;
   }
-  hipLaunchKernelGGL((lstm_fwd_fused_kernel<T, H, SIGM>), dim3(ntiles), dim3(R::NT), smem, st, (const T*)X, DP, NKX,
-                     (const T*)Wpack, bias, (T*)Zst, (const T*)Upack, (T*)Hout, (T*)Cout, steps);
-  return (int)hipGetLastError();
+  return launch_fwd_fused_w<T, H, SIGM, false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, st);
 }
 template <typename T, int H>
 int launch_fwd_fused(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
@@ -821,8 +857,9 @@ int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, c
 
 // k-chunks of the fused input projection for a layer input of width D: ceil(D / KC) rounded up to the ring depth
 int dj_lstm_fused_nkx(int dtype, int H, int D) {
-  const int kc = dtype == DJ_F32 ? 8 : 16;                                           // RecCfg::KC
-  const int pd = dtype == DJ_F32 ? 2 : (H == 128 ? RecCfg<bf16_t, 128>::PD : 4);      // RecCfg::PD
+  const int kc = dtype == DJ_F32 ? 8 : 16;                                   // RecCfg::KC
+  int pd = dtype == DJ_F32 ? 2 : 4;                                          // RecCfg::PD
+  if (dtype != DJ_F32 && H == 128 && RecCfg<bf16_t, 128>::STATF) pd = 8;    // stationary build: 8 = NKC = W ring depth
   int n = (D + kc - 1) / kc;
   return (n + pd - 1) / pd * pd;
 }
