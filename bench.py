@@ -28,6 +28,14 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, MI355X_MICR
 PEAK_HBM_GBS = 8000.0                              # HBM3E, same guide
 
 
+def _fused_xw(cfg, d, H):
+    """Mirror of dj_api.hip fuse_xw at the bench shape (>= 128 sequence tiles): is x*W of a layer with input
+    width d and H units computed inside the recurrent forward kernel?"""
+    if H not in (128, 256):
+        return False
+    return d <= (288 if (H == 128 and cfg.dtype == "bf16") else 2 * H)
+
+
 def category_flops(cfg, B, T, N):
     """ALGORITHMIC FLOPs (2*MAC) per training step of each MFMA kernel category
     (SURVEY.md 8d formulas, generalised to the config)."""
@@ -42,8 +50,8 @@ def category_flops(cfg, B, T, N):
     rec_n = cfg.note_axis_layers * 2 * rows * Hn * 4 * Hn
     # the forward recurrent kernel carries the input projection x*W of every layer with D <= 2H
     # (dj_api.hip fuse_xw); the others keep a separate GEMM launch (category gemm_xw)
-    fx_t = sum(2 * rows * d * 4 * Ht for d in t_in if d <= 2 * Ht)
-    fx_n = sum(2 * rows * d * 4 * Hn for d in n_in if d <= 2 * Hn)
+    fx_t = sum(2 * rows * d * 4 * Ht for d in t_in if _fused_xw(cfg, d, Ht))
+    fx_n = sum(2 * rows * d * 4 * Hn for d in n_in if _fused_xw(cfg, d, Hn))
     return {
         "gemm_xw": xw - fx_t - fx_n, "gemm_dx": xw, "gemm_dw": xw + rec_t + rec_n, "lstm_fwd_time": rec_t + fx_t,
         "lstm_bwd_time": rec_t, "lstm_fwd_note": rec_n + fx_n, "lstm_bwd_note": rec_n,
@@ -65,7 +73,7 @@ def category_bytes(cfg, B, T, N, esize):
                           "lstm_bwd_note")}
     for axis, H, dims in (("time", Ht, t_in), ("note", Hn, n_in)):
         for d in dims:
-            fused = d <= 2 * H
+            fused = _fused_xw(cfg, d, H)
             out["lstm_fwd_" + axis] += rows * esize * ((d + 6 * H) if fused else 10 * H)
             if not fused:
                 out["gemm_xw"] += rows * esize * (d + 4 * H)
@@ -77,7 +85,11 @@ def category_bytes(cfg, B, T, N, esize):
 
 def launches_per_step(cfg):
     Lt, Ln = cfg.time_axis_layers, cfg.note_axis_layers
-    return {"gemm_xw": 1, "gemm_dx": Lt + Ln, "gemm_dw": Lt + Ln, "lstm_fwd_time": Lt,
+    F = 1 + cfg.octave + 1 + cfg.octave_units + cfg.notes_per_bar
+    dims = [(d, cfg.time_axis_units) for d in [F] + [cfg.time_axis_units] * (Lt - 1)]
+    dims += [(d, cfg.note_axis_units) for d in [cfg.time_axis_units + cfg.note_units] + [cfg.note_axis_units] * (Ln - 1)]
+    unfused = sum(not _fused_xw(cfg, d, H) for d, H in dims)
+    return {"gemm_xw": max(1, unfused), "gemm_dx": Lt + Ln, "gemm_dw": Lt + Ln, "lstm_fwd_time": Lt,
             "lstm_bwd_time": Lt, "lstm_fwd_note": Ln, "lstm_bwd_note": Ln}
 
 
