@@ -177,6 +177,14 @@ int32_t dj_lstm_fwd_fused(int32_t dtype, int32_t H, int32_t ntiles, int32_t step
  * dbias[4H] += column sums of dz. */
 int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack_bwd,
                     const void* C, const void* dH, void* dZ, float* dbias, int32_t recurrent_sigmoid, void* stream);
+/* Same sweep that also produces the layer's input gradient dX = dz W^T (row-major [rows, DP], columns
+ * D..DP-1 zero) from the dz tile it holds in LDS; W is the Keras kernel [D, 4H], wtpack its fragment stream
+ * from dj_lstm_pack_wt (roundup(D, 32) * 4H operand elements).  Replaces one dj_gemm_nt pass over dZ per layer
+ * (TF autodiff's dX of model.py:84,122).  Offered by the bf16 H = 128 build for D <= 128 only (code 1015 otherwise). */
+int32_t dj_lstm_pack_wt(int32_t dtype, int32_t H, const float* W, int32_t D, void* wtpack, void* stream);
+int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack_bwd,
+                       const void* C, const void* dH, void* dZ, float* dbias, int32_t recurrent_sigmoid,
+                       const void* wtpack, int32_t D, void* dX, int32_t DP, void* stream);
 /* mask[rows, cols] (fp32 0 or 1/(1-p)) of dropout site `site` -- exposes the counter
  * hash so tests can pin it against the oracle. */
 int32_t dj_dropout_mask(uint64_t seed, int32_t site, float p, int64_t rows, int32_t cols, float* mask, void* stream);

@@ -66,8 +66,8 @@ struct Plan {
   LstmP tl[MAXL], nl[MAXL];
   // workspace offsets (bytes)
   int64_t w_style, w_dstyle, w_bins, w_sp_t[MAXL], w_sp_n[MAXL], w_dpre_t[MAXL], w_dpre_n[MAXL];
-  int64_t w_Wt_t[MAXL], w_Wc_t[MAXL], w_Uf_t[MAXL], w_Ub_t[MAXL];
-  int64_t w_Wt_n[MAXL], w_Wc_n[MAXL], w_Uf_n[MAXL], w_Ub_n[MAXL];
+  int64_t w_Wt_t[MAXL], w_Wc_t[MAXL], w_Uf_t[MAXL], w_Ub_t[MAXL], w_Wp_t[MAXL];
+  int64_t w_Wt_n[MAXL], w_Wc_n[MAXL], w_Uf_n[MAXL], w_Ub_n[MAXL], w_Wp_n[MAXL];
   int64_t w_X_t[MAXL], w_Z_t[MAXL], w_H_t[MAXL], w_C_t[MAXL];
   int64_t w_X_n[MAXL], w_Z_n[MAXL], w_H_n[MAXL], w_C_n[MAXL];
   int64_t w_dH_t, w_dX_t, w_dH_n, w_dX_n, w_featin, w_dZ_t, w_dZ_n, w_zero, w_Xcol, w_Ycol, w_step;
@@ -135,6 +135,7 @@ int make_plan(const dj_config* cfg, Plan& p) {
     p.w_sp_t[l] = wtake(p.BT * L.D * 4); p.w_dpre_t[l] = wtake(p.BT * L.D * 4);
     p.w_Wt_t[l] = wtake((int64_t)4 * L.H * (L.DP + 128) * p.esz); p.w_Wc_t[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
     p.w_Uf_t[l] = wtake((int64_t)L.H * 4 * L.H * p.esz); p.w_Ub_t[l] = wtake((int64_t)L.H * 4 * L.H * p.esz);
+    p.w_Wp_t[l] = wtake((int64_t)(L.D + 31) / 32 * 32 * 4 * L.H * p.esz);
     p.w_X_t[l] = wtake(p.Mt * L.DP * p.esz); p.w_Z_t[l] = wtake(p.Mt * 4 * L.H * p.esz);
     p.w_H_t[l] = wtake(p.Mt * L.H * p.esz); p.w_C_t[l] = wtake(p.Mt * L.H * p.esz);
     if (L.DP > maxDPt) maxDPt = L.DP;
@@ -144,6 +145,7 @@ int make_plan(const dj_config* cfg, Plan& p) {
     p.w_sp_n[l] = wtake(p.BT * L.D * 4); p.w_dpre_n[l] = wtake(p.BT * L.D * 4);
     p.w_Wt_n[l] = wtake((int64_t)4 * L.H * (L.DP + 128) * p.esz); p.w_Wc_n[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
     p.w_Uf_n[l] = wtake((int64_t)L.H * 4 * L.H * p.esz); p.w_Ub_n[l] = wtake((int64_t)L.H * 4 * L.H * p.esz);
+    p.w_Wp_n[l] = wtake((int64_t)(L.D + 31) / 32 * 32 * 4 * L.H * p.esz);
     p.w_X_n[l] = wtake(p.Mn * L.DP * p.esz); p.w_Z_n[l] = wtake(p.Mn * 4 * L.H * p.esz);
     p.w_H_n[l] = wtake(p.Mn * L.H * p.esz); p.w_C_n[l] = wtake(p.Mn * L.H * p.esz);
     if (L.DP > maxDPn) maxDPn = L.DP;
@@ -208,8 +210,16 @@ inline bool fuse_xw(const LstmP& L) {
   return rec_persistent(L.H) && L.D <= dmax && L.tiles >= min_tiles;
 }
 
+// Where the BPTT kernel offers it (bf16, H = 128, D <= H: U^T and W^T both stationary in registers) it also
+// produces dX = dz W^T, which replaces one GEMM pass over dZ for that layer.  DEEPJ_FUSE_DX=0 keeps the GEMM.
+inline bool fuse_dx(const LstmP& L) {
+  const char* e = getenv("DEEPJ_FUSE_DX");
+  return rec_persistent(L.H) && dj_lstm_bwd_has_dx(L.dtype, L.H, L.D) && !(e && e[0] == '0');
+}
+
 // weight conversion/packing for one LSTM layer
-int prep_layer(const Ctx& c, const LstmP& L, int64_t wWt, int64_t wWc, int64_t wUf, int64_t wUb, bool need_bwd) {
+int prep_layer(const Ctx& c, const LstmP& L, int64_t wWt, int64_t wWc, int64_t wUf, int64_t wUb, int64_t wWp,
+               bool need_bwd) {
   const int dt = c.p.c.dtype;
   ProfScope ps(PC_PREP, c.st);
   if (fuse_xw(L))   // input kernel W as MFMA B fragments for the fused x*W inside the recurrent kernel
@@ -222,7 +232,10 @@ int prep_layer(const Ctx& c, const LstmP& L, int64_t wWt, int64_t wWc, int64_t w
     RUN(dj_launch_cvt_transpose(dt, c.P + L.U, L.H, 4 * L.H, c.at(wUf), L.H, c.st));
     if (need_bwd && dt != DJ_F32) RUN(dj_launch_cvt_copy(dt, c.P + L.U, (int64_t)L.H * 4 * L.H, c.at(wUb), c.st));
   }
-  if (need_bwd && dt != DJ_F32) RUN(dj_launch_cvt_copy(dt, c.P + L.W, (int64_t)L.D * 4 * L.H, c.at(wWc), c.st));
+  if (need_bwd && fuse_dx(L))
+    RUN(dj_launch_lstm_pack_wt(dt, L.H, c.P + L.W, L.D, c.at(wWp), c.st));
+  else if (need_bwd && dt != DJ_F32)
+    RUN(dj_launch_cvt_copy(dt, c.P + L.W, (int64_t)L.D * 4 * L.H, c.at(wWc), c.st));
   return 0;
 }
 
@@ -350,13 +363,16 @@ int note_axis_forward(const Ctx& c, int64_t wHin, int in_na, int d_out_site, con
 }
 
 int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int steps, int64_t M, int64_t wX,
-                   int64_t wWc, int64_t wUb, int64_t wZ, int64_t wH, int64_t wC, int64_t wdH, int64_t wdX, int64_t wdZ, bool is_note) {
+                   int64_t wWc, int64_t wWp, int64_t wUb, int64_t wZ, int64_t wH, int64_t wC, int64_t wdH, int64_t wdX,
+                   int64_t wdZ, bool is_note) {
   const int dt = c.p.c.dtype;
+  const bool fdx = fuse_dx(L);
   {
     ProfScope ps(is_note ? PC_LSTM_BWD_NOTE : PC_LSTM_BWD_TIME, c.st);
     if (rec_persistent(L.H)) {
       RUN(dj_launch_lstm_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUb), c.at(wC), c.at(wdH), c.at(wdZ), G + L.b,
-                             c.p.c.recurrent_sigmoid, c.st));
+                             c.p.c.recurrent_sigmoid, fdx ? c.at(wWp) : nullptr, L.D, fdx ? c.at(wdX) : nullptr, L.DP,
+                             c.st));
     } else {
       const void* Uc = dt == DJ_F32 ? (const void*)(c.P + L.U) : (const void*)c.at(wUb);
       RUN(dj_launch_lstm_step_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), Uc, c.at(wC), c.at(wdH), c.at(wdZ), G + L.b,
@@ -368,6 +384,7 @@ int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int st
     RUN(dj_launch_lstm_wgrad(dt, M, steps, c.at(wX), L.DP, L.D, c.at(wH), L.H, c.at(wdZ), 4 * L.H, G + L.W, G + L.U,
                              c.at(c.p.w_zero), c.st));
   }
+  if (fdx) return 0;
   const void* Bt = dt == DJ_F32 ? (const void*)(c.P + L.W) : (const void*)c.at(wWc);
   ProfScope ps(PC_GEMM_DX, c.st);
   RUN(dj_launch_gemm_nt(dt, (int)M, L.D, 4 * L.H, c.at(wdZ), 4 * L.H, Bt, 4 * L.H, c.at(wdX), L.DP, 0, nullptr, c.st));
@@ -473,8 +490,8 @@ int32_t dj_train_fwd_bwd_acc(const dj_config* cfg, const float* params, float* g
   float* G = grads;
   if (!accumulate) DJ_CHECK(hipMemsetAsync(G, 0, p.nparams * sizeof(float), c.st));   // every gradient kernel adds into G
   DJ_CHECK(hipMemsetAsync(loss, 0, sizeof(float), c.st));
-  for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], true));
-  for (int l = 0; l < p.Ln; ++l) RUN(prep_layer(c, p.nl[l], p.w_Wt_n[l], p.w_Wc_n[l], p.w_Uf_n[l], p.w_Ub_n[l], true));
+  for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], p.w_Wp_t[l], true));
+  for (int l = 0; l < p.Ln; ++l) RUN(prep_layer(c, p.nl[l], p.w_Wt_n[l], p.w_Wc_n[l], p.w_Uf_n[l], p.w_Ub_n[l], p.w_Wp_n[l], true));
 
   // ---------------- forward
   RUN(style_forward(c, style));
@@ -485,7 +502,7 @@ int32_t dj_train_fwd_bwd_acc(const dj_config* cfg, const float* params, float* g
   const float pin = p.c.input_dropout, pdr = p.c.dropout;
   for (int l = p.Ln - 1; l >= 0; --l) {
     const LstmP& L = p.nl[l];
-    RUN(lstm_layer_bwd(c, L, G, p.tilesN, p.N, p.Mn, p.w_X_n[l], p.w_Wc_n[l], p.w_Ub_n[l], p.w_Z_n[l], p.w_H_n[l],
+    RUN(lstm_layer_bwd(c, L, G, p.tilesN, p.N, p.Mn, p.w_X_n[l], p.w_Wc_n[l], p.w_Wp_n[l], p.w_Ub_n[l], p.w_Z_n[l], p.w_H_n[l],
                        p.w_C_n[l], p.w_dH_n, p.w_dX_n, p.w_dZ_n, true));
     GlueArgs g;
     g.B = p.B; g.T = p.T; g.N = p.N; g.D = L.D; g.DP = L.DP; g.out_na = 1;
@@ -506,7 +523,7 @@ int32_t dj_train_fwd_bwd_acc(const dj_config* cfg, const float* params, float* g
   }
   for (int l = p.Lt - 1; l >= 0; --l) {
     const LstmP& L = p.tl[l];
-    RUN(lstm_layer_bwd(c, L, G, p.tilesT, p.T, p.Mt, p.w_X_t[l], p.w_Wc_t[l], p.w_Ub_t[l], p.w_Z_t[l], p.w_H_t[l],
+    RUN(lstm_layer_bwd(c, L, G, p.tilesT, p.T, p.Mt, p.w_X_t[l], p.w_Wc_t[l], p.w_Wp_t[l], p.w_Ub_t[l], p.w_Z_t[l], p.w_H_t[l],
                        p.w_C_t[l], p.w_dH_t, p.w_dX_t, p.w_dZ_t, false));
     if (l > 0) {
       GlueArgs g;
@@ -570,8 +587,8 @@ int32_t dj_predict(const dj_config* cfg, const float* params, const float* notes
   if (!params || !notes || !chosen || !beat || !style || !out) return 1210;
   if (target && !loss) return 1211;
   Ctx c{p, params, (char*)ws, (hipStream_t)stream, false, 0};
-  for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], false));
-  for (int l = 0; l < p.Ln; ++l) RUN(prep_layer(c, p.nl[l], p.w_Wt_n[l], p.w_Wc_n[l], p.w_Uf_n[l], p.w_Ub_n[l], false));
+  for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], p.w_Wp_t[l], false));
+  for (int l = 0; l < p.Ln; ++l) RUN(prep_layer(c, p.nl[l], p.w_Wt_n[l], p.w_Wc_n[l], p.w_Uf_n[l], p.w_Ub_n[l], p.w_Wp_n[l], false));
   if (target) DJ_CHECK(hipMemsetAsync(loss, 0, sizeof(float), c.st));
   RUN(style_forward(c, style));
   RUN(time_axis_forward(c, notes, beat));
@@ -586,7 +603,7 @@ int32_t dj_time_model_predict(const dj_config* cfg, const float* params, const f
   RUN(check_ws(p, ws, ws_bytes));
   if (!params || !notes || !beat || !style || !time_out) return 1210;
   Ctx c{p, params, (char*)ws, (hipStream_t)stream, false, 0};
-  for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], false));
+  for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], p.w_Wp_t[l], false));
   RUN(style_forward(c, style));
   RUN(time_axis_forward(c, notes, beat));
   return dj_launch_ta_to_canonical(p.c.dtype, c.at(p.w_H_t[p.Lt - 1]), time_out, p.B, p.T, p.N, p.Ht, c.st);
@@ -599,7 +616,7 @@ int32_t dj_note_model_predict(const dj_config* cfg, const float* params, const f
   RUN(check_ws(p, ws, ws_bytes));
   if (!params || !features || !chosen || !style || !out) return 1210;
   Ctx c{p, params, (char*)ws, (hipStream_t)stream, false, 0};
-  for (int l = 0; l < p.Ln; ++l) RUN(prep_layer(c, p.nl[l], p.w_Wt_n[l], p.w_Wc_n[l], p.w_Uf_n[l], p.w_Ub_n[l], false));
+  for (int l = 0; l < p.Ln; ++l) RUN(prep_layer(c, p.nl[l], p.w_Wt_n[l], p.w_Wc_n[l], p.w_Uf_n[l], p.w_Ub_n[l], p.w_Wp_n[l], false));
   RUN(style_forward(c, style));
   RUN(dj_launch_canonical_to_na(p.c.dtype, features, c.at(p.w_featin), p.B, p.T, p.N, p.Ht, c.st));
   RUN(note_axis_forward(c, p.w_featin, 1, -1, chosen, nullptr, out, nullptr, nullptr));
@@ -625,7 +642,7 @@ int32_t dj_generate_step(const dj_config* cfg, const float* params, const float*
   const int64_t need = (int64_t)(8 * 64 + 4 * 8 * 512 + (int64_t)p.B * p.N * 4 * p.Hn) * 4;
   if (need > p.Mn * (int64_t)p.nl[0].DP * p.esz) return 1302;       // scratch lives in the (unused) dX_n area
   Ctx c{p, params, (char*)ws, (hipStream_t)stream, false, 0};
-  for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], false));
+  for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], p.w_Wp_t[l], false));
   RUN(style_forward(c, style_win));
   RUN(time_axis_forward(c, notes_win, beat_win));                   // generate.py:106-109 (whole window, last step used)
   int64_t offs[6 + 5 * MAXL];
@@ -656,7 +673,7 @@ int32_t dj_generate_step_resident(const dj_config* cfg, const float* params, voi
   const int64_t need = (int64_t)(8 * 64 + 4 * 8 * 512 + (int64_t)p.B * p.N * 4 * p.Hn) * 4;
   if (need > p.Mn * (int64_t)p.nl[0].DP * p.esz) return 1302;
   Ctx c{p, params, (char*)ws, (hipStream_t)stream, false, 0};
-  for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], false));
+  for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], p.w_Wp_t[l], false));
   RUN(style_forward(c, style_win));
   RUN(time_axis_forward(c, notes_src, beat_src));
   int64_t offs[6 + 5 * MAXL];
@@ -732,7 +749,17 @@ int32_t dj_lstm_fwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, voi
 }
 int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack,
                     const void* C, const void* dH, void* dZ, float* dbias, int32_t sigm, void* stream) {
-  return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dbias, sigm, (hipStream_t)stream);
+  return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dbias, sigm, nullptr, 0, nullptr, 0, (hipStream_t)stream);
+}
+int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack,
+                       const void* C, const void* dH, void* dZ, float* dbias, int32_t sigm, const void* wtpack, int32_t D,
+                       void* dX, int32_t DP, void* stream) {
+  if (!wtpack) return 1013;
+  return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dbias, sigm, wtpack, D, dX, DP,
+                            (hipStream_t)stream);
+}
+int32_t dj_lstm_pack_wt(int32_t dtype, int32_t H, const float* W, int32_t D, void* out, void* stream) {
+  return dj_launch_lstm_pack_wt(dtype, H, W, D, out, (hipStream_t)stream);
 }
 
 __global__ void dropout_mask_kernel(DjDrop d, int64_t rows, int cols, float* mask) {

@@ -146,6 +146,13 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   bf16_t a = (bf16_t)lo, b = (bf16_t)hi;
   return (uint32_t)(*(const unsigned short*)&a) | ((uint32_t)(*(const unsigned short*)&b) << 16);
 }
+// 4 consecutive elements of one row as one 8-byte (bf16) / 16-byte (f32) store
+__device__ __forceinline__ void dj_store4(bf16_t* p, float a, float b, float c, float d) {
+  *(uint2*)p = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+}
+__device__ __forceinline__ void dj_store4(float* p, float a, float b, float c, float d) {
+  *(float4*)p = make_float4(a, b, c, d);
+}
 // write 16 fp32 values as a fragment (round to T)
 __device__ __forceinline__ void store_frag(float* p, const float (&x)[16]) {
 #pragma unroll

@@ -63,8 +63,13 @@ int dj_launch_lstm_wgrad(int dtype, int64_t M, int steps, const void* X, int DP,
 int dj_launch_lstm_pack(int dtype, int H, const float* U, void* fwd, void* bwd, hipStream_t st);
 int dj_launch_lstm_fwd(int dtype, int H, int ntiles, int steps, void* Z, const void* Upack, void* Hout, void* Cout,
                        int sigm, int store_z, hipStream_t st);
+// WTpack/D/dX/DP: optional fused input gradient dX = dz W^T (WTpack from dj_launch_lstm_pack_wt; null = off;
+// available where dj_lstm_bwd_has_dx says so)
 int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* UTpack, const void* C,
-                       const void* dH, void* dZ, float* dbias, int sigm, hipStream_t st);
+                       const void* dH, void* dZ, float* dbias, int sigm, const void* WTpack, int D, void* dX, int DP,
+                       hipStream_t st);
+int dj_lstm_bwd_has_dx(int dtype, int H, int D);
+int dj_launch_lstm_pack_wt(int dtype, int H, const float* W, int D, void* out, hipStream_t st);
 int dj_lstm_fused_nkx(int dtype, int H, int D);
 int dj_launch_lstm_pack_w(int dtype, int H, const float* W, int D, int NKX, void* out, hipStream_t st);
 int dj_launch_lstm_fwd_fused(int dtype, int H, int ntiles, int steps, const void* X, int DP, int NKX,

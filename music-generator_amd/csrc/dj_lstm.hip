@@ -158,6 +158,20 @@ __global__ void pack_u_bwd_kernel(const float* __restrict__ U, T* __restrict__ o
   out[idx] = dj_from_f32<T>(U[(int64_t)n * 4 * H + k]);
 }
 
+// WTpack[(q*NKCB + kc)*64 + lane][e] = W[d = q*32 + l31][k = kc*KC + EPL*h + e]  (W is the Keras kernel
+// [D, 4H]; rows d >= D are zero): the fragment stream of dX_t = dz_t W^T inside the BPTT kernel.
+template <typename T, int H>
+__global__ void pack_wt_bwd_kernel(const float* __restrict__ W, int D, int NQ, T* __restrict__ out) {
+  using R = RecCfg<T, H>;
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= NQ * 32 * 4 * H) return;
+  int e = idx % R::EPL, lane = (idx / R::EPL) % 64, rest = idx / (R::EPL * 64);
+  int kc = rest % R::NKCB, q = rest / R::NKCB;
+  int k = kc * R::KC + R::EPL * (lane >> 5) + e;
+  int d = q * 32 + (lane & 31);
+  out[idx] = dj_from_f32<T>(d < D ? W[(int64_t)d * 4 * H + k] : 0.f);
+}
+
 // ---------------------------------------------------------------- forward
 template <typename T, int H, bool SIGM>
 __global__ __launch_bounds__(2 * H) void lstm_fwd_kernel(T* __restrict__ Z, const T* __restrict__ Upack,
@@ -505,10 +519,15 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
 
 // ---------------------------------------------------------------- backward (BPTT)
 // Z: fragment-tiled pre-activations (read only); dZ: row-major [M,4H] output.
-template <typename T, int H, bool SIGM>
+// DX (stationary-U^T builds only): the kernel also produces the layer's input gradient dX_t = dz_t W^T from
+// the dz tile it holds in LDS -- with no U^T stream the W^T fragments are the only weight traffic of the step
+// and cost less vector-memory time than a separate GEMM pass over dZ in HBM.
+template <typename T, int H, bool SIGM, bool DX>
 __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z, const T* __restrict__ UTpack,
                                                        const T* __restrict__ C, const T* __restrict__ dH,
-                                                       T* __restrict__ dZ, float* __restrict__ dbias, int steps) {
+                                                       T* __restrict__ dZ, float* __restrict__ dbias, int steps,
+                                                       const T* __restrict__ WTpack, int NQ, T* __restrict__ dX,
+                                                       int DP) {
   using R = RecCfg<T, H>;
   using Frag = typename DjFrag<T>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -535,6 +554,14 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
     static_assert(R::NJ == 1, "stationary U^T assumes one column tile per wave");
 #pragma unroll
     for (int kc = 0; kc < R::NKCB; ++kc) ub[kc] = up[kc * 64];
+  }
+  Frag wts[DX ? R::NKCB : 1];
+  if constexpr (DX) {
+    static_assert(R::STATB, "fused dX needs the stationary-U^T build");
+    if (w < NQ) {
+#pragma unroll
+      for (int kc = 0; kc < R::NKCB; ++kc) wts[kc] = ((const Frag*)WTpack)[((int64_t)w * R::NKCB + kc) * 64 + lane];
+    }
   }
   auto zaddr = [&](int64_t rb, int g, int j) {
     return Z + ((rb * R::NCB + (g * H + w * R::UW + j * 32) / 32) * 64 + lane) * 16;
@@ -676,6 +703,29 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
       *(uint4*)(dZ + (rb * 32 + row) * (4 * H) + cv) = *(const uint4*)(dzs + row * R::LDZ + cv);
     }
     DJ_STAMP(1, 6, t);
+    if constexpr (DX) {
+      // dX_t = dz_t [32 x 4H] * W^T [4H x D], D <= H: wave w owns the 32-column block q = w, whose W^T slice
+      // is stationary in registers as well (wts, loaded before the sweep); operands are swapped so that a
+      // lane holds 4 consecutive columns of ONE row per register quad.  (Streaming W^T instead -- wider
+      // inputs -- was measured latency-bound at 16 fragments in flight per wave: +1.4 ms for -1.0 ms of GEMM.)
+      if (w < NQ) {
+        const T* apx = dzs + l31 * R::LDZ;
+        f32x16 ax;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ax[r] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < R::NKCB; ++kc) {
+          Frag a = dj_lds_frag(apx + kc * R::KC, h);
+          dj_mfma(ax, wts[kc], a);
+        }
+        T* xrow = dX + (rb * 32 + l31) * DP;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = w * 32 + 8 * g + 4 * h;
+          if (col < DP) dj_store4(xrow + col, ax[4 * g], ax[4 * g + 1], ax[4 * g + 2], ax[4 * g + 3]);
+        }
+      }
+    }
     if (t > 0) {
       // dh_{t-1} (recurrent part) = dz_t [32 x 4H] * U^T [4H x H]; this wave's H/4 output units
 #pragma unroll
@@ -764,30 +814,47 @@ int launch_fwd(int ntiles, int steps, void* Z, const void* Upack, void* Hout, vo
                        (T*)Hout, (T*)Cout, steps, store_z);
   return (int)hipGetLastError();
 }
-template <typename T, int H>
-int launch_bwd(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
-               float* dbias, int sigm, hipStream_t st) {
+template <typename T, int H, bool DX>
+int launch_bwd_x(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
+                 float* dbias, int sigm, const void* WTpack, int NQ, void* dX, int DP, hipStream_t st) {
   using R = RecCfg<T, H>;
   size_t smem = (size_t)32 * (R::LDZ + (R::HOIST ? R::LDH : 0)) * sizeof(T);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_kernel<T, H, false>,
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_kernel<T, H, false, DX>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)lstm_bwd_kernel<T, H, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+      e = hipFuncSetAttribute((const void*)lstm_bwd_kernel<T, H, true, DX>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
   if (sigm)
-    hipLaunchKernelGGL((lstm_bwd_kernel<T, H, true>), dim3(ntiles), dim3(R::NT), smem, st, (const T*)Z, (const T*)UTpack,
-                       (const T*)C, (const T*)dH, (T*)dZ, dbias, steps);
+    hipLaunchKernelGGL((lstm_bwd_kernel<T, H, true, DX>), dim3(ntiles), dim3(R::NT), smem, st, (const T*)Z,
+                       (const T*)UTpack, (const T*)C, (const T*)dH, (T*)dZ, dbias, steps, (const T*)WTpack, NQ, (T*)dX, DP);
   else
-    hipLaunchKernelGGL((lstm_bwd_kernel<T, H, false>), dim3(ntiles), dim3(R::NT), smem, st, (const T*)Z,
-                       (const T*)UTpack, (const T*)C, (const T*)dH, (T*)dZ, dbias, steps);
+    hipLaunchKernelGGL((lstm_bwd_kernel<T, H, false, DX>), dim3(ntiles), dim3(R::NT), smem, st, (const T*)Z,
+                       (const T*)UTpack, (const T*)C, (const T*)dH, (T*)dZ, dbias, steps, (const T*)WTpack, NQ, (T*)dX, DP);
   return (int)hipGetLastError();
 }
-
+template <typename T, int H>
+int launch_bwd(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
+               float* dbias, int sigm, const void* WTpack, int NQ, void* dX, int DP, hipStream_t st) {
+  if (WTpack) {
+    if constexpr (RecCfg<T, H>::STATB) {
+      if (NQ > RecCfg<T, H>::NW) return 1015;      // one stationary 32-column block per wave: D <= H
+      return launch_bwd_x<T, H, true>(ntiles, steps, Z, UTpack, C, dH, dZ, dbias, sigm, WTpack, NQ, dX, DP, st);
+    } else {
+      return 1015;      // fused dX exists for the stationary-U^T build only (bf16, H = 128)
+    }
+  }
+  return launch_bwd_x<T, H, false>(ntiles, steps, Z, UTpack, C, dH, dZ, dbias, sigm, nullptr, 0, nullptr, 0, st);
+}
+template <typename T, int H> int launch_pack_wt(const float* W, int D, int NQ, void* out, hipStream_t st) {
+  int n = NQ * 32 * 4 * H;
+  hipLaunchKernelGGL((pack_wt_bwd_kernel<T, H>), dim3((n + 255) / 256), dim3(256), 0, st, W, D, NQ, (T*)out);
+  return (int)hipGetLastError();
+}
 
 template <typename T, int H>
 int launch_pack_w(const float* W, int D, int NKX, void* out, hipStream_t st) {
@@ -850,9 +917,21 @@ int dj_launch_lstm_fwd(int dtype, int H, int ntiles, int steps, void* Z, const v
   DJ_DISPATCH_TH(launch_fwd, ntiles, steps, Z, Upack, Hout, Cout, sigm, store_z, st)
 }
 int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* UTpack, const void* C,
-                       const void* dH, void* dZ, float* dbias, int sigm, hipStream_t st) {
+                       const void* dH, void* dZ, float* dbias, int sigm, const void* WTpack, int D, void* dX, int DP,
+                       hipStream_t st) {
   if (ntiles <= 0 || steps <= 0) return 0;
-  DJ_DISPATCH_TH(launch_bwd, ntiles, steps, Z, UTpack, C, dH, dZ, dbias, sigm, st)
+  const int NQ = (D + 31) / 32;
+  if (WTpack && (!dX || D < 1 || DP < 8 || (DP % 8) || NQ * 32 < DP)) return 1013;
+  DJ_DISPATCH_TH(launch_bwd, ntiles, steps, Z, UTpack, C, dH, dZ, dbias, sigm, WTpack, NQ, dX, DP, st)
+}
+// does the BPTT kernel of this (dtype, H) offer the fused input gradient?
+int dj_lstm_bwd_has_dx(int dtype, int H, int D) {
+  return dtype == DJ_BF16 && H == 128 && RecCfg<bf16_t, 128>::STATB && D <= H ? 1 : 0;
+}
+// W^T fragment stream of the fused dX product: ceil(D / 32) * 32 * 4H operand elements
+int dj_launch_lstm_pack_wt(int dtype, int H, const float* W, int D, void* out, hipStream_t st) {
+  const int NQ = (D + 31) / 32;
+  DJ_DISPATCH_TH(launch_pack_wt, W, D, NQ, out, st)
 }
 
 // k-chunks of the fused input projection for a layer input of width D: ceil(D / KC) rounded up to the ring depth

@@ -289,3 +289,41 @@ def test_lstm_fwd_fused_input_projection(gpu_device, dtype, H, S, Ls, D):
     torch.testing.assert_close(from_rows(Hd.float().cpu(), S, Ls), Href, rtol=rt, atol=at * 5)
     torch.testing.assert_close(from_rows(from_frag(Cd.float().cpu(), R, H), S, Ls), Cref, rtol=rt, atol=at * 5)
     torch.testing.assert_close(from_rows(from_frag(Zd.float().cpu(), R, 4 * H), S, Ls), Zref, rtol=rt, atol=at * 10)
+
+
+@pytest.mark.parametrize("D", [128, 90])
+def test_lstm_bwd_fused_input_gradient(gpu_device, D):
+    """dj_lstm_bwd_dx (bf16, H = 128): the dX the BPTT kernel produces from its dz tile equals dZ W^T computed
+    from the dZ it wrote; wider inputs are refused."""
+    L, lib = _lib()
+    H, tiles, Ls = 128, 3, 5
+    R, DP = tiles * Ls * 32, (D + 7) // 8 * 8
+    g = torch.Generator().manual_seed(D)
+    bf = lambda t: t.to(torch.bfloat16).to(gpu_device)
+    Z = bf(torch.randn(R * 4 * H, generator=g))
+    Cc = bf(torch.randn(R * H, generator=g) * 0.5)
+    dH = bf(torch.randn(R, H, generator=g) * 0.1)
+    U = (torch.randn(H, 4 * H, generator=g) * 0.05).to(gpu_device)
+    W = (torch.randn(D, 4 * H, generator=g) * 0.05).to(gpu_device)
+    upf = torch.empty(H * 4 * H * 2, dtype=torch.uint8, device=gpu_device); upb = torch.empty_like(upf)
+    L.check(lib.dj_lstm_pack(1, H, L.ptr(U), L.ptr(upf), L.ptr(upb), _st()), "pack")
+    wt = torch.zeros(((D + 31) // 32) * 32 * 4 * H * 2, dtype=torch.uint8, device=gpu_device)
+    L.check(lib.dj_lstm_pack_wt(1, H, L.ptr(W), D, L.ptr(wt), _st()), "pack_wt")
+    dZ = torch.zeros(R, 4 * H, dtype=torch.bfloat16, device=gpu_device)
+    dX = torch.full((R, DP), 7.0, dtype=torch.bfloat16, device=gpu_device)
+    db = torch.zeros(4 * H, device=gpu_device)
+    L.check(lib.dj_lstm_bwd_dx(1, H, tiles, Ls, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ), L.ptr(db), 0,
+                               L.ptr(wt), D, L.ptr(dX), DP, _st()), "bwd_dx")
+    ref = dZ.float().cpu() @ W.to(torch.bfloat16).float().cpu().T
+    got = dX.float().cpu()
+    torch.testing.assert_close(got[:, :D], ref, rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
+    if DP > D:
+        assert float(got[:, D:].abs().max()) == 0.0
+    # the same sweep without the fused gradient writes the same dZ
+    dZ2 = torch.zeros_like(dZ); db2 = torch.zeros_like(db)
+    L.check(lib.dj_lstm_bwd(1, H, tiles, Ls, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ2), L.ptr(db2), 0,
+                            _st()), "bwd")
+    assert torch.equal(dZ, dZ2)
+    # D > H is not offered
+    assert lib.dj_lstm_bwd_dx(1, H, tiles, Ls, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ), L.ptr(db), 0,
+                              L.ptr(wt), 259, L.ptr(dX), 264, _st()) == 1015
