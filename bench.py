@@ -36,6 +36,11 @@ def _fused_xw(cfg, d, H):
     return d <= (288 if (H == 128 and cfg.dtype == "bf16") else 2 * H)
 
 
+def _fused_dx(cfg, d, H):
+    """Mirror of dj_api.hip fuse_dx: is dX = dz W^T of this layer produced inside the BPTT kernel?"""
+    return cfg.dtype == "bf16" and H == 128 and d <= H
+
+
 def category_flops(cfg, B, T, N):
     """ALGORITHMIC FLOPs (2*MAC) per training step of each MFMA kernel category
     (SURVEY.md 8d formulas, generalised to the config)."""
@@ -52,9 +57,12 @@ def category_flops(cfg, B, T, N):
     # (dj_api.hip fuse_xw); the others keep a separate GEMM launch (category gemm_xw)
     fx_t = sum(2 * rows * d * 4 * Ht for d in t_in if _fused_xw(cfg, d, Ht))
     fx_n = sum(2 * rows * d * 4 * Hn for d in n_in if _fused_xw(cfg, d, Hn))
+    dx_t = sum(2 * rows * d * 4 * Ht for d in t_in if _fused_dx(cfg, d, Ht))
+    dx_n = sum(2 * rows * d * 4 * Hn for d in n_in if _fused_dx(cfg, d, Hn))
     return {
-        "gemm_xw": xw - fx_t - fx_n, "gemm_dx": xw, "gemm_dw": xw + rec_t + rec_n, "lstm_fwd_time": rec_t + fx_t,
-        "lstm_bwd_time": rec_t, "lstm_fwd_note": rec_n + fx_n, "lstm_bwd_note": rec_n,
+        "gemm_xw": xw - fx_t - fx_n, "gemm_dx": xw - dx_t - dx_n, "gemm_dw": xw + rec_t + rec_n,
+        "lstm_fwd_time": rec_t + fx_t, "lstm_bwd_time": rec_t + dx_t, "lstm_fwd_note": rec_n + fx_n,
+        "lstm_bwd_note": rec_n + dx_n,
     }
 
 
@@ -79,7 +87,10 @@ def category_bytes(cfg, B, T, N, esize):
                 out["gemm_xw"] += rows * esize * (d + 4 * H)
             out["lstm_bwd_" + axis] += rows * esize * 10 * H
             out["gemm_dw"] += rows * esize * (5 * H + d)
-            out["gemm_dx"] += rows * esize * (4 * H + d)
+            if _fused_dx(cfg, d, H):
+                out["lstm_bwd_" + axis] += rows * esize * d          # dx written by the BPTT kernel itself
+            else:
+                out["gemm_dx"] += rows * esize * (4 * H + d)
     return out
 
 
