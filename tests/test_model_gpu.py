@@ -310,16 +310,16 @@ def test_full_size_properties(gpu_device, monkeypatch):
     # (4) reproducible forward
     l0b, out0b, _ = run(cfg32, P0)
     assert torch.equal(out0, out0b)
-    # (1) directional derivative (fp64 accumulation of g.d; eps sized for fp32 loss rounding)
-    gen = torch.Generator(device=gpu_device).manual_seed(3)
-    d = torch.randn(P0.shape, device=gpu_device, generator=gen)
-    d = d / d.norm()
-    eps = 2e-2
+    # (1) directional derivative along the gradient itself (a random direction in 1.27 M dimensions has a
+    # slope of ~5e-4, below the ~1e-6 rounding noise of the fp32 loss sum divided by a usable eps); along
+    # d = g/|g| the slope is |g| and the central difference resolves it to well under a percent
+    gn = float(g0.double().norm())
+    d = (g0.double() / gn).float()
+    eps = 1e-2
     lp, _, _ = run(cfg32, P0 + eps * d)
     lm, _, _ = run(cfg32, P0 - eps * d)
     fd = (lp - lm) / (2 * eps)
-    gd = float((g0.double() * d.double()).sum())
-    assert abs(fd - gd) <= 2e-2 * max(abs(gd), 1e-3), (fd, gd)
+    assert abs(fd - gn) <= 2e-2 * gn, (fd, gn)
     # (2) unfused forward structure (threshold above the 256 tiles of this shape)
     l1, out1, g1 = run(cfg32, P0, fuse_min_tiles=100000)
     torch.testing.assert_close(out1, out0, rtol=1e-3, atol=1e-5)
