@@ -37,7 +37,9 @@ def _fused_xw(cfg, d, H):
 
 
 def _fused_dx(cfg, d, H):
-    """Mirror of dj_api.hip fuse_dx: is dX = dz W^T of this layer produced inside the BPTT kernel?"""
+    """Mirror of dj_api.hip fuse_dx == 1: is the whole dX = dz W^T of this layer produced inside the BPTT
+    kernel?  (Mode 2 -- only the last 3 columns of note layer 0 -- moves a negligible share and stays under
+    gemm_dx in this accounting.)"""
     return cfg.dtype == "bf16" and H == 128 and d <= H
 
 

@@ -180,7 +180,9 @@ int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, con
 /* Same sweep that also produces the layer's input gradient dX = dz W^T (row-major [rows, DP], columns
  * D..DP-1 zero) from the dz tile it holds in LDS; W is the Keras kernel [D, 4H], wtpack its fragment stream
  * from dj_lstm_pack_wt (roundup(D, 32) * 4H operand elements).  Replaces one dj_gemm_nt pass over dZ per layer
- * (TF autodiff's dX of model.py:84,122).  Offered by the bf16 H = 128 build for D <= 128 only (code 1015 otherwise). */
+ * (TF autodiff's dX of model.py:84,122).  Offered by the bf16 H = 128 build: for D <= 128 the
+ * whole dX; for D = 256k + 1..4 (note layer 0: 259) only the last 32-column block (4 columns stored), the rest being
+ * left to dj_gemm_nt; code 1015 otherwise. */
 int32_t dj_lstm_pack_wt(int32_t dtype, int32_t H, const float* W, int32_t D, void* wtpack, void* stream);
 int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack_bwd,
                        const void* C, const void* dH, void* dZ, float* dbias, int32_t recurrent_sigmoid,

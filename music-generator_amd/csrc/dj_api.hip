@@ -212,9 +212,10 @@ inline bool fuse_xw(const LstmP& L) {
 
 // Where the BPTT kernel offers it (bf16, H = 128, D <= H: U^T and W^T both stationary in registers) it also
 // produces dX = dz W^T, which replaces one GEMM pass over dZ for that layer.  DEEPJ_FUSE_DX=0 keeps the GEMM.
-inline bool fuse_dx(const LstmP& L) {
+inline int fuse_dx(const LstmP& L) {            // 0: GEMM, 1: whole dX in the kernel, 2: last column block only
   const char* e = getenv("DEEPJ_FUSE_DX");
-  return rec_persistent(L.H) && dj_lstm_bwd_has_dx(L.dtype, L.H, L.D) && !(e && e[0] == '0');
+  if (!rec_persistent(L.H) || (e && e[0] == '0')) return 0;
+  return dj_lstm_bwd_has_dx(L.dtype, L.H, L.D);
 }
 
 // weight conversion/packing for one LSTM layer
@@ -232,9 +233,8 @@ int prep_layer(const Ctx& c, const LstmP& L, int64_t wWt, int64_t wWc, int64_t w
     RUN(dj_launch_cvt_transpose(dt, c.P + L.U, L.H, 4 * L.H, c.at(wUf), L.H, c.st));
     if (need_bwd && dt != DJ_F32) RUN(dj_launch_cvt_copy(dt, c.P + L.U, (int64_t)L.H * 4 * L.H, c.at(wUb), c.st));
   }
-  if (need_bwd && fuse_dx(L))
-    RUN(dj_launch_lstm_pack_wt(dt, L.H, c.P + L.W, L.D, c.at(wWp), c.st));
-  else if (need_bwd && dt != DJ_F32)
+  if (need_bwd && fuse_dx(L)) RUN(dj_launch_lstm_pack_wt(dt, L.H, c.P + L.W, L.D, c.at(wWp), c.st));
+  if (need_bwd && fuse_dx(L) != 1 && dt != DJ_F32)
     RUN(dj_launch_cvt_copy(dt, c.P + L.W, (int64_t)L.D * 4 * L.H, c.at(wWc), c.st));
   return 0;
 }
@@ -366,7 +366,7 @@ int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int st
                    int64_t wWc, int64_t wWp, int64_t wUb, int64_t wZ, int64_t wH, int64_t wC, int64_t wdH, int64_t wdX,
                    int64_t wdZ, bool is_note) {
   const int dt = c.p.c.dtype;
-  const bool fdx = fuse_dx(L);
+  const int fdx = fuse_dx(L);
   {
     ProfScope ps(is_note ? PC_LSTM_BWD_NOTE : PC_LSTM_BWD_TIME, c.st);
     if (rec_persistent(L.H)) {
@@ -384,10 +384,11 @@ int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int st
     RUN(dj_launch_lstm_wgrad(dt, M, steps, c.at(wX), L.DP, L.D, c.at(wH), L.H, c.at(wdZ), 4 * L.H, G + L.W, G + L.U,
                              c.at(c.p.w_zero), c.st));
   }
-  if (fdx) return 0;
+  if (fdx == 1) return 0;
   const void* Bt = dt == DJ_F32 ? (const void*)(c.P + L.W) : (const void*)c.at(wWc);
+  const int ncols = fdx == 2 ? L.D - L.D % 32 : L.D;       // the kernel above already wrote the last column block
   ProfScope ps(PC_GEMM_DX, c.st);
-  RUN(dj_launch_gemm_nt(dt, (int)M, L.D, 4 * L.H, c.at(wdZ), 4 * L.H, Bt, 4 * L.H, c.at(wdX), L.DP, 0, nullptr, c.st));
+  RUN(dj_launch_gemm_nt(dt, (int)M, ncols, 4 * L.H, c.at(wdZ), 4 * L.H, Bt, 4 * L.H, c.at(wdX), L.DP, 0, nullptr, c.st));
   return 0;
 }
 

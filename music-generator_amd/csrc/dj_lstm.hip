@@ -522,7 +522,10 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
 // DX (stationary-U^T builds only): the kernel also produces the layer's input gradient dX_t = dz_t W^T from
 // the dz tile it holds in LDS -- with no U^T stream the W^T fragments are the only weight traffic of the step
 // and cost less vector-memory time than a separate GEMM pass over dZ in HBM.
-template <typename T, int H, bool SIGM, bool DX>
+// DX == 2: only the LAST 32-column block of dX (columns 32*(NQ-1) ..., at most 4 of them valid: the `chosen`
+// inputs of note layer 0) is produced here, its K range split over the waves (8 stationary fragments each) and
+// the partial sums folded through LDS one step later; the GEMM then covers a multiple of 256 columns only.
+template <typename T, int H, bool SIGM, int DX>
 __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z, const T* __restrict__ UTpack,
                                                        const T* __restrict__ C, const T* __restrict__ dH,
                                                        T* __restrict__ dZ, float* __restrict__ dbias, int steps,
@@ -555,14 +558,36 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
 #pragma unroll
     for (int kc = 0; kc < R::NKCB; ++kc) ub[kc] = up[kc * 64];
   }
-  Frag wts[DX ? R::NKCB : 1];
-  if constexpr (DX) {
+  constexpr int NWT = DX == 1 ? R::NKCB : DX == 2 ? R::NKCB / R::NW : 1;
+  Frag wts[NWT];
+  // DX == 2: [NW][32 rows][4 cols] partial sums of the last block, behind the dz tile and the dH staging tile
+  float* xpart = (float*)(dzs + 32 * R::LDZ + 32 * R::LDH);
+  if constexpr (DX == 1) {
     static_assert(R::STATB, "fused dX needs the stationary-U^T build");
     if (w < NQ) {
 #pragma unroll
       for (int kc = 0; kc < R::NKCB; ++kc) wts[kc] = ((const Frag*)WTpack)[((int64_t)w * R::NKCB + kc) * 64 + lane];
     }
   }
+  if constexpr (DX == 2) {
+    static_assert(R::STATB && R::NKCB % R::NW == 0, "remainder dX needs the stationary-U^T build");
+#pragma unroll
+    for (int i = 0; i < NWT; ++i)       // this wave's K quarter of block NQ-1
+      wts[i] = ((const Frag*)WTpack)[((int64_t)(NQ - 1) * R::NKCB + w * NWT + i) * 64 + lane];
+  }
+  // fold the partial sums of the step that has just been processed (row block rbp) and store 4 columns per row
+  auto xpart_fold = [&](int64_t rbp) {
+    if (w == 0 && h == 0) {
+      float v[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        v[c] = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < R::NW; ++ww) v[c] += xpart[(ww * 32 + l31) * 4 + c];
+      }
+      dj_store4(dX + (rbp * 32 + l31) * DP + (NQ - 1) * 32, v[0], v[1], v[2], v[3]);
+    }
+  };
   auto zaddr = [&](int64_t rb, int g, int j) {
     return Z + ((rb * R::NCB + (g * H + w * R::UW + j * 32) / 32) * 64 + lane) * 16;
   };
@@ -650,6 +675,9 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
     DJ_STAMP(1, 1, t);
     lds_barrier();
     DJ_STAMP(1, 2, t);
+    if constexpr (DX == 2) {
+      if (t < steps - 1) xpart_fold(rb + 1);      // partials of step t+1: every wave wrote them before this barrier
+    }
     float dhv[R::NJ][16];
 #pragma unroll
     for (int j = 0; j < R::NJ; ++j)
@@ -703,7 +731,19 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
       *(uint4*)(dZ + (rb * 32 + row) * (4 * H) + cv) = *(const uint4*)(dzs + row * R::LDZ + cv);
     }
     DJ_STAMP(1, 6, t);
-    if constexpr (DX) {
+    if constexpr (DX == 2) {
+      const T* apx = dzs + l31 * R::LDZ;
+      f32x16 ax;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ax[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NWT; ++i) {
+        Frag a = dj_lds_frag(apx + (w * NWT + i) * R::KC, h);
+        dj_mfma(ax, wts[i], a);
+      }
+      if (h == 0) *(float4*)(xpart + (w * 32 + l31) * 4) = make_float4(ax[0], ax[1], ax[2], ax[3]);   // columns 0..3
+    }
+    if constexpr (DX == 1) {
       // dX_t = dz_t [32 x 4H] * W^T [4H x D], D <= H: wave w owns the 32-column block q = w, whose W^T slice
       // is stationary in registers as well (wts, loaded before the sweep); operands are swapped so that a
       // lane holds 4 consecutive columns of ONE row per register quad.  (Streaming W^T instead -- wider
@@ -782,6 +822,10 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
     // (SPLIT) the next step's first barrier already orders this step's dzs reads before its gate writes
     if constexpr (!SPLIT) lds_barrier();
   }
+  if constexpr (DX == 2) {
+    lds_barrier();
+    xpart_fold(tile * steps);
+  }
   if (dbias) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -814,11 +858,11 @@ int launch_fwd(int ntiles, int steps, void* Z, const void* Upack, void* Hout, vo
                        (T*)Hout, (T*)Cout, steps, store_z);
   return (int)hipGetLastError();
 }
-template <typename T, int H, bool DX>
+template <typename T, int H, int DX>
 int launch_bwd_x(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
                  float* dbias, int sigm, const void* WTpack, int NQ, void* dX, int DP, hipStream_t st) {
   using R = RecCfg<T, H>;
-  size_t smem = (size_t)32 * (R::LDZ + (R::HOIST ? R::LDH : 0)) * sizeof(T);
+  size_t smem = (size_t)32 * (R::LDZ + (R::HOIST ? R::LDH : 0)) * sizeof(T) + (DX == 2 ? R::NW * 32 * 4 * sizeof(float) : 0);
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_kernel<T, H, false, DX>,
@@ -842,13 +886,15 @@ int launch_bwd(int ntiles, int steps, const void* Z, const void* UTpack, const v
                float* dbias, int sigm, const void* WTpack, int NQ, void* dX, int DP, hipStream_t st) {
   if (WTpack) {
     if constexpr (RecCfg<T, H>::STATB) {
-      if (NQ > RecCfg<T, H>::NW) return 1015;      // one stationary 32-column block per wave: D <= H
-      return launch_bwd_x<T, H, true>(ntiles, steps, Z, UTpack, C, dH, dZ, dbias, sigm, WTpack, NQ, dX, DP, st);
+      if (NQ <= RecCfg<T, H>::NW)                  // one stationary 32-column block per wave: D <= H
+        return launch_bwd_x<T, H, 1>(ntiles, steps, Z, UTpack, C, dH, dZ, dbias, sigm, WTpack, NQ, dX, DP, st);
+      if (DP < (NQ - 1) * 32 + 4) return 1015;     // remainder mode stores 4 columns of the last block
+      return launch_bwd_x<T, H, 2>(ntiles, steps, Z, UTpack, C, dH, dZ, dbias, sigm, WTpack, NQ, dX, DP, st);
     } else {
       return 1015;      // fused dX exists for the stationary-U^T build only (bf16, H = 128)
     }
   }
-  return launch_bwd_x<T, H, false>(ntiles, steps, Z, UTpack, C, dH, dZ, dbias, sigm, nullptr, 0, nullptr, 0, st);
+  return launch_bwd_x<T, H, 0>(ntiles, steps, Z, UTpack, C, dH, dZ, dbias, sigm, nullptr, 0, nullptr, 0, st);
 }
 template <typename T, int H> int launch_pack_wt(const float* W, int D, int NQ, void* out, hipStream_t st) {
   int n = NQ * 32 * 4 * H;
@@ -925,8 +971,12 @@ int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, c
   DJ_DISPATCH_TH(launch_bwd, ntiles, steps, Z, UTpack, C, dH, dZ, dbias, sigm, WTpack, NQ, dX, DP, st)
 }
 // does the BPTT kernel of this (dtype, H) offer the fused input gradient?
+// 1: the whole dX (D <= H); 2: only the last 32-column block, for inputs whose width is 1..4 columns past a
+// multiple of 256 (note layer 0: 259 = time-axis h + 3 chosen columns) -- the GEMM then covers D - D%32 columns
 int dj_lstm_bwd_has_dx(int dtype, int H, int D) {
-  return dtype == DJ_BF16 && H == 128 && RecCfg<bf16_t, 128>::STATB && D <= H ? 1 : 0;
+  if (!(dtype == DJ_BF16 && H == 128 && RecCfg<bf16_t, 128>::STATB)) return 0;
+  if (D <= H) return 1;
+  return (D % 256 >= 1 && D % 256 <= 4) ? 2 : 0;
 }
 // W^T fragment stream of the fused dX product: ceil(D / 32) * 32 * 4H operand elements
 int dj_launch_lstm_pack_wt(int dtype, int H, const float* W, int D, void* out, hipStream_t st) {

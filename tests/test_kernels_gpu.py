@@ -324,6 +324,33 @@ def test_lstm_bwd_fused_input_gradient(gpu_device, D):
     L.check(lib.dj_lstm_bwd(1, H, tiles, Ls, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ2), L.ptr(db2), 0,
                             _st()), "bwd")
     assert torch.equal(dZ, dZ2)
-    # D > H is not offered
-    assert lib.dj_lstm_bwd_dx(1, H, tiles, Ls, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ), L.ptr(db), 0,
-                              L.ptr(wt), 259, L.ptr(dX), 264, _st()) == 1015
+
+
+def test_lstm_bwd_remainder_input_gradient(gpu_device):
+    """dj_lstm_bwd_dx with D = 259 (note layer 0: 256 time-axis features + 3 chosen columns): the kernel
+    produces only the last 32-column block (4 columns stored), K split over its waves and folded through LDS
+    one step later; columns 0..255 are left to the GEMM."""
+    L, lib = _lib()
+    H, tiles, Ls, D, DP = 128, 3, 6, 259, 264
+    R = tiles * Ls * 32
+    g = torch.Generator().manual_seed(5)
+    bf = lambda t: t.to(torch.bfloat16).to(gpu_device)
+    Z = bf(torch.randn(R * 4 * H, generator=g))
+    Cc = bf(torch.randn(R * H, generator=g) * 0.5)
+    dH = bf(torch.randn(R, H, generator=g) * 0.1)
+    U = (torch.randn(H, 4 * H, generator=g) * 0.05).to(gpu_device)
+    W = (torch.randn(D, 4 * H, generator=g) * 0.05).to(gpu_device)
+    upf = torch.empty(H * 4 * H * 2, dtype=torch.uint8, device=gpu_device); upb = torch.empty_like(upf)
+    L.check(lib.dj_lstm_pack(1, H, L.ptr(U), L.ptr(upf), L.ptr(upb), _st()), "pack")
+    wt = torch.zeros(((D + 31) // 32) * 32 * 4 * H * 2, dtype=torch.uint8, device=gpu_device)
+    L.check(lib.dj_lstm_pack_wt(1, H, L.ptr(W), D, L.ptr(wt), _st()), "pack_wt")
+    dZ = torch.zeros(R, 4 * H, dtype=torch.bfloat16, device=gpu_device)
+    dX = torch.full((R, DP), 7.0, dtype=torch.bfloat16, device=gpu_device)
+    db = torch.zeros(4 * H, device=gpu_device)
+    L.check(lib.dj_lstm_bwd_dx(1, H, tiles, Ls, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ), L.ptr(db), 0,
+                               L.ptr(wt), D, L.ptr(dX), DP, _st()), "bwd_dx")
+    ref = dZ.float().cpu() @ W.to(torch.bfloat16).float().cpu().T          # [R, 259]
+    got = dX.float().cpu()
+    torch.testing.assert_close(got[:, 256:259], ref[:, 256:259], rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
+    assert float(got[:, 259].abs().max()) == 0.0                           # 4th stored column: zero weight row
+    assert bool((got[:, :256] == 7.0).all()) and bool((got[:, 260:] == 7.0).all())
