@@ -246,10 +246,16 @@ int style_forward(const Ctx& c, const float* style_in) {
                             p.SU, 0, c.st));                                            // model.py:141-142
   return 0;
 }
-int style_proj(const Ctx& c, const LstmP& L, int64_t w_sp) {                            // model.py:77,110-113 + tanh
+// sp_l = tanh(style Wd_l + bd_l) of all layers of one axis in one launch      (model.py:77,110-113 + tanh)
+int style_proj_all(const Ctx& c, const LstmP* Ls, const int64_t* w_sp, int n) {
   ProfScope ps(PC_STYLE_FWD, c.st);
-  return dj_launch_dense_small(c.at<float>(c.p.w_style), (int)c.p.BT, c.p.SU, c.P + L.dW, c.P + L.db,
-                               c.at<float>(w_sp), L.D, 1, c.st);
+  DenseBatch d;
+  memset(&d, 0, sizeof(d));
+  d.n = n; d.M = (int)c.p.BT; d.K = c.p.SU; d.A = c.at<float>(c.p.w_style);
+  for (int l = 0; l < n; ++l) {
+    d.W[l] = c.P + Ls[l].dW; d.b[l] = c.P + Ls[l].db; d.C[l] = c.at<float>(w_sp[l]); d.N[l] = Ls[l].D;
+  }
+  return dj_launch_dense_small_batch(&d, 1, c.st);
 }
 
 int lstm_layer_fwd(const Ctx& c, const LstmP& L, int64_t tiles, int steps, int64_t M, int64_t wX, int64_t wWt,
@@ -286,7 +292,7 @@ int time_axis_forward(const Ctx& c, const float* notes, const float* beat) {
   const float pin = p.c.input_dropout, pdr = p.c.dropout;
   DjDrop d_notes = mkdrop(c.seed, DJ_SITE_NOTES, pin, c.train);
   RUN(dj_launch_bins(notes, c.at<float>(p.w_bins), p.B, p.T, p.N, p.c.octave, d_notes, c.st));
-  for (int l = 0; l < p.Lt; ++l) RUN(style_proj(c, p.tl[l], p.w_sp_t[l]));
+  RUN(style_proj_all(c, p.tl, p.w_sp_t, p.Lt));
   FeatArgs fa;
   fa.notes = notes; fa.beat = beat; fa.bins = c.at<float>(p.w_bins); fa.sp0 = c.at<float>(p.w_sp_t[0]);
   fa.Wc = c.P + p.p_conv_W; fa.bc = c.P + p.p_conv_b;
@@ -323,7 +329,7 @@ int note_axis_forward(const Ctx& c, int64_t wHin, int in_na, int d_out_site, con
   const Plan& p = c.p;
   const int dt = p.c.dtype;
   const float pin = p.c.input_dropout, pdr = p.c.dropout;
-  for (int l = 0; l < p.Ln; ++l) RUN(style_proj(c, p.nl[l], p.w_sp_n[l]));
+  RUN(style_proj_all(c, p.nl, p.w_sp_n, p.Ln));
   for (int l = 0; l < p.Ln; ++l) {
     const LstmP& L = p.nl[l];
     GlueArgs g;
@@ -392,14 +398,21 @@ int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int st
   return 0;
 }
 
-int style_dense_bwd(const Ctx& c, const LstmP& L, float* G, int64_t w_dpre, bool first) {
+// gradients of every per-layer style Dense in two launches (weight/bias gradients; input gradient summed into dstyle)
+int style_dense_bwd_all(const Ctx& c, float* G) {
   const Plan& p = c.p;
   ProfScope ps(PC_STYLE_BWD, c.st);
-  RUN(dj_launch_dense_small_bwd_w(c.at<float>(p.w_style), (int)p.BT, p.SU, c.at<float>(w_dpre), L.D, G + L.dW,
-                                  G + L.db, c.st));
-  RUN(dj_launch_dense_small_bwd_x(c.at<float>(w_dpre), (int)p.BT, L.D, c.P + L.dW, p.SU, c.at<float>(p.w_dstyle),
-                                  first ? 0 : 1, c.st));
-  return 0;
+  DenseBatch d;
+  memset(&d, 0, sizeof(d));
+  d.M = (int)p.BT; d.K = p.SU; d.A = c.at<float>(p.w_style);
+  auto add = [&](const LstmP& L, int64_t w_dpre) {
+    const int l = d.n++;
+    d.W[l] = c.P + L.dW; d.dC[l] = c.at<float>(w_dpre); d.dW[l] = G + L.dW; d.db[l] = G + L.db; d.N[l] = L.D;
+  };
+  for (int l = 0; l < p.Lt; ++l) add(p.tl[l], p.w_dpre_t[l]);
+  for (int l = 0; l < p.Ln; ++l) add(p.nl[l], p.w_dpre_n[l]);
+  DJ_CHECK(hipMemsetAsync(c.at<float>(p.w_dstyle), 0, p.BT * p.SU * sizeof(float), c.st));
+  return dj_launch_dense_small_batch_bwd(&d, c.at<float>(p.w_dstyle), c.st);
 }
 
 int check_ws(const Plan& p, void* ws, int64_t bytes) {
@@ -550,9 +563,7 @@ int32_t dj_train_fwd_bwd_acc(const dj_config* cfg, const float* params, float* g
     }
   }
   // style Dense layers and the style embedding (model.py:141-142,77,110-113)
-  bool first = true;
-  for (int l = 0; l < p.Lt; ++l) { RUN(style_dense_bwd(c, p.tl[l], G, p.w_dpre_t[l], first)); first = false; }
-  for (int l = 0; l < p.Ln; ++l) { RUN(style_dense_bwd(c, p.nl[l], G, p.w_dpre_n[l], first)); first = false; }
+  RUN(style_dense_bwd_all(c, G));
   ProfScope ps(PC_STYLE_BWD, c.st);
   RUN(dj_launch_dense_small_bwd_w(style, (int)p.BT, p.S, c.at<float>(p.w_dstyle), p.SU, G + p.p_style_W,
                                   G + p.p_style_b, c.st));

@@ -34,8 +34,9 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&x)[8]) {
 // ------------------------------------------------------------------ small dense (fp32)
 // C[m, n] = act(A[m,:K] . W[:K, n] + b[n])      (reference model.py:141-142 style
 // embedding; model.py:77,110-113 per-layer style Dense followed by tanh)
-__global__ void dense_small_kernel(const float* __restrict__ A, int M, int K, const float* __restrict__ W,
-                                   const float* __restrict__ b, float* __restrict__ C, int N, int act_tanh) {
+__device__ __forceinline__ void dense_small_body(const float* __restrict__ A, int M, int K,
+                                                 const float* __restrict__ W, const float* __restrict__ b,
+                                                 float* __restrict__ C, int N, int act_tanh) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)M * N) return;
   int m = idx / N, n = idx % N;
@@ -43,12 +44,23 @@ __global__ void dense_small_kernel(const float* __restrict__ A, int M, int K, co
   for (int k = 0; k < K; ++k) s += A[(int64_t)m * K + k] * W[(int64_t)k * N + n];
   C[idx] = act_tanh ? dj_tanh(s) : s;
 }
+__global__ void dense_small_kernel(const float* __restrict__ A, int M, int K, const float* __restrict__ W,
+                                   const float* __restrict__ b, float* __restrict__ C, int N, int act_tanh) {
+  dense_small_body(A, M, K, W, b, C, N, act_tanh);
+}
+// Several small dense layers that share the input A in ONE launch (blockIdx.y = layer): the per-layer style
+// projections and their gradients are latency-bound kernels of a few microseconds of work each, so running
+// them side by side costs the time of the longest instead of the sum.
+__global__ void dense_small_batch_kernel(DenseBatch d, int act_tanh) {
+  const int l = blockIdx.y;
+  dense_small_body(d.A, d.M, d.K, d.W[l], d.b[l], d.C[l], d.N[l], act_tanh);
+}
 // dA[m,k] (+)= sum_n dC[m,n] * W[k,n].  Block = 8 rows; n runs in chunks of NC columns: W^T chunk
 // staged in LDS ([n][K], conflict-free across k), the 8 dC rows too; thread (k, row pair).
 constexpr int DSBX_NC = 320;
-__global__ __launch_bounds__(256) void dense_small_bwd_x_kernel(const float* __restrict__ dC, int M, int N,
-                                                                const float* __restrict__ W, int K,
-                                                                float* __restrict__ dA, int accumulate) {
+__device__ __forceinline__ void dense_small_bwd_x_body(const float* __restrict__ dC, int M, int N,
+                                                       const float* __restrict__ W, int K, float* __restrict__ dA,
+                                                       int accumulate) {
   extern __shared__ float sm[];
   const int NC = N < DSBX_NC ? N : DSBX_NC;
   const int KP = K + 1;         // padded row: the transposing store and the k-parallel read are conflict-free
@@ -79,15 +91,29 @@ __global__ __launch_bounds__(256) void dense_small_bwd_x_kernel(const float* __r
   }
   if (k >= K) return;
   int m = m0 + 2 * rp;
+  if (accumulate == 2) {          // several layers add into the same dA concurrently
+    if (m < M) atomicAdd(dA + (int64_t)m * K + k, s0);
+    if (m + 1 < M) atomicAdd(dA + (int64_t)(m + 1) * K + k, s1);
+    return;
+  }
   if (m < M) dA[(int64_t)m * K + k] = accumulate ? dA[(int64_t)m * K + k] + s0 : s0;
   if (m + 1 < M) dA[(int64_t)(m + 1) * K + k] = accumulate ? dA[(int64_t)(m + 1) * K + k] + s1 : s1;
 }
+__global__ __launch_bounds__(256) void dense_small_bwd_x_kernel(const float* __restrict__ dC, int M, int N,
+                                                                const float* __restrict__ W, int K,
+                                                                float* __restrict__ dA, int accumulate) {
+  dense_small_bwd_x_body(dC, M, N, W, K, dA, accumulate);
+}
+__global__ __launch_bounds__(256) void dense_small_bwd_x_batch_kernel(DenseBatch d, float* __restrict__ dA) {
+  const int l = blockIdx.y;
+  dense_small_bwd_x_body(d.dC[l], d.M, d.N[l], d.W[l], d.K, dA, 2);
+}
 // dW[k,n] += sum_m A[m,k] dC[m,n];  db[n] += sum_m dC[m,n].  One block per
 // (row chunk, 64-col strip); thread (kq, n) owns K/4 rows of dW for its column.
-__global__ __launch_bounds__(256) void dense_small_bwd_w_kernel(const float* __restrict__ A, int M, int K,
-                                                                const float* __restrict__ dC, int N,
-                                                                float* __restrict__ dW, float* __restrict__ db,
-                                                                int rows_per_block) {
+__device__ __forceinline__ void dense_small_bwd_w_body(const float* __restrict__ A, int M, int K,
+                                                       const float* __restrict__ dC, int N,
+                                                       float* __restrict__ dW, float* __restrict__ db,
+                                                       int rows_per_block) {
   extern __shared__ float sm[];   // As[rows][K]
   const int tid = threadIdx.x, nl = tid & 63, kq = tid >> 6;
   const int n = blockIdx.y * 64 + nl;
@@ -118,6 +144,16 @@ __global__ __launch_bounds__(256) void dense_small_bwd_w_kernel(const float* __r
     if (k < K) atomicAdd(dW + (int64_t)k * N + n, acc[i]);
   }
   if (db && kq == 0) atomicAdd(db + n, bsum);
+}
+__global__ __launch_bounds__(256) void dense_small_bwd_w_kernel(const float* __restrict__ A, int M, int K,
+                                                                const float* __restrict__ dC, int N,
+                                                                float* __restrict__ dW, float* __restrict__ db,
+                                                                int rows_per_block) {
+  dense_small_bwd_w_body(A, M, K, dC, N, dW, db, rows_per_block);
+}
+__global__ __launch_bounds__(256) void dense_small_bwd_w_batch_kernel(DenseBatch d, int rows_per_block) {
+  const int l = blockIdx.z;
+  dense_small_bwd_w_body(d.A, d.M, d.K, d.dC[l], d.N[l], d.dW[l], d.db[l], rows_per_block);
 }
 
 // ------------------------------------------------------------------ pitch bins (model.py:43-49)
@@ -759,6 +795,34 @@ int dj_launch_dense_small_bwd_w(const float* A, int M, int K, const float* dC, i
   dim3 grid((M + rpb - 1) / rpb, (N + 63) / 64);
   hipLaunchKernelGGL(dense_small_bwd_w_kernel, grid, dim3(256), (size_t)rpb * K * sizeof(float), st, A, M, K, dC, N, dW,
                      db, rpb);
+  return (int)hipGetLastError();
+}
+int dj_launch_dense_small_batch(const DenseBatch* d, int act_tanh, hipStream_t st) {
+  if (d->n < 1 || d->n > DJ_DENSE_BATCH_MAX) return 1028;
+  int maxn = 0;
+  for (int l = 0; l < d->n; ++l) maxn = d->N[l] > maxn ? d->N[l] : maxn;
+  hipLaunchKernelGGL(dense_small_batch_kernel, dim3(nblk((int64_t)d->M * maxn), d->n), dim3(256), 0, st, *d, act_tanh);
+  return (int)hipGetLastError();
+}
+// gradients of a batch: dW_l += A^T dC_l, db_l += colsum(dC_l); dA += sum_l dC_l W_l^T (dA must be zeroed by the caller)
+int dj_launch_dense_small_batch_bwd(const DenseBatch* d, float* dA, hipStream_t st) {
+  if (d->n < 1 || d->n > DJ_DENSE_BATCH_MAX || d->K > 64) return 1028;
+  int maxn = 0;
+  for (int l = 0; l < d->n; ++l) maxn = d->N[l] > maxn ? d->N[l] : maxn;
+  const int rpb = 32;
+  hipLaunchKernelGGL(dense_small_bwd_w_batch_kernel, dim3((d->M + rpb - 1) / rpb, (maxn + 63) / 64, d->n), dim3(256),
+                     (size_t)rpb * d->K * sizeof(float), st, *d, rpb);
+  const int NC = maxn < DSBX_NC ? maxn : DSBX_NC;
+  const size_t smb = ((size_t)NC * (d->K + 1) + 8 * (size_t)NC) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)dense_small_bwd_x_batch_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  if (smb > 96 * 1024) return 1026;
+  hipLaunchKernelGGL(dense_small_bwd_x_batch_kernel, dim3((d->M + 7) / 8, d->n), dim3(256), smb, st, *d, dA);
   return (int)hipGetLastError();
 }
 int dj_launch_bins(const float* notes, float* bins, int B, int T, int N, int octave, DjDrop dn, hipStream_t st) {

@@ -49,6 +49,20 @@ struct NadamArgs {
   float gscale;               // gradient pre-scale (1/world_size for data parallel)
 };
 
+// up to 8 small dense layers on the same input A [M, K] (the per-layer style projections)
+constexpr int DJ_DENSE_BATCH_MAX = 8;
+struct DenseBatch {
+  int n, M, K;
+  const float* A;
+  const float* W[DJ_DENSE_BATCH_MAX];    // [K, N_l]
+  const float* b[DJ_DENSE_BATCH_MAX];    // [N_l] or null
+  float* C[DJ_DENSE_BATCH_MAX];          // forward outputs [M, N_l]
+  const float* dC[DJ_DENSE_BATCH_MAX];   // backward inputs [M, N_l]
+  float* dW[DJ_DENSE_BATCH_MAX];
+  float* db[DJ_DENSE_BATCH_MAX];
+  int N[DJ_DENSE_BATCH_MAX];
+};
+
 // dj_gemm.hip
 int dj_launch_gemm_nt(int dtype, int M, int N, int K, const void* A, int lda, const void* Bt, int ldb, void* C, int ldc,
                       int c_mode, const float* bias, hipStream_t st);
@@ -88,6 +102,8 @@ int dj_launch_dense_small_bwd_x(const float* dC, int M, int N, const float* W, i
                                 hipStream_t st);
 int dj_launch_dense_small_bwd_w(const float* A, int M, int K, const float* dC, int N, float* dW, float* db,
                                 hipStream_t st);
+int dj_launch_dense_small_batch(const DenseBatch* d, int act_tanh, hipStream_t st);
+int dj_launch_dense_small_batch_bwd(const DenseBatch* d, float* dA, hipStream_t st);
 int dj_launch_bins(const float* notes, float* bins, int B, int T, int N, int octave, DjDrop dn, hipStream_t st);
 int dj_launch_feature_fwd(int dtype, const void* fa, void* X, void* Xcol, void* Ycol, hipStream_t st);
 int dj_launch_feature_bwd(int dtype, const void* fa, const void* dX, void* Ycol, float* dbc, float* dpre0,
