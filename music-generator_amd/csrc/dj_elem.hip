@@ -51,9 +51,36 @@ __global__ void dense_small_kernel(const float* __restrict__ A, int M, int K, co
 // Several small dense layers that share the input A in ONE launch (blockIdx.y = layer): the per-layer style
 // projections and their gradients are latency-bound kernels of a few microseconds of work each, so running
 // them side by side costs the time of the longest instead of the sum.
-__global__ void dense_small_batch_kernel(DenseBatch d, int act_tanh) {
-  const int l = blockIdx.y;
-  dense_small_body(d.A, d.M, d.K, d.W[l], d.b[l], d.C[l], d.N[l], act_tanh);
+// Tile = 32 rows x 64 columns per workgroup, A tile in LDS (one wave = one 8-row group, so its reads are
+// broadcasts), each weight element loaded once per 8 outputs.  K <= 64.
+__global__ __launch_bounds__(256) void dense_small_batch_kernel(DenseBatch d, int act_tanh) {
+  __shared__ float As[32][65];
+  const int l = blockIdx.z, N = d.N[l], K = d.K;
+  const int nl = threadIdx.x & 63, rg = threadIdx.x >> 6, n = blockIdx.x * 64 + nl, m0 = blockIdx.y * 32;
+  if (blockIdx.x * 64 >= N) return;                       // whole workgroup past this layer's width
+  for (int i = threadIdx.x; i < 32 * K; i += 256) {
+    const int r = i / K, k = i % K;
+    As[r][k] = (m0 + r < d.M) ? d.A[(int64_t)(m0 + r) * K + k] : 0.f;
+  }
+  __syncthreads();
+  if (n >= N) return;
+  const float* W = d.W[l];
+  const float bv = d.b[l] ? d.b[l][n] : 0.f;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = bv;
+#pragma unroll 8
+  for (int k = 0; k < K; ++k) {
+    const float w = W[(int64_t)k * N + n];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += As[rg * 8 + i][k] * w;
+  }
+  float* C = d.C[l];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + rg * 8 + i;
+    if (m < d.M) C[(int64_t)m * N + n] = act_tanh ? dj_tanh(acc[i]) : acc[i];
+  }
 }
 // dA[m,k] (+)= sum_n dC[m,n] * W[k,n].  Block = 8 rows; n runs in chunks of NC columns: W^T chunk
 // staged in LDS ([n][K], conflict-free across k), the 8 dC rows too; thread (k, row pair).
@@ -801,7 +828,9 @@ int dj_launch_dense_small_batch(const DenseBatch* d, int act_tanh, hipStream_t s
   if (d->n < 1 || d->n > DJ_DENSE_BATCH_MAX) return 1028;
   int maxn = 0;
   for (int l = 0; l < d->n; ++l) maxn = d->N[l] > maxn ? d->N[l] : maxn;
-  hipLaunchKernelGGL(dense_small_batch_kernel, dim3(nblk((int64_t)d->M * maxn), d->n), dim3(256), 0, st, *d, act_tanh);
+  if (d->K > 64) return 1020;
+  hipLaunchKernelGGL(dense_small_batch_kernel, dim3((maxn + 63) / 64, (d->M + 31) / 32, d->n), dim3(256), 0, st, *d,
+                     act_tanh);
   return (int)hipGetLastError();
 }
 // gradients of a batch: dW_l += A^T dC_l, db_l += colsum(dC_l); dA += sum_l dC_l W_l^T (dA must be zeroed by the caller)
