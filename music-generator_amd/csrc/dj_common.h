@@ -70,17 +70,20 @@ __host__ __device__ __forceinline__ uint32_t dj_lowbias32(uint32_t x) {
 }
 struct DjDrop {
   uint32_t key;     // seed ^ site*golden
-  uint32_t thr;     // ceil(p * 2^24); 0 => dropout disabled
+  uint32_t thr;     // ceil(p * 2^16); 0 => dropout disabled
   float scale;      // 1/(1-p)
 };
 __host__ __device__ __forceinline__ uint32_t dj_rowkey(const DjDrop& d, uint32_t row) {
   return dj_lowbias32(row + d.key);
 }
 // returns the multiplier (0 or 1/(1-p)) for element (row, c)
+// One hash serves a pair of columns (2 x 16 bits): the elementwise kernels walk 8 consecutive columns per
+// thread and were partly bound by this integer work at one hash per element.
 __host__ __device__ __forceinline__ float dj_keep(const DjDrop& d, uint32_t rowkey, uint32_t c) {
   if (d.thr == 0) return 1.0f;
-  uint32_t h = dj_lowbias32(rowkey + c * 0x9E3779B9u);
-  return ((h >> 8) >= d.thr) ? d.scale : 0.0f;
+  const uint32_t h = dj_lowbias32(rowkey + (c >> 1) * 0x9E3779B9u);
+  const uint32_t bits = (c & 1u) ? (h >> 16) : (h & 0xFFFFu);
+  return (bits >= d.thr) ? d.scale : 0.0f;
 }
 
 // ---------------------------------------------------------------- activations

@@ -153,18 +153,20 @@ def _lowbias32(x: np.ndarray) -> np.ndarray:
 
 
 def drop_threshold(p: float) -> int:
-    return int(math.ceil(float(np.float32(p)) * 16777216.0))
+    return int(math.ceil(float(np.float32(p)) * 65536.0))
 
 
 def keep_mask(seed: int, site: int, rows: int, d: int, p: float) -> np.ndarray:
-    """Boolean keep mask [rows, d]; element (row, c) is kept iff
-    (lowbias32(lowbias32(row + key) + c*0x9E3779B9) >> 8) >= ceil(p * 2^24)."""
+    """Boolean keep mask [rows, d]; one hash serves a pair of columns: with
+    h = lowbias32(lowbias32(row + key) + (c >> 1) * 0x9E3779B9), element (row, c) is kept iff
+    (h >> 16 if c is odd else h & 0xFFFF) >= ceil(p * 2^16)."""
     with np.errstate(over="ignore"):
         key = np.uint32(seed & 0xFFFFFFFF) ^ (np.uint32(site) * np.uint32(0x9E3779B9))
         rk = _lowbias32(np.arange(rows, dtype=np.uint32) + key)
-        c = np.arange(d, dtype=np.uint32) * np.uint32(0x9E3779B9)
-        h = _lowbias32(rk[:, None] + c[None, :])
-    return (h >> np.uint32(8)) >= np.uint32(drop_threshold(p))
+        cols = np.arange(d, dtype=np.uint32)
+        h = _lowbias32(rk[:, None] + ((cols >> np.uint32(1)) * np.uint32(0x9E3779B9))[None, :])
+        bits = np.where((cols & np.uint32(1))[None, :] == 1, h >> np.uint32(16), h & np.uint32(0xFFFF))
+    return bits >= np.uint32(drop_threshold(p))
 
 
 def make_masks(cfg: OracleConfig, B: int, seed: int, input_dropout: float, dropout: float,

@@ -117,4 +117,4 @@ def test_dropout_hash_statistics_and_determinism():
     assert abs(m2.mean() - 0.8) < 0.01
     np.testing.assert_array_equal(m, O.keep_mask(11, 4, 4096, 64, 0.5))
     assert (O.keep_mask(12, 4, 64, 64, 0.5) != m[:64]).any()
-    assert O.drop_threshold(0.5) == 8388608 and O.drop_threshold(0.2) == 3355444
+    assert O.drop_threshold(0.5) == 32768 and O.drop_threshold(0.2) == 13108
