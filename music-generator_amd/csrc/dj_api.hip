@@ -70,7 +70,7 @@ struct Plan {
   int64_t w_Wt_n[MAXL], w_Wc_n[MAXL], w_Uf_n[MAXL], w_Ub_n[MAXL], w_Wp_n[MAXL];
   int64_t w_X_t[MAXL], w_Z_t[MAXL], w_H_t[MAXL], w_C_t[MAXL];
   int64_t w_X_n[MAXL], w_Z_n[MAXL], w_H_n[MAXL], w_C_n[MAXL];
-  int64_t w_dH_t, w_dX_t, w_dH_n, w_dX_n, w_featin, w_dZ_t, w_dZ_n, w_zero, w_Xcol, w_Ycol, w_step;
+  int64_t w_dH_t, w_dX_t, w_dH_n, w_dX_n, w_featin, w_dZ_t, w_dZ_n, w_zero, w_Xcol, w_Ycol, w_WcT, w_step;
   int64_t ws_bytes;
 };
 
@@ -156,7 +156,8 @@ int make_plan(const dj_config* cfg, Plan& p) {
   p.w_dZ_t = wtake(p.Mt * 4 * p.Ht * p.esz);  // row-major dz of the layer in flight (BPTT)
   p.w_dZ_n = wtake(p.Mn * 4 * p.Hn * p.esz);
   p.w_Xcol = wtake(p.Mt * 80 * p.esz);       // im2col view of the (dropped-out) notes, conv-kernel tap order
-  p.w_Ycol = wtake(p.Mt * 64 * p.esz);       // tanh(conv) stash, overwritten by its gradient in BPTT
+  p.w_Ycol = wtake(p.Mt * 64 * p.esz);       // conv pre-activation -> tanh(conv) stash -> its gradient in BPTT
+  p.w_WcT = wtake(64 * 80 * p.esz);         // conv kernel as the k-contiguous Bt operand [64 outputs][80 taps]
   p.w_zero = wtake(256);                      // a zero line (h_{-1} rows of the fused weight-gradient GEMM)
   {                                           // fp32 scratch of the per-step path (layers with H not 128/256)
     int64_t fl = 0;
@@ -302,8 +303,12 @@ int time_axis_forward(const Ctx& c, const float* notes, const float* beat) {
   fa.d_style = mkdrop(c.seed, DJ_SITE_TSTYLE + 0, pdr, c.train);
   {
     ProfScope ps(PC_FEATURE_FWD, c.st);
-    RUN(dj_launch_feature_fwd(dt, &fa, c.at(p.w_X_t[0]), c.train ? c.at(p.w_Xcol) : nullptr,
-                              c.train ? c.at(p.w_Ycol) : nullptr, c.st));
+    // conv as im2col GEMM on the MFMA units: Xcol -> Y = Xcol Wc + bc -> tanh / dropout / assembly
+    RUN(dj_launch_cvt_transpose(dt, c.P + p.p_conv_W, 72, 64, c.at(p.w_WcT), 80, c.st));
+    RUN(dj_launch_feature_xcol(dt, &fa, c.at(p.w_Xcol), c.st));
+    RUN(dj_launch_gemm_nt(dt, (int)p.Mt, 64, 80, c.at(p.w_Xcol), 80, c.at(p.w_WcT), 80, c.at(p.w_Ycol), 64, 0,
+                          c.P + p.p_conv_b, c.st));
+    RUN(dj_launch_feature_asm(dt, &fa, c.at(p.w_X_t[0]), c.at(p.w_Ycol), c.train ? 1 : 0, c.st));
   }
   for (int l = 0; l < p.Lt; ++l) {
     const LstmP& L = p.tl[l];

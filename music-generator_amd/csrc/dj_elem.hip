@@ -209,28 +209,19 @@ constexpr int CONV_K = 24, CONV_C = 3, CONV_O = 64, CONV_L = 11;   // 'same': pa
 constexpr int XCOL_LD = 80;                                        // 72 taps padded to a multiple of 8
 
 // x0[b,n,t,:] = concat[pos, class, bins, drop(tanh(conv)), drop(beat)] + drop(tanh-style)  (model.py:56-82)
-// Training additionally stashes Ycol = tanh(conv) [rows,64] and the im2col view Xcol [rows,80]
-// (72 taps in conv-kernel order k*3+c, zero padded) so BPTT gets dWc from an MFMA TN GEMM.
-// One (b,t) at a time per workgroup, notes in chunks of FEAT_NC: the X rows of a chunk are assembled in
-// LDS ([FEAT_NC][FP]) and leave with 16-byte stores; the per-row dropout keys are hashed once per note.
+// The octave convolution (Conv1D(64, 24, 'same') along the notes, model.py:56-58) is a GEMM over the im2col
+// view: (1) feature_xcol_kernel writes Xcol [rows, 80] (72 taps of the dropped-out notes in conv-kernel order
+// k*3+c, zero padded), (2) dj_gemm_nt multiplies it with the transposed kernel (+ bias) into Y [rows, 64] on the
+// MFMA units, (3) feature_asm_kernel applies tanh (stashing it in place for BPTT), dropout and the style term
+// and assembles whole X rows in LDS ([FEAT_NC][FP], 16-byte stores).  Xcol doubles as the operand of the
+// conv weight gradient (dWc = Xcol^T dY).
 constexpr int FEAT_NC = 128;
 template <typename T>
-__global__ __launch_bounds__(256) void feature_fwd_kernel(FeatArgs a, T* __restrict__ X, T* __restrict__ Xcol,
-                                                          T* __restrict__ Ycol) {
+__global__ __launch_bounds__(256) void feature_xcol_kernel(FeatArgs a, T* __restrict__ Xcol) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
   const int XR = (a.N + 3) / 4 * 4 + CONV_K + 3;          // padded note rows of the dropped-out input
   float* xin = (float*)fsm;                                // [XR][3]
-  uint32_t* rkc = (uint32_t*)(xin + XR * 3);               // [N] conv-dropout row keys
-  uint32_t* rks = rkc + a.N;                               // [N] style-dropout row keys
-  T* xrow = (T*)(fsm + ((size_t)(XR * 3 + 2 * a.N) * 4 + 15) / 16 * 16);   // [FEAT_NC][FP]
-  const int tid = threadIdx.x, o = tid & 63, ng = tid >> 6;
-  float wreg[CONV_K * CONV_C];
-#pragma unroll
-  for (int i = 0; i < CONV_K * CONV_C; ++i) wreg[i] = a.Wc[i * CONV_O + o];
-  const float bo = a.bc[o];
-  const int conv_col0 = 2 + a.octave;           // 14
-  const int nrest = a.FP - CONV_O, vpr = a.FP / 8;
-
+  const int tid = threadIdx.x;
   for (int bt = blockIdx.x; bt < a.B * a.T; bt += gridDim.x) {
     const int b = bt / a.T, t = bt % a.T;
     __syncthreads();
@@ -243,37 +234,63 @@ __global__ __launch_bounds__(256) void feature_fwd_kernel(FeatArgs a, T* __restr
       }
       xin[i] = v;
     }
+    __syncthreads();
+    for (int i = tid; i < a.N * (XCOL_LD / 8); i += 256) {      // XCOL_LD/8 16-byte vectors per note
+      const int n = i / (XCOL_LD / 8), q0 = (i % (XCOL_LD / 8)) * 8;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int q = q0 + e;
+        v[e] = q < CONV_K * CONV_C ? xin[(n + q / CONV_C) * 3 + q % CONV_C] : 0.f;
+      }
+      store8(Xcol + dj_row_ta(b, t, n, a.T, a.N) * XCOL_LD + q0, v);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void feature_asm_kernel(FeatArgs a, T* __restrict__ X, T* __restrict__ Y,
+                                                          int store_y) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  uint32_t* rkc = (uint32_t*)fsm;                          // [N] conv-dropout row keys
+  uint32_t* rks = rkc + a.N;                               // [N] style-dropout row keys
+  T* xrow = (T*)(fsm + ((size_t)(2 * a.N) * 4 + 15) / 16 * 16);   // [FEAT_NC][FP]
+  const int tid = threadIdx.x;
+  const int conv_col0 = 2 + a.octave;           // 14
+  const int nrest = a.FP - CONV_O, vpr = a.FP / 8;
+
+  for (int bt = blockIdx.x; bt < a.B * a.T; bt += gridDim.x) {
+    const int b = bt / a.T, t = bt % a.T;
+    __syncthreads();
     for (int n = tid; n < a.N; n += 256) {
       const uint32_t r = (uint32_t)bt * a.N + n;
       rkc[n] = dj_rowkey(a.d_conv, r);
       rks[n] = dj_rowkey(a.d_style, r);
     }
     __syncthreads();
-    const float spo = a.sp0[(int64_t)bt * a.F + conv_col0 + o];
     for (int n0 = 0; n0 < a.N; n0 += FEAT_NC) {
       const int nc = a.N - n0 < FEAT_NC ? a.N - n0 : FEAT_NC;
-      // octave conv: thread (o, ng) -> notes n0 + [ng*32, ng*32+32) in groups of 4
-      for (int nb = n0 + ng * (FEAT_NC / 4); nb < n0 + (ng + 1) * (FEAT_NC / 4) && nb < n0 + nc; nb += 4) {
-        float acc[4] = {bo, bo, bo, bo};
+      // conv columns: thread = (8-output chunk oc, note slot nn); 16-byte accesses to Y, 4 notes per thread in flight
+      {
+        const int oc = tid & 7, nn = tid >> 3;
+        float sp8[8];
 #pragma unroll
-        for (int kk = 0; kk < CONV_K + 3; ++kk)
+        for (int e = 0; e < 8; ++e) sp8[e] = a.sp0[(int64_t)bt * a.F + conv_col0 + oc * 8 + e];
 #pragma unroll
-          for (int c = 0; c < CONV_C; ++c) {
-            float xv = xin[(nb + kk) * 3 + c];
+        for (int it = 0; it < FEAT_NC / 32; ++it) {
+          const int n = n0 + it * 32 + nn;
+          if (n < n0 + nc) {
+            T* yp = Y + dj_row_ta(b, t, n, a.T, a.N) * CONV_O + oc * 8;
+            float y[8];
+            load8(yp, y);
 #pragma unroll
-            for (int dn = 0; dn < 4; ++dn) {
-              int k = kk - dn;
-              if (k >= 0 && k < CONV_K) acc[dn] += xv * wreg[k * CONV_C + c];
-            }
-          }
+            for (int e = 0; e < 8; ++e) y[e] = dj_tanh(y[e]);
+            if (store_y) store8(yp, y);
+            T* xp = xrow + (n - n0) * a.FP + conv_col0 + oc * 8;
 #pragma unroll
-        for (int dn = 0; dn < 4; ++dn) {
-          const int n = nb + dn;
-          if (n < a.N) {
-            const float y = dj_tanh(acc[dn]);
-            const float v = y * dj_keep(a.d_conv, rkc[n], o) + spo * dj_keep(a.d_style, rks[n], conv_col0 + o);
-            xrow[(n - n0) * a.FP + conv_col0 + o] = dj_from_f32<T>(v);
-            if (Ycol) Ycol[dj_row_ta(b, t, n, a.T, a.N) * CONV_O + o] = dj_from_f32<T>(y);
+            for (int e = 0; e < 8; ++e)
+              xp[e] = dj_from_f32<T>(y[e] * dj_keep(a.d_conv, rkc[n], oc * 8 + e) +
+                                     sp8[e] * dj_keep(a.d_style, rks[n], conv_col0 + oc * 8 + e));
           }
         }
       }
@@ -307,18 +324,6 @@ __global__ __launch_bounds__(256) void feature_fwd_kernel(FeatArgs a, T* __restr
         } else {
           ((uint4*)dst)[0] = ((const uint4*)src)[0];
           ((uint4*)dst)[1] = ((const uint4*)src)[1];
-        }
-      }
-      if (Xcol) {                                                 // im2col rows: XCOL_LD/8 vectors per note
-        for (int i = tid; i < nc * (XCOL_LD / 8); i += 256) {
-          const int nl = i / (XCOL_LD / 8), q0 = (i % (XCOL_LD / 8)) * 8, n = n0 + nl;
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int q = q0 + e;
-            v[e] = q < CONV_K * CONV_C ? xin[(n + q / CONV_C) * 3 + q % CONV_C] : 0.f;
-          }
-          store8(Xcol + dj_row_ta(b, t, n, a.T, a.N) * XCOL_LD + q0, v);
         }
       }
       __syncthreads();
@@ -866,19 +871,28 @@ int dj_launch_bins(const float* notes, float* bins, int B, int T, int N, int oct
                      dn);
   return (int)hipGetLastError();
 }
-static size_t feat_smem(int N, int FP, size_t esz) {
-  const int XR = (N + 3) / 4 * 4 + CONV_K + 3;
-  return ((size_t)(XR * 3 + 2 * N) * 4 + 15) / 16 * 16 + (size_t)FEAT_NC * FP * esz;
+// steps (1) and (3) of the feature assembly; the caller runs the conv GEMM (2) in between
+int dj_launch_feature_xcol(int dtype, const void* fa, void* Xcol, hipStream_t st) {
+  const FeatArgs& a = *(const FeatArgs*)fa;
+  const int XR = (a.N + 3) / 4 * 4 + CONV_K + 3;
+  const size_t smem = (size_t)XR * 3 * sizeof(float);
+  if (smem > 64 * 1024) return 1027;
+  int grid = a.B * a.T < 4096 ? a.B * a.T : 4096;
+  DJ_T_DISPATCH(hipLaunchKernelGGL(feature_xcol_kernel<float>, dim3(grid), dim3(256), smem, st, a, (float*)Xcol),
+                hipLaunchKernelGGL(feature_xcol_kernel<bf16_t>, dim3(grid), dim3(256), smem, st, a, (bf16_t*)Xcol))
+  return (int)hipGetLastError();
 }
-int dj_launch_feature_fwd(int dtype, const void* fa, void* X, void* Xcol, void* Ycol, hipStream_t st) {
+int dj_launch_feature_asm(int dtype, const void* fa, void* X, void* Y, int store_y, hipStream_t st) {
   const FeatArgs& a = *(const FeatArgs*)fa;
   if (a.FP - CONV_O > 64 || a.FP % 8) return 1021;
-  int grid = a.B * a.T < 2048 ? a.B * a.T : 2048;
-  if (feat_smem(a.N, a.FP, 4) > 64 * 1024) return 1027;
-  DJ_T_DISPATCH(hipLaunchKernelGGL(feature_fwd_kernel<float>, dim3(grid), dim3(256), feat_smem(a.N, a.FP, 4), st, a,
-                                   (float*)X, (float*)Xcol, (float*)Ycol),
-                hipLaunchKernelGGL(feature_fwd_kernel<bf16_t>, dim3(grid), dim3(256), feat_smem(a.N, a.FP, 2), st, a,
-                                   (bf16_t*)X, (bf16_t*)Xcol, (bf16_t*)Ycol))
+  const size_t esz = dtype == DJ_F32 ? 4 : 2;
+  const size_t smem = ((size_t)(2 * a.N) * 4 + 15) / 16 * 16 + (size_t)FEAT_NC * a.FP * esz;
+  if (smem > 64 * 1024) return 1027;
+  int grid = a.B * a.T < 4096 ? a.B * a.T : 4096;
+  DJ_T_DISPATCH(hipLaunchKernelGGL(feature_asm_kernel<float>, dim3(grid), dim3(256), smem, st, a, (float*)X, (float*)Y,
+                                   store_y),
+                hipLaunchKernelGGL(feature_asm_kernel<bf16_t>, dim3(grid), dim3(256), smem, st, a, (bf16_t*)X,
+                                   (bf16_t*)Y, store_y))
   return (int)hipGetLastError();
 }
 int dj_launch_feature_bwd(int dtype, const void* fa, const void* dX, void* Ycol, float* dbc, float* dpre0,

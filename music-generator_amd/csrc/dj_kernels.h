@@ -105,7 +105,8 @@ int dj_launch_dense_small_bwd_w(const float* A, int M, int K, const float* dC, i
 int dj_launch_dense_small_batch(const DenseBatch* d, int act_tanh, hipStream_t st);
 int dj_launch_dense_small_batch_bwd(const DenseBatch* d, float* dA, hipStream_t st);
 int dj_launch_bins(const float* notes, float* bins, int B, int T, int N, int octave, DjDrop dn, hipStream_t st);
-int dj_launch_feature_fwd(int dtype, const void* fa, void* X, void* Xcol, void* Ycol, hipStream_t st);
+int dj_launch_feature_xcol(int dtype, const void* fa, void* Xcol, hipStream_t st);
+int dj_launch_feature_asm(int dtype, const void* fa, void* X, void* Y, int store_y, hipStream_t st);
 int dj_launch_feature_bwd(int dtype, const void* fa, const void* dX, void* Ycol, float* dbc, float* dpre0,
                           hipStream_t st);
 int dj_launch_glue_fwd(int dtype, const void* ga, const void* Hin, void* X, hipStream_t st);
