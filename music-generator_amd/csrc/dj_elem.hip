@@ -338,46 +338,76 @@ __global__ __launch_bounds__(256) void feature_asm_kernel(FeatArgs a, T* __restr
 template <typename T>
 __global__ __launch_bounds__(256) void feature_bwd_kernel(FeatArgs a, const T* __restrict__ dX, T* __restrict__ Ycol,
                                                           float* __restrict__ dbc, float* __restrict__ dpre0) {
-  __shared__ float red[2 * 128 + 4 * 64];
+  // the dX rows of one (b,t) (FEAT_NC notes at a time) are staged in LDS once and feed both reductions
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  T* dxs = (T*)fsm;                                               // [FEAT_NC][FP]
+  uint32_t* rkc = (uint32_t*)(fsm + (size_t)FEAT_NC * a.FP * sizeof(T));   // [FEAT_NC] conv-dropout row keys
+  uint32_t* rks = rkc + FEAT_NC;                                  // [FEAT_NC] style-dropout row keys
+  float* red = (float*)(rks + FEAT_NC);                           // [2][128] style partials, [64] conv-bias sums
   const int tid = threadIdx.x;
-  const int conv_col0 = 2 + a.octave;
-  float bsum = 0.f;                                  // thread (o = tid&63, ng = tid>>6)
+  const int conv_col0 = 2 + a.octave, vpr = a.FP / 8;
+  const int oc = tid & 7, nn = tid >> 3;                          // conv part: (8-output chunk, note slot)
+  const int d = tid % 128, part = tid / 128;                      // style part: (column, note half)
+  float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (tid < 64) red[256 + tid] = 0.f;
   for (int bt = blockIdx.x; bt < a.B * a.T; bt += gridDim.x) {
     const int b = bt / a.T, t = bt % a.T;
-    __syncthreads();
-    {
-      const int d = tid % 128, part = tid / 128;
-      if (d < a.F) {
-        float s = 0.f;
-        const int nh = (a.N + 1) / 2;
-        for (int n = part * nh; n < (part + 1) * nh && n < a.N; ++n) {
-          const uint32_t r = (uint32_t)bt * a.N + n;
-          s += dj_to_f32(dX[dj_row_ta(b, t, n, a.T, a.N) * a.FP + d]) * dj_keep(a.d_style, dj_rowkey(a.d_style, r), d);
+    float ssum = 0.f;
+    for (int n0 = 0; n0 < a.N; n0 += FEAT_NC) {
+      const int nc = a.N - n0 < FEAT_NC ? a.N - n0 : FEAT_NC;
+      __syncthreads();
+      for (int i = tid; i < nc * vpr; i += 256) {
+        const int nl = i / vpr, cv = (i - nl * vpr) * 8;
+        const T* src = dX + dj_row_ta(b, t, n0 + nl, a.T, a.N) * a.FP + cv;
+        T* dst = dxs + nl * a.FP + cv;
+        if constexpr (sizeof(T) == 2) {
+          *(uint4*)dst = *(const uint4*)src;
+        } else {
+          ((uint4*)dst)[0] = ((const uint4*)src)[0];
+          ((uint4*)dst)[1] = ((const uint4*)src)[1];
         }
-        red[part * 128 + d] = s;
+      }
+      for (int nl = tid; nl < nc; nl += 256) {
+        const uint32_t r = (uint32_t)bt * a.N + n0 + nl;
+        rkc[nl] = dj_rowkey(a.d_conv, r);
+        rks[nl] = dj_rowkey(a.d_style, r);
+      }
+      __syncthreads();
+      if (d < a.F) {                                              // style gradient: sum over the notes
+        const int nh = (nc + 1) / 2;
+        for (int nl = part * nh; nl < (part + 1) * nh && nl < nc; ++nl)
+          ssum += dj_to_f32(dxs[nl * a.FP + d]) * dj_keep(a.d_style, rks[nl], d);
+      }
+#pragma unroll
+      for (int it = 0; it < FEAT_NC / 32; ++it) {                 // conv pre-activation gradient, in place over Ycol
+        const int nl = it * 32 + nn;
+        if (nl < nc) {
+          T* yp = Ycol + dj_row_ta(b, t, n0 + nl, a.T, a.N) * CONV_O + oc * 8;
+          float y[8];
+          load8(yp, y);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float g = dj_to_f32(dxs[nl * a.FP + conv_col0 + oc * 8 + e]) *
+                            dj_keep(a.d_conv, rkc[nl], oc * 8 + e) * (1.f - y[e] * y[e]);
+            y[e] = g;
+            bs[e] += g;
+          }
+          store8(yp, y);
+        }
       }
     }
+    if (d < a.F) red[part * 128 + d] = ssum;
     __syncthreads();
     if (tid < a.F) {
       const float sp = a.sp0[(int64_t)bt * a.F + tid];
       dpre0[(int64_t)bt * a.F + tid] = (red[tid] + red[128 + tid]) * (1.f - sp * sp);
     }
-    const int o = tid & 63, ng = tid >> 6;
-    for (int n = ng; n < a.N; n += 4) {
-      const uint32_t r = (uint32_t)bt * a.N + n;
-      const int64_t row = dj_row_ta(b, t, n, a.T, a.N);
-      const float y = dj_to_f32(Ycol[row * CONV_O + o]);
-      const float g = dj_to_f32(dX[row * a.FP + conv_col0 + o]) * dj_keep(a.d_conv, dj_rowkey(a.d_conv, r), o) *
-                      (1.f - y * y);
-      Ycol[row * CONV_O + o] = dj_from_f32<T>(g);
-      bsum += g;
-    }
   }
   __syncthreads();
-  float* r4 = red + 256;
-  r4[(tid >> 6) * 64 + (tid & 63)] = bsum;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) atomicAdd(&red[256 + oc * 8 + e], bs[e]);
   __syncthreads();
-  if (tid < 64) atomicAdd(dbc + tid, r4[tid] + r4[64 + tid] + r4[128 + tid] + r4[192 + tid]);
+  if (tid < 64) atomicAdd(dbc + tid, red[256 + tid]);
 }
 
 // ------------------------------------------------------------------ inter-layer glue
@@ -900,9 +930,13 @@ int dj_launch_feature_bwd(int dtype, const void* fa, const void* dX, void* Ycol,
   const FeatArgs& a = *(const FeatArgs*)fa;
   if (a.F > 128) return 1022;
   int grid = a.B * a.T < 2048 ? a.B * a.T : 2048;
-  DJ_T_DISPATCH(hipLaunchKernelGGL(feature_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, a, (const float*)dX,
+  if (a.FP % 8) return 1021;
+  const size_t esz = dtype == DJ_F32 ? 4 : 2;
+  const size_t smem = (size_t)FEAT_NC * a.FP * esz + (size_t)2 * FEAT_NC * 4 + (size_t)(256 + 64) * 4;
+  if (smem > 64 * 1024) return 1027;
+  DJ_T_DISPATCH(hipLaunchKernelGGL(feature_bwd_kernel<float>, dim3(grid), dim3(256), smem, st, a, (const float*)dX,
                                    (float*)Ycol, dbc, dpre0),
-                hipLaunchKernelGGL(feature_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a, (const bf16_t*)dX,
+                hipLaunchKernelGGL(feature_bwd_kernel<bf16_t>, dim3(grid), dim3(256), smem, st, a, (const bf16_t*)dX,
                                    (bf16_t*)Ycol, dbc, dpre0))
   return (int)hipGetLastError();
 }
