@@ -297,7 +297,13 @@ class TrainableModel(Model):
         if target is None:
             target = chosen
         B, T = notes.shape[0], notes.shape[1]
-        eng = s.engine(B, T, train=True)
+        # micro-batches (DEEPJ_MICRO_BATCH=k): a batch that is a multiple of k runs as B/k passes of k sequences
+        # with gradient accumulation -- one workspace of k sequences, one optimizer step (how the scaled
+        # 3x1024 model takes its global batch of 128).  As with data-parallel ranks, pitch_bins (model.py:43-49)
+        # couples samples within a micro-batch only.
+        micro = int(os.environ.get("DEEPJ_MICRO_BATCH", "0") or 0)
+        parts = B // micro if (micro > 0 and B > micro and B % micro == 0 and hasattr(be, "resident")) else 1
+        eng = s.engine(B // parts, T, train=True)
         if s.grads is None:
             s.grads = be.tensor(np.zeros(s.nparams, np.float32))
         if s.optimizer is None:
@@ -307,7 +313,16 @@ class TrainableModel(Model):
         world = dist.get_world_size() if dist else 1
         seed = (s.seed * 1000003 + s.step * world + rank) & 0xFFFFFFFF
         t = [notes, chosen, beat, style, target] if on_device else [be.tensor(a) for a in (notes, chosen, beat, style, target)]
-        loss = eng.train_fwd_bwd(s.params, s.grads, *t, seed=seed)
+        if parts == 1:
+            loss = eng.train_fwd_bwd(s.params, s.grads, *t, seed=seed)
+        else:
+            k, loss = B // parts, None
+            for i in range(parts):
+                mb = [x_[i * k:(i + 1) * k].contiguous() for x_ in t]
+                li = eng.train_fwd_bwd(s.params, s.grads, *mb, seed=(seed + 7919 * i) & 0xFFFFFFFF, accumulate=i > 0)
+                loss = li.clone() if loss is None else loss + li
+            loss = loss / parts                              # equal parts: mean of the micro-batch means
+            s.grads.mul_(1.0 / parts)
         weight = float(B)
         if dist:
             import torch
