@@ -13,6 +13,15 @@
 // kernel U is streamed every step from L2 as pre-packed MFMA B fragments (one
 // coalesced 1 KiB wave-load per fragment, software-pipelined PD chunks ahead).
 //
+// Variants (RecCfg flags; DESIGN.md section 5 has the measurements behind each):
+//  * lstm_fwd_fused_kernel: x_t W is computed inside the step from an LDS-staged X tile, W and U being one
+//    continuous fragment stream (no Zx round trip through HBM);
+//  * H = 128 in bf16 (one wave per SIMD, VGPR + AGPR): the wave's slices of U / U^T, of W up to 128 input
+//    columns and of W^T of a <= 128-wide layer are loaded once and stay in registers (STATF / STATB / WSTAT /
+//    DX), so the note-axis recurrence streams no weights; wider inputs stream W 8 fragments deep;
+//  * the BPTT kernel can also emit dX = dz W^T (whole, or the last 32-column block with K split over the
+//    waves) from the dz tile it holds in LDS.
+//
 // Data layouts in HBM:
 //  * Z  (x_t W + b in, pre-activations z_t out, in place) and the cell stash C are
 //    FRAGMENT-TILED: for 32-row block rb (= tile*steps + step) and 32-col block cb,
