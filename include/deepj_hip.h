@@ -187,6 +187,13 @@ int32_t dj_lstm_pack_wt(int32_t dtype, int32_t H, const float* W, int32_t D, voi
 int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack_bwd,
                        const void* C, const void* dH, void* dZ, float* dbias, int32_t recurrent_sigmoid,
                        const void* wtpack, int32_t D, void* dX, int32_t DP, void* stream);
+/* The bf16 H = 256 forward sweep of 64..256 tiles runs as weight-stationary clusters of 8 workgroups that meet
+ * once per step through a counter in L2 (dj_lstm.hip); a member that never arrives (grid not co-resident, e.g.
+ * the device shared with another stream's kernels) cannot hang the device: the wait expires, the affected
+ * tiles carry NaN from there on (so does the loss), and the event is counted.  Returns the number of expired
+ * waits since the previous call (synchronises the device; 0 in a healthy run), -1 on a HIP error.
+ * DEEPJ_CLUSTER=0 in the environment selects the per-tile kernel instead. */
+int32_t dj_lstm_cluster_faults(void);
 /* mask[rows, cols] (fp32 0 or 1/(1-p)) of dropout site `site` -- exposes the counter
  * hash so tests can pin it against the oracle. */
 int32_t dj_dropout_mask(uint64_t seed, int32_t site, float p, int64_t rows, int32_t cols, float* mask, void* stream);

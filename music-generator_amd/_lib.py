@@ -57,6 +57,7 @@ _SIGS = {
     "dj_lstm_bwd_dx": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P,
                                    C.c_int32, _P, C.c_int32, _P]),
     "dj_lstm_pack_wt": (C.c_int32, [C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),
+    "dj_lstm_cluster_faults": (C.c_int32, []),
     "dj_dropout_mask": (C.c_int32, [C.c_uint64, C.c_int32, C.c_float, C.c_int64, C.c_int32, _P, _P]),
     "dj_profile_enable": (C.c_int32, [C.c_int32]),
     "dj_profile_category_count": (C.c_int32, []),

@@ -775,6 +775,7 @@ int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, 
   return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dbias, sigm, wtpack, D, dX, DP,
                             (hipStream_t)stream);
 }
+int32_t dj_lstm_cluster_faults(void) { return dj_lstm_cluster_faults_impl(); }
 int32_t dj_lstm_pack_wt(int32_t dtype, int32_t H, const float* W, int32_t D, void* out, void* stream) {
   return dj_launch_lstm_pack_wt(dtype, H, W, D, out, (hipStream_t)stream);
 }

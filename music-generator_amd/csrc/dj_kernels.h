@@ -89,6 +89,8 @@ int dj_launch_lstm_pack_w(int dtype, int H, const float* W, int D, int NKX, void
 int dj_launch_lstm_fwd_fused(int dtype, int H, int ntiles, int steps, const void* X, int DP, int NKX,
                              const void* Wpack, const float* bias, void* Zst, const void* Upack, void* Hout,
                              void* Cout, int sigm, hipStream_t st);
+// expired cluster waits since the last call (0 in a healthy run; the affected tiles carry NaN), -1 on a HIP error
+int dj_lstm_cluster_faults_impl();
 // dj_step.hip -- generic-H path (one GEMM + gate launch per recurrence step)
 int64_t dj_lstm_step_scratch_floats(int H, int64_t ntiles);
 int dj_launch_lstm_step_fwd(int dtype, int H, int ntiles, int steps, void* Z, const void* Ut, void* Hs, void* Cs,

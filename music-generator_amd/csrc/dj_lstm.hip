@@ -32,6 +32,8 @@
 //    perfectly coalesced -- no scalar loads, no partial-line writes.
 //  * h (Hout), dH and dz are ROW-MAJOR [rows, cols] (they feed the GEMMs and the
 //    glue kernels) and go through LDS for wide coalesced rows.
+#include <stdlib.h>
+
 #include "dj_kernels.h"
 
 #ifdef DJ_EXP_STAMP
@@ -526,6 +528,236 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
   }
 }
 
+// ---------------------------------------------------------------- forward, weight-stationary cluster (bf16, H = 256)
+// The per-tile kernel above streams every W and U fragment from L2 every step in every workgroup: 33.5 GB of
+// L2 reads per launch of time layer 1, ~72 % of the chip's aggregate L2 bandwidth, which is what bounds it.
+// Here 8 workgroups that share an XCD (blocks b, b+8, ..., b+56) form a CLUSTER that owns 8 sequence tiles:
+// member s owns hidden units [32s, 32s+32) of all four gates, whose W and U slices (the fragment slices of
+// "wave s" of the per-tile kernel: 4*NKX + 64 KiB) stay in LDS for the whole sweep; wave w multiplies the 32
+// rows of tile w, [x_t | h_{t-1}], with them, so the cell update stays lane-local.  Per step a workgroup now
+// reads 8 x (16 KiB x + 16 KiB h) instead of 1 MiB of weights.  Every member writes its 32-unit slice of
+// h_t; a per-cluster counter in L2 closes the step.  The x_t W half does not depend on the exchange and runs
+// before the wait.
+//  * x rows are fetched as full 128-byte lines (8 lanes per row) and turned into A fragments through a 4 KiB
+//    LDS tile per wave, 64 columns per round (fragments read straight from the rows are 32 segments of 32 bytes
+//    per instruction).
+//  * h travels in the MFMA A-fragment image (dj_cluster_hx below), one contiguous 1 KiB load per fragment.
+//  * Measured dead ends: requesting x_{t+1} a step ahead -- loads return in order, so the
+//    h fragments queue behind the HBM reads -- and per-tile counters without the workgroup barrier.
+// Coherence: members of a cluster run on ONE XCD (round-robin workgroup dispatch, any power-of-two XCD count),
+// whose L2 is the coherence point for their h slices -- stores are acknowledged (vmcnt 0) before the counter is
+// bumped, the exchange loads bypass L1 (sc1).  The wait is bounded: an expired wait (grid not co-resident)
+// poisons the tile's cell state with NaN and is counted (dj_lstm_cluster_faults), never a silent wrong answer
+// and never a hung device; the launcher only uses this kernel when the device has a compute unit per workgroup.
+#ifndef DJ_EXP_CL_XAHEAD
+#define DJ_EXP_CL_XAHEAD 0
+#endif
+__device__ int dj_cluster_cnt[64];
+__device__ int dj_cluster_fault;              // expired waits since the last dj_cluster_faults()
+constexpr int CL_M = 8;                      // members (= tiles) per cluster
+// h exchange in the exact MFMA A-fragment image: [tile][step parity][kc][lane] x 16 bytes, so a consumer wave
+// fetches a fragment as ONE contiguous 1 KiB load (row-major h rows would be 32 segments of 32 bytes per
+// fragment: measured 13 k cycles per 16 fragments) and a producer stores its two chunks the same way.  The two
+// parities are reused every other step, so the consumer loads bypass the (non-coherent) L1 with sc1.
+__device__ uint4 dj_cluster_hx[256 * 2 * 16 * 64];
+__device__ __forceinline__ uint4 ld_sc1(const uint4* p) {
+  uint4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+template <int NR> struct ClXRegs { uint4 v[NR][4]; };
+// rows r8, r8+8, r8+16, r8+24 of a 32-row block, 16 bytes at column 64 r + 8 xc each (zero past DP), rounds R0..R1-1
+template <int NR, int R0, int R1>
+__device__ __forceinline__ void cl_load_x(ClXRegs<NR>& q, const bf16_t* xb, int DP, int xc) {
+#pragma unroll
+  for (int r = R0; r < R1; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = r * 64 + xc * 8 < DP;
+      const uint4 v = *(const uint4*)(xb + (ok ? 8 * i * DP + r * 64 : 0));
+      q.v[r][i] = ok ? v : make_uint4(0, 0, 0, 0);
+    }
+}
+template <bool SIGM, int NKX>
+__global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __restrict__ X, int DP,
+                                                               const bf16_t* __restrict__ Wpack,
+                                                               const float* __restrict__ bias,
+                                                               bf16_t* __restrict__ Zst,
+                                                               const bf16_t* __restrict__ Upack,
+                                                               bf16_t* __restrict__ Hout, bf16_t* __restrict__ Cout,
+                                                               int steps) {
+  using T = bf16_t;
+  constexpr int H = 256;
+  using R = RecCfg<T, H>;
+  using Frag = typename DjFrag<T>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Frag* Bw = (Frag*)smem_raw;                              // [4][NKX][64]  W slice of this member
+  Frag* Bu = Bw + 4 * NKX * 64;                            // [4][NKC][64]  U slice
+  T* hto = (T*)(Bu + 4 * R::NKC * 64);                     // [8 waves] 4 KiB: x transposition rounds / h_t tile
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, s = j & (CL_M - 1);
+  const int cid = xcd + 8 * (j >> 3);                      // cluster id; its tiles are CL_M*cid .. CL_M*cid+7
+  const int64_t tile = (int64_t)CL_M * cid + w;            // this wave's tile
+  int* cnt = dj_cluster_cnt + cid;
+
+  // stationary operand slices -> LDS (contiguous in the packed streams)
+  {
+    const uint4* gw = (const uint4*)((const Frag*)Wpack + (int64_t)s * 4 * NKX * 64);
+    const uint4* gu = (const uint4*)((const Frag*)Upack + (int64_t)s * 4 * R::NKC * 64);
+    for (int i = tid; i < 4 * NKX * 64; i += 512) ((uint4*)Bw)[i] = gw[i];
+    for (int i = tid; i < 4 * R::NKC * 64; i += 512) ((uint4*)Bu)[i] = gu[i];
+  }
+  float c[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r] = 0.f;
+  float bv[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bv[g] = bias[g * H + s * 32 + l31];
+  __syncthreads();
+
+  unsigned char* xs = (unsigned char*)hto + w * 4096;      // this wave's 4 KiB tile: x rounds, then the h tile
+  T* ht = (T*)xs;
+  // x rows are fetched as full 128-byte lines, 8 lanes per row (fragments read straight from the rows would be
+  // 32 segments of 32 bytes per instruction), ONE STEP AHEAD: the reads of a step otherwise queue behind the
+  // write burst of the previous one in HBM (measured: 8 k cycles until x_t arrives, a quarter of the step).
+  const int xr8 = lane >> 3, xc = lane & 7;
+  constexpr int NR = (NKX + 3) / 4, NRA = (NR + 1) / 2;   // rounds; those requested with the h fragments
+  ClXRegs<NR> xq;
+#if DJ_EXP_CL_XAHEAD
+  cl_load_x<NR, 0, NR>(xq, X + (tile * steps * 32 + xr8) * DP + xc * 8, DP, xc);
+#endif
+  for (int t = 0; t < steps; ++t) {
+    const int64_t rb = tile * steps + t;
+    DJ_STAMP(0, 0, t);
+    f32x16 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;   // bias joins in the cell update (a hoisted splat would spill)
+    // ---- x_t W: independent of the exchange; x_t was requested during the previous step (see below) and is
+    // turned into A fragments through this wave's 4 KiB LDS tile, 64 columns per round.
+    {
+#if !DJ_EXP_CL_XAHEAD
+      cl_load_x<NR, 0, NR>(xq, X + (rb * 32 + xr8) * DP + xc * 8, DP, xc);
+#endif
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(uint4*)(xs + (xr8 + 8 * i) * 128 + ((xc ^ xr8) << 4)) = xq.v[r][i];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int kc = 4 * r + q;
+          if (kc < NKX) {
+            const Frag a = *(const Frag*)(xs + l31 * 128 + (((2 * q + h) ^ (l31 & 7)) << 4));
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dj_mfma(acc[g], a, Bw[(g * NKX + kc) * 64 + lane]);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    DJ_STAMP(0, 1, t);
+#if DJ_EXP_CL_XAHEAD
+    const T* xnext = X + ((tile * steps + (t + 1 < steps ? t + 1 : t)) * 32 + xr8) * DP + xc * 8;
+#endif
+    // ---- h_{t-1} U: needs the slices of all members
+    if (t > 0) {
+      int ok = 1;
+      if (lane == 0) {
+        const int target = CL_M * t;
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while ((ok = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) == 0 &&
+               __builtin_readcyclecounter() - t0 < 20000000ull)       // ~10 ms: hang protection only
+          __builtin_amdgcn_s_sleep(2);
+      }
+      if (!__builtin_amdgcn_readfirstlane(ok)) {
+        // a member never arrived (grid not co-resident): never a silent wrong answer -- count it and poison the
+        // cell state, so every later h of this tile, and the loss, is NaN
+        if (lane == 0) atomicAdd(&dj_cluster_fault, 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = __builtin_nanf("");
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+      DJ_STAMP(0, 2, t);
+      const uint4* hx = dj_cluster_hx + ((tile * 2 + ((t - 1) & 1)) * 16) * 64 + lane;
+      uint4 ah[R::NKC];
+#pragma unroll
+      for (int kc = 0; kc < R::NKC; ++kc) ah[kc] = ld_sc1(hx + kc * 64);
+      asm volatile("" ::: "memory");
+      // the first rounds of x_{t+1} go out right behind the h fragments (loads return in order: in front they
+      // would hold the h fragments back), always 4*NRA requests, so the wait below is a constant
+#if DJ_EXP_CL_XAHEAD == 1
+      cl_load_x<NR, 0, NRA>(xq, xnext, DP, xc);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NRA) : "memory");
+#else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#pragma unroll
+      for (int kc = 0; kc < R::NKC; ++kc) {
+        Frag a;
+        __builtin_memcpy(&a, &ah[kc], 16);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dj_mfma(acc[g], a, Bu[(g * R::NKC + kc) * 64 + lane]);
+      }
+    }
+#if DJ_EXP_CL_XAHEAD == 1
+    else
+      cl_load_x<NR, 0, NRA>(xq, xnext, DP, xc);
+    cl_load_x<NR, NRA, NR>(xq, xnext, DP, xc);   // the rest once the h fragments' registers are free
+#endif
+    DJ_STAMP(0, 3, t);
+    // ---- cell update (lane-local), stash, h slice out
+    float cv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float zi = (acc[0][r] += bv[0]), zf = (acc[1][r] += bv[1]), zg = (acc[2][r] += bv[2]),
+                  zo = (acc[3][r] += bv[3]);
+      const float ig = dj_ract<SIGM>(zi), fg = dj_ract<SIGM>(zf), gg = dj_tanh(zg), og = dj_ract<SIGM>(zo);
+      const float cn = fg * c[r] + ig * gg;
+      c[r] = cn;
+      cv[r] = cn;
+      ht[dj_crow(r, lane) * 32 + l31] = dj_from_f32<T>(og * dj_tanh(cn));
+    }
+    DJ_STAMP(0, 4, t);
+    if (Cout) store_frag(Cout + ((rb * R::NCBH + s) * 64 + lane) * 16, cv);
+    if (Zst) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float zv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zv[r] = acc[g][r];
+        store_frag(Zst + ((rb * R::NCB + (g * H + s * 32) / 32) * 64 + lane) * 16, zv);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // h tile of this wave: 32 rows x 64 bytes -> 2 x 16-byte vectors per lane
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = lane + 64 * i, row = v >> 2, cq = (v & 3) * 8;
+      *(uint4*)(Hout + (rb * 32 + row) * H + s * 32 + cq) = *(const uint4*)(ht + row * 32 + cq);
+    }
+    // the same slice in fragment image for the exchange: chunks 2s, 2s+1 of this tile, 1 KiB each
+    {
+      uint4* hxo = dj_cluster_hx + ((tile * 2 + (t & 1)) * 16 + 2 * s) * 64 + lane;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) hxo[jj * 64] = *(const uint4*)(ht + l31 * 32 + 16 * jj + 8 * h);
+    }
+    // every wave's stores acknowledged by L2, then one increment per member
+    DJ_STAMP(0, 5, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DJ_STAMP(0, 6, t);
+#if DJ_EXP_CL_XAHEAD == 2
+    cl_load_x<NR, 0, NR>(xq, xnext, DP, xc);    // x_{t+1} travels while the members meet
+#endif
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ---------------------------------------------------------------- backward (BPTT)
 // Z: fragment-tiled pre-activations (read only); dZ: row-major [M,4H] output.
 // DX (stationary-U^T builds only): the kernel also produces the layer's input gradient dX_t = dz_t W^T from
@@ -954,6 +1186,57 @@ int launch_fwd_fused(int ntiles, int steps, const void* X, int DP, int NKX, cons
               : launch_fwd_fused_s<T, H, false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, st);
 }
 
+template <bool SIGM, int NKX>
+int launch_fwd_cluster_k(int ntiles, int steps, const void* X, int DP, const void* Wpack, const float* bias,
+                         void* Zst, const void* Upack, void* Hout, void* Cout, size_t smem, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_cluster_kernel<SIGM, NKX>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((lstm_fwd_cluster_kernel<SIGM, NKX>), dim3(ntiles), dim3(512), smem, st, (const bf16_t*)X, DP,
+                     (const bf16_t*)Wpack, bias, (bf16_t*)Zst, (const bf16_t*)Upack, (bf16_t*)Hout, (bf16_t*)Cout, steps);
+  return (int)hipGetLastError();
+}
+template <bool SIGM>
+int launch_fwd_cluster_s(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
+                         void* Zst, const void* Upack, void* Hout, void* Cout, size_t smem, hipStream_t st) {
+  switch (NKX) {   // the input widths the model has: 94 -> 6 chunks, 256 -> 16 (dj_lstm_cluster_ok)
+    case 6: return launch_fwd_cluster_k<SIGM, 6>(ntiles, steps, X, DP, Wpack, bias, Zst, Upack, Hout, Cout, smem, st);
+    case 16: return launch_fwd_cluster_k<SIGM, 16>(ntiles, steps, X, DP, Wpack, bias, Zst, Upack, Hout, Cout, smem, st);
+  }
+  return 1016;
+}
+// compute units of the current device (one 160 KiB workgroup each): the cluster kernel needs its whole grid resident
+int cluster_cus() {
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+int launch_fwd_cluster(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
+                       void* Zst, const void* Upack, void* Hout, void* Cout, int sigm, hipStream_t st) {
+  using R = RecCfg<bf16_t, 256>;
+  if (ntiles % CL_M || ntiles > 256 || ntiles / CL_M > 64 || NKX * R::KC > 256 || DP > 256 || DP % 8) return 1016;
+  const size_t smem = (size_t)(4 * NKX * 64 + 4 * R::NKC * 64) * 16 + (size_t)8 * 4096;
+  static void* cnt_addr = nullptr;
+  if (!cnt_addr) {
+    hipError_t e = hipGetSymbolAddress(&cnt_addr, HIP_SYMBOL(dj_cluster_cnt));
+    if (e != hipSuccess) return (int)e;
+  }
+  hipError_t e = hipMemsetAsync(cnt_addr, 0, sizeof(int) * 64, st);
+  if (e != hipSuccess) return (int)e;
+  return sigm ? launch_fwd_cluster_s<true>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, st)
+              : launch_fwd_cluster_s<false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, st);
+}
+
 }  // namespace
 
 #define DJ_DISPATCH_TH(FN, ...)                                     \
@@ -1004,9 +1287,25 @@ int dj_lstm_fused_nkx(int dtype, int H, int D) {
 int dj_launch_lstm_pack_w(int dtype, int H, const float* W, int D, int NKX, void* out, hipStream_t st) {
   DJ_DISPATCH_TH(launch_pack_w, W, D, NKX, out, st)
 }
+int dj_lstm_cluster_faults_impl() {
+  int n = 0, zero = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(dj_cluster_fault), sizeof(int)) != hipSuccess) return -1;
+  if (n && hipMemcpyToSymbol(HIP_SYMBOL(dj_cluster_fault), &zero, sizeof(int)) != hipSuccess) return -1;
+  return n;
+}
 int dj_launch_lstm_fwd_fused(int dtype, int H, int ntiles, int steps, const void* X, int DP, int NKX,
                              const void* Wpack, const float* bias, void* Zst, const void* Upack, void* Hout,
                              void* Cout, int sigm, hipStream_t st) {
   if (ntiles <= 0 || steps <= 0) return 0;
+#ifndef DJ_EXP_CLUSTER
+#define DJ_EXP_CLUSTER 1
+#endif
+  // weight-stationary cluster kernel where the whole grid is co-resident and splits into clusters of 8 tiles
+  if (DJ_EXP_CLUSTER && dtype == DJ_BF16 && H == 256 && ntiles % CL_M == 0 && ntiles <= 256 && ntiles >= 64 &&
+      (NKX == 6 || NKX == 16) && DP <= 256) {
+    const char* e = getenv("DEEPJ_CLUSTER");
+    if (!(e && e[0] == '0') && cluster_cus() >= ntiles)
+      return launch_fwd_cluster(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, sigm, st);
+  }
   DJ_DISPATCH_TH(launch_fwd_fused, ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, sigm, st)
 }

@@ -336,6 +336,14 @@ class TrainableModel(Model):
             loss_value = float(lw.cpu()[0])
         else:
             loss_value = float(be.numpy(loss)[0])
+        if loss_value != loss_value:
+            # a NaN loss can be the mark of an expired cluster wait (include/deepj_hip.h dj_lstm_cluster_faults):
+            # name it, and leave the parameters untouched
+            from . import _lib
+            faults = _lib.load().dj_lstm_cluster_faults()
+            if faults:
+                raise RuntimeError("%d cluster waits of the recurrent forward kernel expired (device shared with other "
+                                   "kernels?); set DEEPJ_CLUSTER=0 to use the per-tile kernel" % faults)
         s.optimizer.step(s.params, s.grads, 1.0)
         s.step += 1
         return loss_value

@@ -252,7 +252,9 @@ def test_nadam_matches_oracle(gpu_device):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("H,S,Ls,D", [(256, 64, 5, 94), (128, 40, 6, 259), (256, 32, 3, 256), (128, 96, 4, 128),
-                                      (128, 40, 6, 90)])
+                                      (128, 40, 6, 90),
+                                      # 64 / 256 sequence tiles: bf16 H = 256 takes the weight-stationary cluster kernel
+                                      (256, 2048, 6, 256), (256, 8192, 3, 94)])
 def test_lstm_fwd_fused_input_projection(gpu_device, dtype, H, S, Ls, D):
     """z = x W + h U + b inside the recurrent kernel (dj_lstm_fwd_fused) vs the restated cell."""
     L, lib = _lib()
@@ -289,6 +291,7 @@ def test_lstm_fwd_fused_input_projection(gpu_device, dtype, H, S, Ls, D):
     torch.testing.assert_close(from_rows(Hd.float().cpu(), S, Ls), Href, rtol=rt, atol=at * 5)
     torch.testing.assert_close(from_rows(from_frag(Cd.float().cpu(), R, H), S, Ls), Cref, rtol=rt, atol=at * 5)
     torch.testing.assert_close(from_rows(from_frag(Zd.float().cpu(), R, 4 * H), S, Ls), Zref, rtol=rt, atol=at * 10)
+    assert lib.dj_lstm_cluster_faults() == 0      # no cluster wait expired
 
 
 @pytest.mark.parametrize("D", [128, 90])
