@@ -1203,8 +1203,8 @@ int launch_fwd_cluster_k(int ntiles, int steps, const void* X, int DP, const voi
 template <bool SIGM>
 int launch_fwd_cluster_s(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
                          void* Zst, const void* Upack, void* Hout, void* Cout, size_t smem, hipStream_t st) {
-  switch (NKX) {   // the input widths the model has: 94 -> 6 chunks, 256 -> 16 (dj_lstm_cluster_ok)
-    case 6: return launch_fwd_cluster_k<SIGM, 6>(ntiles, steps, X, DP, Wpack, bias, Zst, Upack, Hout, Cout, smem, st);
+  switch (NKX) {   // the input widths the model has (dj_lstm_fused_nkx): 94 -> 8 chunks, 256 -> 16
+    case 8: return launch_fwd_cluster_k<SIGM, 8>(ntiles, steps, X, DP, Wpack, bias, Zst, Upack, Hout, Cout, smem, st);
     case 16: return launch_fwd_cluster_k<SIGM, 16>(ntiles, steps, X, DP, Wpack, bias, Zst, Upack, Hout, Cout, smem, st);
   }
   return 1016;
@@ -1224,7 +1224,8 @@ int cluster_cus() {
 int launch_fwd_cluster(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
                        void* Zst, const void* Upack, void* Hout, void* Cout, int sigm, hipStream_t st) {
   using R = RecCfg<bf16_t, 256>;
-  if (ntiles % CL_M || ntiles > 256 || ntiles / CL_M > 64 || NKX * R::KC > 256 || DP > 256 || DP % 8) return 1016;
+  // blocks come in groups of 64 = 8 XCDs x 8 members (cluster id = xcd + 8 * group)
+  if (ntiles % 64 || ntiles > 256 || NKX * R::KC > 256 || DP > 256 || DP % 8) return 1016;
   const size_t smem = (size_t)(4 * NKX * 64 + 4 * R::NKC * 64) * 16 + (size_t)8 * 4096;
   static void* cnt_addr = nullptr;
   if (!cnt_addr) {
@@ -1300,12 +1301,25 @@ int dj_launch_lstm_fwd_fused(int dtype, int H, int ntiles, int steps, const void
 #ifndef DJ_EXP_CLUSTER
 #define DJ_EXP_CLUSTER 1
 #endif
-  // weight-stationary cluster kernel where the whole grid is co-resident and splits into clusters of 8 tiles
-  if (DJ_EXP_CLUSTER && dtype == DJ_BF16 && H == 256 && ntiles % CL_M == 0 && ntiles <= 256 && ntiles >= 64 &&
-      (NKX == 6 || NKX == 16) && DP <= 256) {
+  // weight-stationary cluster kernel, in launches whose whole grid is co-resident (at most one workgroup per
+  // compute unit) and splits into groups of 8 clusters of 8 tiles; what is left over takes the per-tile kernel
+  if (DJ_EXP_CLUSTER && dtype == DJ_BF16 && H == 256 && ntiles >= 64 && (NKX == 8 || NKX == 16) && DP <= 256) {
     const char* e = getenv("DEEPJ_CLUSTER");
-    if (!(e && e[0] == '0') && cluster_cus() >= ntiles)
-      return launch_fwd_cluster(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, sigm, st);
+    const int cap = cluster_cus() < 256 ? cluster_cus() / 64 * 64 : 256;   // groups of 64 = 8 XCDs x 8 members
+    if (!(e && e[0] == '0') && cap >= 64) {
+      while (ntiles >= 64) {
+        const int n = ntiles < cap ? ntiles / 64 * 64 : cap;
+        const int rc = launch_fwd_cluster(n, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, sigm, st);
+        if (rc) return rc;
+        const int64_t rows = (int64_t)n * steps * 32;      // all five buffers are tile-major
+        X = (const bf16_t*)X + rows * DP;
+        if (Zst) Zst = (bf16_t*)Zst + rows * 4 * H;
+        Hout = (bf16_t*)Hout + rows * H;
+        if (Cout) Cout = (bf16_t*)Cout + rows * H;
+        ntiles -= n;
+      }
+      if (ntiles == 0) return 0;
+    }
   }
   DJ_DISPATCH_TH(launch_fwd_fused, ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, sigm, st)
 }

@@ -254,7 +254,9 @@ def test_nadam_matches_oracle(gpu_device):
 @pytest.mark.parametrize("H,S,Ls,D", [(256, 64, 5, 94), (128, 40, 6, 259), (256, 32, 3, 256), (128, 96, 4, 128),
                                       (128, 40, 6, 90),
                                       # 64 / 256 sequence tiles: bf16 H = 256 takes the weight-stationary cluster kernel
-                                      (256, 2048, 6, 256), (256, 8192, 3, 94)])
+                                      (256, 2048, 6, 256), (256, 8192, 3, 94),
+                                      # two cluster launches (256 + 64 tiles) and a per-tile remainder of 11
+                                      (256, 331 * 32, 2, 94)])
 def test_lstm_fwd_fused_input_projection(gpu_device, dtype, H, S, Ls, D):
     """z = x W + h U + b inside the recurrent kernel (dj_lstm_fwd_fused) vs the restated cell."""
     L, lib = _lib()
