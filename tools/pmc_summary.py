@@ -27,6 +27,8 @@ def category(name):
     n = name
     if "lstm_bwd_kernel" in n:
         return "lstm_bwd_time" if "Li256" in n else "lstm_bwd_note"
+    if "lstm_fwd_cluster" in n:
+        return "lstm_fwd_time"
     if "lstm_fwd" in n:
         return "lstm_fwd_time" if "Li256" in n else "lstm_fwd_note"
     if "lstm_wgrad" in n:
