@@ -549,6 +549,8 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
 // bumped, the exchange loads bypass L1 (sc1).  The wait is bounded: an expired wait (grid not co-resident)
 // poisons the tile's cell state with NaN and is counted (dj_lstm_cluster_faults), never a silent wrong answer
 // and never a hung device; the launcher only uses this kernel when the device has a compute unit per workgroup.
+// experiment switch: 0 = x_t requested at the start of its step (measured best), 1 = a step
+// ahead, split around the h product, 2 = a step ahead, before the barrier -- both slower
 #ifndef DJ_EXP_CL_XAHEAD
 #define DJ_EXP_CL_XAHEAD 0
 #endif
@@ -635,8 +637,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;   // bias joins in the cell update (a hoisted splat would spill)
-    // ---- x_t W: independent of the exchange; x_t was requested during the previous step (see below) and is
-    // turned into A fragments through this wave's 4 KiB LDS tile, 64 columns per round.
+    // ---- x_t W: independent of the exchange, so it runs before the wait; x_t is turned into A fragments through
+    // this wave's 4 KiB LDS tile, 64 columns per round.
     {
 #if !DJ_EXP_CL_XAHEAD
       cl_load_x<NR, 0, NR>(xq, X + (rb * 32 + xr8) * DP + xc * 8, DP, xc);
@@ -687,9 +689,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
 #pragma unroll
       for (int kc = 0; kc < R::NKC; ++kc) ah[kc] = ld_sc1(hx + kc * 64);
       asm volatile("" ::: "memory");
+#if DJ_EXP_CL_XAHEAD == 1
       // the first rounds of x_{t+1} go out right behind the h fragments (loads return in order: in front they
       // would hold the h fragments back), always 4*NRA requests, so the wait below is a constant
-#if DJ_EXP_CL_XAHEAD == 1
       cl_load_x<NR, 0, NRA>(xq, xnext, DP, xc);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NRA) : "memory");
 #else
