@@ -33,6 +33,12 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------- conversions
 __device__ __forceinline__ float dj_to_f32(float v) { return v; }
 __device__ __forceinline__ float dj_to_f32(bf16_t v) { return (float)v; }
+// per-device slots of host-side caches (kernel attributes, symbol addresses): one process may drive several GPUs
+constexpr int DJ_MAX_DEVICES = 64;
+inline int dj_current_device() {
+  int d = 0;
+  return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < DJ_MAX_DEVICES) ? d : 0;
+}
 template <typename T> __device__ __forceinline__ T dj_from_f32(float v);
 template <> __device__ __forceinline__ float dj_from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t dj_from_f32<bf16_t>(float v) { return (bf16_t)v; }

@@ -844,7 +844,8 @@ int dj_launch_dense_small_bwd_x(const float* dC, int M, int N, const float* W, i
   if (K > 64) return 1020;
   const int NC = N < DSBX_NC ? N : DSBX_NC;
   const size_t smb = ((size_t)NC * (K + 1) + DSBX_RB * (size_t)NC) * sizeof(float);
-  static bool attr_done = false;
+  static bool attr_done_dev[DJ_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[dj_current_device()];
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)dense_small_bwd_x_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -884,7 +885,8 @@ int dj_launch_dense_small_batch_bwd(const DenseBatch* d, float* dA, hipStream_t 
                      (size_t)rpb * d->K * sizeof(float), st, *d, rpb);
   const int NC = maxn < DSBX_NC ? maxn : DSBX_NC;
   const size_t smb = ((size_t)NC * (d->K + 1) + DSBX_RB * (size_t)NC) * sizeof(float);
-  static bool attr_done = false;
+  static bool attr_done_dev[DJ_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[dj_current_device()];
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)dense_small_bwd_x_batch_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);

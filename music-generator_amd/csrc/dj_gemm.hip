@@ -955,7 +955,8 @@ int dj_launch_gemm_nt_rbs(int dtype, int M, int N, int K, const void* A, int lda
     int grid3 = 256;
     if ((int64_t)ntn3 * ntm3 < 256) grid3 = ((ntn3 * ntm3 + 7) / 8) * 8;   // whole XCD rounds (blockIdx & 7 = XCD)
     const size_t smem = (size_t)NT3_NS * NT3_STAGE;
-    static bool attr3_done = false;
+    static bool attr3_done_dev[DJ_MAX_DEVICES] = {};
+    bool& attr3_done = attr3_done_dev[dj_current_device()];
     if (!attr3_done) {
       const void* fns[3] = {(const void*)gemm_nt_bf16_wide_kernel<bf16_t, false>,
                             (const void*)gemm_nt_bf16_wide_kernel<float, false>,
@@ -993,7 +994,8 @@ int dj_launch_gemm_nt_rbs(int dtype, int M, int N, int K, const void* A, int lda
       grid2 = mrows * ntn2;
     }
     const size_t smem = (size_t)NT2_NS * NT2_STAGE;
-    static bool attr_done = false;
+    static bool attr_done_dev[DJ_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[dj_current_device()];
     if (!attr_done) {
       const void* fns[3] = {(const void*)gemm_nt_bf16_dma_kernel<bf16_t, false>,
                             (const void*)gemm_nt_bf16_dma_kernel<float, false>,
@@ -1048,7 +1050,8 @@ int dj_launch_gemm_tn(int dtype, int64_t M, int Ka, int ka_valid, int N, const v
     rps2 = ((rps2 + TN2_BK - 1) / TN2_BK) * TN2_BK;
     int splits2 = (int)((M + rps2 - 1) / rps2);
     const size_t smem = (size_t)TN2_NS * TN2_STAGE;
-    static bool attr_done = false;
+    static bool attr_done_dev[DJ_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[dj_current_device()];
     if (!attr_done) {
       hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_bf16_dma_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1087,7 +1090,8 @@ int dj_launch_lstm_wgrad(int dtype, int64_t M, int steps, const void* X, int DP,
     int splits = (int)want;                          // trailing splits may be empty (nkt = 0)
     a.xcd_map = 1;
     const size_t smem = (size_t)WG_NS * WG_STAGE;
-    static bool attr_done = false;
+    static bool attr_done_dev[DJ_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[dj_current_device()];
     if (!attr_done) {
       hipError_t e = hipFuncSetAttribute((const void*)lstm_wgrad_bf16_kernel,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

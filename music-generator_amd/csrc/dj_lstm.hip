@@ -1106,7 +1106,8 @@ int launch_bwd_x(int ntiles, int steps, const void* Z, const void* UTpack, const
                  float* dbias, int sigm, const void* WTpack, int NQ, void* dX, int DP, hipStream_t st) {
   using R = RecCfg<T, H>;
   size_t smem = (size_t)32 * (R::LDZ + (R::HOIST ? R::LDH : 0)) * sizeof(T) + (DX == 2 ? R::NW * 32 * 4 * sizeof(float) : 0);
-  static bool attr_done = false;
+  static bool attr_done_dev[DJ_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[dj_current_device()];
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_kernel<T, H, false, DX>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1156,7 +1157,8 @@ template <typename T, int H, bool SIGM, bool WSTAT>
 int launch_fwd_fused_w(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
                        void* Zst, const void* Upack, void* Hout, void* Cout, size_t smem, hipStream_t st) {
   using R = RecCfg<T, H>;
-  static bool attr_done = false;
+  static bool attr_done_dev[DJ_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[dj_current_device()];
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_fused_kernel<T, H, SIGM, WSTAT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1191,7 +1193,8 @@ int launch_fwd_fused(int ntiles, int steps, const void* X, int DP, int NKX, cons
 template <bool SIGM, int NKX>
 int launch_fwd_cluster_k(int ntiles, int steps, const void* X, int DP, const void* Wpack, const float* bias,
                          void* Zst, const void* Upack, void* Hout, void* Cout, size_t smem, hipStream_t st) {
-  static bool attr_done = false;
+  static bool attr_done_dev[DJ_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[dj_current_device()];
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_cluster_kernel<SIGM, NKX>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1213,9 +1216,8 @@ int launch_fwd_cluster_s(int ntiles, int steps, const void* X, int DP, int NKX, 
 }
 // compute units of the current device (one 160 KiB workgroup each): the cluster kernel needs its whole grid resident
 int cluster_cus() {
-  static int cus[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  static int cus[DJ_MAX_DEVICES] = {};
+  const int dev = dj_current_device();
   if (!cus[dev]) {
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
@@ -1229,7 +1231,8 @@ int launch_fwd_cluster(int ntiles, int steps, const void* X, int DP, int NKX, co
   // blocks come in groups of 64 = 8 XCDs x 8 members (cluster id = xcd + 8 * group)
   if (ntiles % 64 || ntiles > 256 || NKX * R::KC > 256 || DP > 256 || DP % 8) return 1016;
   const size_t smem = (size_t)(4 * NKX * 64 + 4 * R::NKC * 64) * 16 + (size_t)8 * 4096;
-  static void* cnt_addr = nullptr;
+  static void* cnt_addr_dev[DJ_MAX_DEVICES] = {};      // a __device__ symbol has one address per device
+  void*& cnt_addr = cnt_addr_dev[dj_current_device()];
   if (!cnt_addr) {
     hipError_t e = hipGetSymbolAddress(&cnt_addr, HIP_SYMBOL(dj_cluster_cnt));
     if (e != hipSuccess) return (int)e;

@@ -11,7 +11,7 @@ notes, chosen, beat, style, target = [np.concatenate([a] * nb).astype(np.float64
 model = build_models(time_steps=T, config=DeepJConfig(num_notes=N, time_steps=T, dtype="bf16"), dtype="bf16")[0]
 model.fit([notes, target, beat, style], [target], epochs=1, batch_size=B, verbose=0)      # warm-up
 t0 = time.time()
-model.fit([notes, target, beat, style], [target], epochs=2, batch_size=B, verbose=0)
+model.fit([notes, target, beat, style], [target], epochs=8, batch_size=B, verbose=0)
 dt = time.time() - t0
-steps = 2 * nb
+steps = 8 * nb
 print(f"fit: {dt / steps * 1e3:.1f} ms/batch, {steps * B * T * N / dt / 1e6:.1f} M note-steps/s (host float64 inputs, B={B})")
