@@ -192,7 +192,9 @@ int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, 
  * the device shared with another stream's kernels) cannot hang the device: the wait expires, the affected
  * tiles carry NaN from there on (so does the loss), and the event is counted.  Returns the number of expired
  * waits since the previous call (synchronises the device; 0 in a healthy run), -1 on a HIP error.
- * DEEPJ_CLUSTER=0 in the environment selects the per-tile kernel instead. */
+ * The clusters' counters and exchange buffer are per device, not per stream: run at most one such sweep per device
+ * at a time (one training stream per device, as one process per GPU does), or set DEEPJ_CLUSTER=0, which selects
+ * the per-tile kernel instead. */
 int32_t dj_lstm_cluster_faults(void);
 /* mask[rows, cols] (fp32 0 or 1/(1-p)) of dropout site `site` -- exposes the counter
  * hash so tests can pin it against the oracle. */
