@@ -259,7 +259,19 @@ def test_nadam_matches_oracle(gpu_device):
                                       (256, 331 * 32, 2, 94)])
 def test_lstm_fwd_fused_input_projection(gpu_device, dtype, H, S, Ls, D):
     """z = x W + h U + b inside the recurrent kernel (dj_lstm_fwd_fused) vs the restated cell."""
+    _fwd_fused_case(gpu_device, dtype, H, S, Ls, D, 0)
+
+
+@pytest.mark.parametrize("H,S,Ls,D", [(256, 2048, 4, 256), (256, 96, 4, 94), (128, 64, 5, 128)])
+def test_lstm_fwd_fused_recurrent_sigmoid(gpu_device, H, S, Ls, D):
+    """The same kernels with recurrent_activation='sigmoid' (template switch; Keras' default is hard_sigmoid), bf16:
+    cluster kernel (64 tiles), per-tile H = 256, register-stationary H = 128."""
+    _fwd_fused_case(gpu_device, "bf16", H, S, Ls, D, 1)
+
+
+def _fwd_fused_case(gpu_device, dtype, H, S, Ls, D, sigm):
     L, lib = _lib()
+    ract = torch.sigmoid if sigm else O.hard_sigmoid
     DP = (D + 7) // 8 * 8
     x, W, U, b = _lstm_setup(S, Ls, D, H, H + D)
     rnd = (lambda t: t.to(torch.bfloat16).float()) if dtype == "bf16" else (lambda t: t)
@@ -268,8 +280,7 @@ def test_lstm_fwd_fused_input_projection(gpu_device, dtype, H, S, Ls, D):
     hs, cs, zs = [], [], []
     for t in range(Ls):
         z = xr[:, t] @ Wr + b + h @ Ur
-        i, f, gg, o = O.hard_sigmoid(z[:, :H]), O.hard_sigmoid(z[:, H:2 * H]), torch.tanh(z[:, 2 * H:3 * H]), \
-            O.hard_sigmoid(z[:, 3 * H:])
+        i, f, gg, o = ract(z[:, :H]), ract(z[:, H:2 * H]), torch.tanh(z[:, 2 * H:3 * H]), ract(z[:, 3 * H:])
         c = f * c + i * gg
         h = o * torch.tanh(c)
         hs.append(h); cs.append(c); zs.append(z)
@@ -287,7 +298,7 @@ def test_lstm_fwd_fused_input_projection(gpu_device, dtype, H, S, Ls, D):
     Hd = torch.zeros(R, H, dtype=Xd.dtype, device=gpu_device)
     Cd = torch.zeros(R * H, dtype=Xd.dtype, device=gpu_device)
     rc = lib.dj_lstm_fwd_fused(DT[dtype], H, tiles, Ls, L.ptr(Xd), DP, D, L.ptr(wpack), L.ptr(b.to(gpu_device)),
-                               L.ptr(Zd), L.ptr(upf), L.ptr(Hd), L.ptr(Cd), 0, _st())
+                               L.ptr(Zd), L.ptr(upf), L.ptr(Hd), L.ptr(Cd), sigm, _st())
     L.check(rc, "fwd_fused")
     rt, at = _tol(dtype)
     torch.testing.assert_close(from_rows(Hd.float().cpu(), S, Ls), Href, rtol=rt, atol=at * 5)
