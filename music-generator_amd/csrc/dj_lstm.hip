@@ -554,7 +554,15 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
 #ifndef DJ_EXP_CL_XAHEAD
 #define DJ_EXP_CL_XAHEAD 0
 #endif
-__device__ int dj_cluster_cnt[64];
+// experiment switch: 1 = the two halves of a workgroup (waves 0-3 / 4-7) run half a step apart, each with its own
+// cluster counter fed by one atomic per wave, and never meet in a workgroup barrier (tools/memlat.hip: the same
+// memory pattern is 11-20 % faster when the halves alternate between memory and arithmetic)
+#ifndef DJ_EXP_CL_GROUPS
+#define DJ_EXP_CL_GROUPS 0
+#endif
+// one 128-byte line per counter: counters of clusters on different XCDs must not share a line
+constexpr int CL_CNT_STRIDE = 32;
+__device__ int dj_cluster_cnt[64 * 2 * CL_CNT_STRIDE];
 __device__ int dj_cluster_fault;              // expired waits since the last dj_cluster_faults()
 constexpr int CL_M = 8;                      // members (= tiles) per cluster
 // h exchange in the exact MFMA A-fragment image: [tile][step parity][kc][lane] x 16 bytes, so a consumer wave
@@ -601,7 +609,13 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, s = j & (CL_M - 1);
   const int cid = xcd + 8 * (j >> 3);                      // cluster id; its tiles are CL_M*cid .. CL_M*cid+7
   const int64_t tile = (int64_t)CL_M * cid + w;            // this wave's tile
-  int* cnt = dj_cluster_cnt + cid;
+#if DJ_EXP_CL_GROUPS
+  int* cnt = dj_cluster_cnt + (2 * cid + (w >> 2)) * CL_CNT_STRIDE;
+  constexpr int ARRIVALS = 4 * CL_M;          // one per wave of the half, from every member
+#else
+  int* cnt = dj_cluster_cnt + 2 * cid * CL_CNT_STRIDE;
+  constexpr int ARRIVALS = CL_M;
+#endif
 
   // stationary operand slices -> LDS (contiguous in the packed streams)
   {
@@ -618,6 +632,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
   for (int g = 0; g < 4; ++g) bv[g] = bias[g * H + s * 32 + l31];
   __syncthreads();
 
+#if DJ_EXP_CL_GROUPS
+  if (w >> 2) {
+    const unsigned long long t00 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t00 < 14000ull) __builtin_amdgcn_s_sleep(8);      // about half a step
+  }
+#endif
   unsigned char* xs = (unsigned char*)hto + w * 4096;      // this wave's 4 KiB tile: x rounds, then the h tile
   T* ht = (T*)xs;
   // x rows are fetched as full 128-byte lines, 8 lanes per row (fragments read straight from the rows would be
@@ -668,7 +688,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
     if (t > 0) {
       int ok = 1;
       if (lane == 0) {
-        const int target = CL_M * t;
+        const int target = ARRIVALS * t;
         const unsigned long long t0 = __builtin_readcyclecounter();
         while ((ok = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) == 0 &&
                __builtin_readcyclecounter() - t0 < 20000000ull)       // ~10 ms: hang protection only
@@ -755,8 +775,15 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
 #if DJ_EXP_CL_XAHEAD == 2
     cl_load_x<NR, 0, NR>(xq, xnext, DP, xc);    // x_{t+1} travels while the members meet
 #endif
+#ifndef DJ_EXP_CL_ASCOPE
+#define DJ_EXP_CL_ASCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
+#if DJ_EXP_CL_GROUPS
+    if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, DJ_EXP_CL_ASCOPE);
+#else
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, DJ_EXP_CL_ASCOPE);
+#endif
   }
 }
 
@@ -1237,7 +1264,7 @@ int launch_fwd_cluster(int ntiles, int steps, const void* X, int DP, int NKX, co
     hipError_t e = hipGetSymbolAddress(&cnt_addr, HIP_SYMBOL(dj_cluster_cnt));
     if (e != hipSuccess) return (int)e;
   }
-  hipError_t e = hipMemsetAsync(cnt_addr, 0, sizeof(int) * 64, st);
+  hipError_t e = hipMemsetAsync(cnt_addr, 0, sizeof(int) * 64 * 2 * CL_CNT_STRIDE, st);
   if (e != hipSuccess) return (int)e;
   return sigm ? launch_fwd_cluster_s<true>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, st)
               : launch_fwd_cluster_s<false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, st);

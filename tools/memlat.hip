@@ -20,6 +20,15 @@ __global__ __launch_bounds__(512) void memlat_kernel(const uint4* __restrict__ X
   const long tile_w = 8L * blockIdx.x + w;
   const long ntile_r = (mode & 2) ? gridDim.x : 8L * gridDim.x;
   uint4 acc = make_uint4(0, 0, 0, 0);
+  // bit 4: the two halves of the workgroup (waves 0-3 / 4-7) run half a step apart and meet per half through LDS
+  __shared__ int gcnt[2];
+  if (threadIdx.x < 2) gcnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int g = w >> 2;
+  if ((mode & 16) && g == 1) {
+    const unsigned long long t00 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t00 < 9000ull + work / 2) __builtin_amdgcn_s_sleep(8);
+  }
   for (int t = 0; t < steps; ++t) {
     const uint4* xp = X + ((tile_r * steps + t) * 16) * 64 + lane;      // 16 KiB per (tile, step)
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -48,7 +57,16 @@ __global__ __launch_bounds__(512) void memlat_kernel(const uint4* __restrict__ X
     if (work > 0) {
       while (__builtin_readcyclecounter() - t2 < (unsigned long long)work) __builtin_amdgcn_s_sleep(8);
     }
-    __syncthreads();
+    if (mode & 16) {
+      if (lane == 0) {
+        __hip_atomic_fetch_add(&gcnt[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(&gcnt[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4 * (t + 1))
+          __builtin_amdgcn_s_sleep(1);
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      __syncthreads();
+    }
     if (blockIdx.x == 17 && threadIdx.x == 0) {
       stamps[3 * t] = t1 - t0;
       stamps[3 * t + 1] = t2 - t1;
@@ -69,7 +87,7 @@ int main() {
   CK(hipMemset(X, 1, xbytes));
   CK(hipMemset(Z, 0, zbytes));
   std::vector<unsigned long long> h(3 * steps);
-  const int modes[][2] = {{3, 0}, {7, 0}, {3, 8000}, {7, 8000}, {1, 0}, {5, 0}};
+  const int modes[][2] = {{3, 0}, {19, 0}, {3, 8000}, {19, 8000}, {3, 12000}, {19, 12000}};
   for (auto& m : modes) {
     float best = 1e9f;
     for (int rep = 0; rep < 3; ++rep) {
@@ -90,8 +108,8 @@ int main() {
     std::vector<unsigned long long> rd, wr, tot;
     for (int t = 8; t < steps - 8; ++t) { rd.push_back(h[3 * t]); wr.push_back(h[3 * t + 1]); tot.push_back(h[3 * t + 2]); }
     std::sort(rd.begin(), rd.end()); std::sort(wr.begin(), wr.end()); std::sort(tot.begin(), tot.end());
-    printf("reads-before-burst %d wbl2 %d writes %d shared-by-8 %d idle %5d cycles: read wait median %6llu (p90 %6llu), write+ack %6llu, step %6llu cycles; kernel %.3f ms\n",
-           (m[0] >> 2) & 1, (m[0] >> 3) & 1, m[0] & 1, (m[0] >> 1) & 1, m[1], rd[rd.size() / 2], rd[rd.size() * 9 / 10], wr[wr.size() / 2], tot[tot.size() / 2], best);
+    printf("antiphase %d reads-before-burst %d wbl2 %d writes %d shared-by-8 %d idle %5d cycles: read wait median %6llu (p90 %6llu), write+ack %6llu, step %6llu cycles; kernel %.3f ms\n",
+           (m[0] >> 4) & 1, (m[0] >> 2) & 1, (m[0] >> 3) & 1, m[0] & 1, (m[0] >> 1) & 1, m[1], rd[rd.size() / 2], rd[rd.size() * 9 / 10], wr[wr.size() / 2], tot[tot.size() / 2], best);
   }
   return 0;
 }
