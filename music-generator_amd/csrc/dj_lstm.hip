@@ -744,6 +744,22 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
       ht[dj_crow(r, lane) * 32 + l31] = dj_from_f32<T>(og * dj_tanh(cn));
     }
     DJ_STAMP(0, 4, t);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the exchange copy goes out FIRST: only it has to be acknowledged before the counter moves; chunks 2s, 2s+1 of
+    // this tile in fragment image, 1 KiB each
+    {
+      uint4* hxo = dj_cluster_hx + ((tile * 2 + (t & 1)) * 16 + 2 * s) * 64 + lane;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) hxo[jj * 64] = *(const uint4*)(ht + l31 * 32 + 16 * jj + 8 * h);
+    }
+    asm volatile("" ::: "memory");
+    // then the row-major h slice (32 rows x 64 bytes -> 2 x 16-byte vectors per lane) and the stash
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = lane + 64 * i, row = v >> 2, cq = (v & 3) * 8;
+      *(uint4*)(Hout + (rb * 32 + row) * H + s * 32 + cq) = *(const uint4*)(ht + row * 32 + cq);
+    }
     if (Cout) store_frag(Cout + ((rb * R::NCBH + s) * 64 + lane) * 16, cv);
     if (Zst) {
 #pragma unroll
@@ -754,23 +770,18 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
         store_frag(Zst + ((rb * R::NCB + (g * H + s * 32) / 32) * 64 + lane) * 16, zv);
       }
     }
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // h tile of this wave: 32 rows x 64 bytes -> 2 x 16-byte vectors per lane
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int v = lane + 64 * i, row = v >> 2, cq = (v & 3) * 8;
-      *(uint4*)(Hout + (rb * 32 + row) * H + s * 32 + cq) = *(const uint4*)(ht + row * 32 + cq);
-    }
-    // the same slice in fragment image for the exchange: chunks 2s, 2s+1 of this tile, 1 KiB each
-    {
-      uint4* hxo = dj_cluster_hx + ((tile * 2 + (t & 1)) * 16 + 2 * s) * 64 + lane;
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) hxo[jj * 64] = *(const uint4*)(ht + l31 * 32 + 16 * jj + 8 * h);
-    }
-    // every wave's stores acknowledged by L2, then one increment per member
     DJ_STAMP(0, 5, t);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // stores are acknowledged in order: wait until only the ones issued after the exchange copy are outstanding
+    // (2 h + 2 c + 8 z; they drain under the next step and at the latest at the end of the kernel)
+    asm volatile("" ::: "memory");
+    if (Zst && Cout)
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (Zst)
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (Cout)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     DJ_STAMP(0, 6, t);
 #if DJ_EXP_CL_XAHEAD == 2
     cl_load_x<NR, 0, NR>(xq, xnext, DP, xc);    // x_{t+1} travels while the members meet
