@@ -542,17 +542,20 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
 //    LDS tile per wave, 64 columns per round (fragments read straight from the rows are 32 segments of 32 bytes
 //    per instruction).
 //  * h travels in the MFMA A-fragment image (dj_cluster_hx below), one contiguous 1 KiB load per fragment.
-//  * Measured dead ends: requesting x_{t+1} a step ahead -- loads return in order, so the
-//    h fragments queue behind the HBM reads -- and per-tile counters without the workgroup barrier.
+//  * x_{t+1} is requested during step t, behind the h fragments (loads return in order: in front of them it would
+//    hold the h fragments back); with spilled registers the same idea is a loss.
 // Coherence: members of a cluster run on ONE XCD (round-robin workgroup dispatch, any power-of-two XCD count),
 // whose L2 is the coherence point for their h slices -- stores are acknowledged (vmcnt 0) before the counter is
 // bumped, the exchange loads bypass L1 (sc1).  The wait is bounded: an expired wait (grid not co-resident)
 // poisons the tile's cell state with NaN and is counted (dj_lstm_cluster_faults), never a silent wrong answer
 // and never a hung device; the launcher only uses this kernel when the device has a compute unit per workgroup.
-// experiment switch: 0 = x_t requested at the start of its step (measured best), 1 = a step
-// ahead, split around the h product, 2 = a step ahead, before the barrier -- both slower
+// where x is requested: 1 (default) = one step ahead, the first half of x_{t+1} right behind the
+// h fragments of step t, the second half once the h product has freed their registers (2.92 ms per training step for
+// the two time-axis layers); 0 = at the start of its own step (2.98); 3 = all of it behind the h fragments (3.00);
+// 2 = a step ahead, before the barrier (slower).  Only without register spills: the step must be unconditional
+// (round 0 of the exchange carries h = 0), a conditional h product costs a second set of accumulators.
 #ifndef DJ_EXP_CL_XAHEAD
-#define DJ_EXP_CL_XAHEAD 0
+#define DJ_EXP_CL_XAHEAD 1
 #endif
 // experiment switch: 1 = the two halves of a workgroup (waves 0-3 / 4-7) run half a step apart, each with its own
 // cluster counter fed by one atomic per wave, and never meet in a workgroup barrier (tools/memlat.hip: the same
@@ -630,7 +633,21 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
   float bv[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) bv[g] = bias[g * H + s * 32 + l31];
+  // round 0 of the exchange: h_{-1} = 0 goes into the parity-1 slots like any h_t, so that step 0 is a step like the
+  // others (a conditional h product costs a second set of accumulators: 64 registers)
+  {
+    uint4* hxo = dj_cluster_hx + ((tile * 2 + 1) * 16 + 2 * s) * 64 + lane;
+    hxo[0] = make_uint4(0, 0, 0, 0);
+    hxo[64] = make_uint4(0, 0, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if DJ_EXP_CL_GROUPS
   __syncthreads();
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  __syncthreads();
+  if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 
 #if DJ_EXP_CL_GROUPS
   if (w >> 2) {
@@ -657,8 +674,8 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;   // bias joins in the cell update (a hoisted splat would spill)
-    // ---- x_t W: independent of the exchange, so it runs before the wait; x_t is turned into A fragments through
-    // this wave's 4 KiB LDS tile, 64 columns per round.
+    // ---- x_t W: independent of the exchange, so it runs before the wait; x_t (requested during the previous step) is
+    // turned into A fragments through this wave's 4 KiB LDS tile, 64 columns per round.
     {
 #if !DJ_EXP_CL_XAHEAD
       cl_load_x<NR, 0, NR>(xq, X + (rb * 32 + xr8) * DP + xc * 8, DP, xc);
@@ -675,6 +692,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
             const Frag a = *(const Frag*)(xs + l31 * 128 + (((2 * q + h) ^ (l31 & 7)) << 4));
 #pragma unroll
             for (int g = 0; g < 4; ++g) dj_mfma(acc[g], a, Bw[(g * NKX + kc) * 64 + lane]);
+#if DJ_EXP_CL_SCHED
+            __builtin_amdgcn_sched_barrier(0);
+#endif
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -685,10 +705,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
     const T* xnext = X + ((tile * steps + (t + 1 < steps ? t + 1 : t)) * 32 + xr8) * DP + xc * 8;
 #endif
     // ---- h_{t-1} U: needs the slices of all members
-    if (t > 0) {
+    {
       int ok = 1;
       if (lane == 0) {
-        const int target = ARRIVALS * t;
+        const int target = ARRIVALS * (t + 1);
         const unsigned long long t0 = __builtin_readcyclecounter();
         while ((ok = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) == 0 &&
                __builtin_readcyclecounter() - t0 < 20000000ull)       // ~10 ms: hang protection only
@@ -704,12 +724,15 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
       DJ_STAMP(0, 2, t);
-      const uint4* hx = dj_cluster_hx + ((tile * 2 + ((t - 1) & 1)) * 16) * 64 + lane;
+      const uint4* hx = dj_cluster_hx + ((tile * 2 + ((t + 1) & 1)) * 16) * 64 + lane;
       uint4 ah[R::NKC];
 #pragma unroll
       for (int kc = 0; kc < R::NKC; ++kc) ah[kc] = ld_sc1(hx + kc * 64);
       asm volatile("" ::: "memory");
-#if DJ_EXP_CL_XAHEAD == 1
+#if DJ_EXP_CL_XAHEAD == 3
+      cl_load_x<NR, 0, NR>(xq, xnext, DP, xc);      // all of x_{t+1} right behind the h fragments
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NR) : "memory");
+#elif DJ_EXP_CL_XAHEAD == 1
       // the first rounds of x_{t+1} go out right behind the h fragments (loads return in order: in front they
       // would hold the h fragments back), always 4*NRA requests, so the wait below is a constant
       cl_load_x<NR, 0, NRA>(xq, xnext, DP, xc);
@@ -723,11 +746,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
         __builtin_memcpy(&a, &ah[kc], 16);
 #pragma unroll
         for (int g = 0; g < 4; ++g) dj_mfma(acc[g], a, Bu[(g * R::NKC + kc) * 64 + lane]);
+#if DJ_EXP_CL_SCHED
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     }
 #if DJ_EXP_CL_XAHEAD == 1
-    else
-      cl_load_x<NR, 0, NRA>(xq, xnext, DP, xc);
     cl_load_x<NR, NRA, NR>(xq, xnext, DP, xc);   // the rest once the h fragments' registers are free
 #endif
     DJ_STAMP(0, 3, t);
