@@ -552,7 +552,8 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
 // where x is requested: 1 (default) = one step ahead, the first half of x_{t+1} right behind the
 // h fragments of step t, the second half once the h product has freed their registers (2.92 ms per training step for
 // the two time-axis layers); 0 = at the start of its own step (2.98); 3 = all of it behind the h fragments (3.00);
-// 2 = a step ahead, before the barrier (slower).  Only without register spills: the step must be unconditional
+// 2 = a step ahead, before the barrier (slower); 4 = as 1 with the second half of x_t W moved under the h fragments'
+// latency (2.97).  Only without register spills: the step must be unconditional
 // (round 0 of the exchange carries h = 0), a conditional h product costs a second set of accumulators.
 #ifndef DJ_EXP_CL_XAHEAD
 #define DJ_EXP_CL_XAHEAD 1
@@ -680,25 +681,25 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
 #if !DJ_EXP_CL_XAHEAD
       cl_load_x<NR, 0, NR>(xq, X + (rb * 32 + xr8) * DP + xc * 8, DP, xc);
 #endif
-#pragma unroll
-      for (int r = 0; r < NR; ++r) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *(uint4*)(xs + (xr8 + 8 * i) * 128 + ((xc ^ xr8) << 4)) = xq.v[r][i];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int kc = 4 * r + q;
-          if (kc < NKX) {
-            const Frag a = *(const Frag*)(xs + l31 * 128 + (((2 * q + h) ^ (l31 & 7)) << 4));
-#pragma unroll
-            for (int g = 0; g < 4; ++g) dj_mfma(acc[g], a, Bw[(g * NKX + kc) * 64 + lane]);
-#if DJ_EXP_CL_SCHED
-            __builtin_amdgcn_sched_barrier(0);
+#define DJ_CL_X_ROUNDS(R0, R1)                                                                            \
+  _Pragma("unroll") for (int r = (R0); r < (R1); ++r) {                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
+        *(uint4*)(xs + (xr8 + 8 * i) * 128 + ((xc ^ xr8) << 4)) = xq.v[r][i];                             \
+    __builtin_amdgcn_wave_barrier();                                                                      \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                       \
+      const int kc = 4 * r + q;                                                                           \
+      if (kc < NKX) {                                                                                     \
+        const Frag a = *(const Frag*)(xs + l31 * 128 + (((2 * q + h) ^ (l31 & 7)) << 4));                 \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) dj_mfma(acc[g], a, Bw[(g * NKX + kc) * 64 + lane]); \
+      }                                                                                                   \
+    }                                                                                                     \
+    __builtin_amdgcn_wave_barrier();                                                                      \
+  }
+#if DJ_EXP_CL_XAHEAD == 4
+      DJ_CL_X_ROUNDS(0, NRA)      // the rest runs while the h fragments travel (below)
+#else
+      DJ_CL_X_ROUNDS(0, NR)
 #endif
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
     }
     DJ_STAMP(0, 1, t);
 #if DJ_EXP_CL_XAHEAD
@@ -729,7 +730,11 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
 #pragma unroll
       for (int kc = 0; kc < R::NKC; ++kc) ah[kc] = ld_sc1(hx + kc * 64);
       asm volatile("" ::: "memory");
-#if DJ_EXP_CL_XAHEAD == 3
+#if DJ_EXP_CL_XAHEAD == 4
+      cl_load_x<NR, 0, NRA>(xq, xnext, DP, xc);     // first half of x_{t+1}, into the registers rounds 0..NRA-1 freed
+      DJ_CL_X_ROUNDS(NRA, NR)                       // second half of x_t W under the h fragments' latency
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NRA) : "memory");
+#elif DJ_EXP_CL_XAHEAD == 3
       cl_load_x<NR, 0, NR>(xq, xnext, DP, xc);      // all of x_{t+1} right behind the h fragments
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NR) : "memory");
 #elif DJ_EXP_CL_XAHEAD == 1
@@ -751,7 +756,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
 #endif
       }
     }
-#if DJ_EXP_CL_XAHEAD == 1
+#if DJ_EXP_CL_XAHEAD == 1 || DJ_EXP_CL_XAHEAD == 4
     cl_load_x<NR, NRA, NR>(xq, xnext, DP, xc);   // the rest once the h fragments' registers are free
 #endif
     DJ_STAMP(0, 3, t);
