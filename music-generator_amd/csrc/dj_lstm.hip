@@ -835,6 +835,18 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
 // DX == 2: only the LAST 32-column block of dX (columns 32*(NQ-1) ..., at most 4 of them valid: the `chosen`
 // inputs of note layer 0) is produced here, its K range split over the waves (8 stationary fragments each) and
 // the partial sums folded through LDS one step later; the GEMM then covers a multiple of 256 columns only.
+#ifndef DJ_EXP_ULDS
+#define DJ_EXP_ULDS 8
+#endif
+// LDS-resident part of the streamed U^T (bf16 H = 256 only): KL k-chunks per wave behind the dz and dH tiles
+template <typename T, int H> struct BwdUlds {
+  using R = RecCfg<T, H>;
+  static constexpr int KL = (sizeof(T) == 2 && H == 256 && !R::STATB) ? DJ_EXP_ULDS : 0;
+  static constexpr size_t bytes = (size_t)R::NW * KL * 64 * 16;
+  static constexpr size_t offset(int DX) {
+    return (size_t)32 * (R::LDZ + (R::HOIST ? R::LDH : 0)) * sizeof(T) + (DX == 2 ? R::NW * 32 * 4 * sizeof(float) : 0);
+  }
+};
 template <typename T, int H, bool SIGM, int DX>
 __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z, const T* __restrict__ UTpack,
                                                        const T* __restrict__ C, const T* __restrict__ dH,
@@ -862,6 +874,14 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
     for (int g = 0; g < 4; ++g) dbs[g][j] = 0.f;
   }
   const Frag* up = (const Frag*)UTpack + (int64_t)w * R::NJ * R::NKCB * 64 + lane;
+  // streamed U^T (H = 256): the first KL k-chunks of every wave's slice stay in the LDS the tiles leave free
+  // (KL x 8 KiB), the stream covers the rest -- the product is bound by the vector-memory path, LDS reads are not on it
+  constexpr int KL = BwdUlds<T, H>::KL;
+  Frag* ulw = (Frag*)(smem_raw + BwdUlds<T, H>::offset(DX)) + (w * KL) * 64 + lane;
+  if constexpr (KL > 0) {
+#pragma unroll
+    for (int kc = 0; kc < KL; ++kc) ulw[kc * 64] = up[kc * 64];
+  }
   Frag ub[R::STATB ? R::NKCB : 1];
   if constexpr (R::STATB) {
     static_assert(R::NJ == 1, "stationary U^T assumes one column tile per wave");
@@ -1098,12 +1118,20 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
 #pragma unroll
         for (int p = 0; p < R::PDB; ++p)
 #pragma unroll
-          for (int j = 0; j < R::NJ; ++j) bq[p][j] = up[(j * R::NKCB + p) * 64];
-        static_assert(R::UNRB % R::PDB == 0 && R::NKCB % R::UNRB == 0, "ring / unroll geometry");
+          for (int j = 0; j < R::NJ; ++j) bq[p][j] = up[(j * R::NKCB + KL + p) * 64];
+        static_assert(R::UNRB % R::PDB == 0 && (R::NKCB - KL) % R::UNRB == 0, "ring / unroll geometry");
+        static_assert(KL == 0 || R::NJ == 1, "LDS-resident chunks assume one column tile per wave");
+        if constexpr (KL > 0) {          // LDS-resident chunks first: the ring's first fragments arrive meanwhile
+#pragma unroll
+          for (int kc = 0; kc < KL; ++kc) {
+            Frag a = dj_lds_frag(ap + kc * R::KC, h);
+            dj_mfma(acc[0], a, ulw[kc * 64]);
+          }
+        }
         // all blocks but the last refill the ring; the last block only drains it
         constexpr int KMAIN = TAILPF ? R::NKCB - R::UNRB : R::NKCB;
 #pragma unroll 1
-        for (int kc0 = 0; kc0 < KMAIN; kc0 += R::UNRB) {
+        for (int kc0 = KL; kc0 < KMAIN; kc0 += R::UNRB) {
 #pragma unroll
           for (int u = 0; u < R::UNRB; ++u) {
             const int kc = kc0 + u;
@@ -1172,7 +1200,7 @@ template <typename T, int H, int DX>
 int launch_bwd_x(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
                  float* dbias, int sigm, const void* WTpack, int NQ, void* dX, int DP, hipStream_t st) {
   using R = RecCfg<T, H>;
-  size_t smem = (size_t)32 * (R::LDZ + (R::HOIST ? R::LDH : 0)) * sizeof(T) + (DX == 2 ? R::NW * 32 * 4 * sizeof(float) : 0);
+  size_t smem = BwdUlds<T, H>::offset(DX) + BwdUlds<T, H>::bytes;
   static bool attr_done_dev[DJ_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[dj_current_device()];
   if (!attr_done) {
