@@ -34,6 +34,8 @@
 //    glue kernels) and go through LDS for wide coalesced rows.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "dj_kernels.h"
 
 #ifdef DJ_EXP_STAMP
@@ -431,26 +433,25 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
 #pragma unroll
           for (int q = 0; q < 4; ++q) dj_mfma(acc[q], a, wf[kc][q]);
         }
-      } else {                  // wide input: W streamed, 8 fragments per gate in flight (NKX is a multiple of 8)
-        constexpr int PW = 8;
-        Frag bw[PW][4];
-#pragma unroll
-        for (int p = 0; p < PW; ++p)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) bw[p][q] = wp[(q * NKX + p) * 64];
-#pragma unroll 1
-        for (int kc0 = 0; kc0 < NKX; kc0 += PW) {
-#pragma unroll
-          for (int uu = 0; uu < PW; ++uu) {
-            const int kc = kc0 + uu;
-            Frag a = dj_lds_frag(xp + kc * R::KC, h);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dj_mfma(acc[q], a, bw[uu][q]);
-            const int kn = (kc + PW < NKX) ? kc + PW : NKX - 1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bw[uu][q] = wp[(q * NKX + kn) * 64];
-          }
-        }
+      } else {                  // wide input: W streamed, 8 (or 6) fragments per gate in flight; NKX is a multiple of
+                                // the ring depth (259 inputs: 18 chunks = 3 x 6 instead of 24 = 3 x 8)
+#define DJ_W_STREAM(PW)                                                                     \
+  {                                                                                         \
+    Frag bw[PW][4];                                                                         \
+    _Pragma("unroll") for (int p = 0; p < PW; ++p)                                          \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) bw[p][q] = wp[(q * NKX + p) * 64];    \
+    _Pragma("unroll 1") for (int kc0 = 0; kc0 < NKX; kc0 += PW) {                           \
+      _Pragma("unroll") for (int uu = 0; uu < PW; ++uu) {                                   \
+        const int kc = kc0 + uu;                                                            \
+        Frag a = dj_lds_frag(xp + kc * R::KC, h);                                           \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) dj_mfma(acc[q], a, bw[uu][q]);        \
+        const int kn = (kc + PW < NKX) ? kc + PW : NKX - 1;                                 \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) bw[uu][q] = wp[(q * NKX + kn) * 64];  \
+      }                                                                                     \
+    }                                                                                       \
+  }
+        if (NKX % 8 == 0) DJ_W_STREAM(8) else DJ_W_STREAM(6)
+#undef DJ_W_STREAM
       }
       if (t > 0) {
 #pragma unroll
@@ -1269,12 +1270,14 @@ int launch_fwd_fused_s(int ntiles, int steps, const void* X, int DP, int NKX, co
                        void* Zst, const void* Upack, void* Hout, void* Cout, hipStream_t st) {
   using R = RecCfg<T, H>;
   const size_t smem = ((size_t)2 * 32 * R::LDH + (size_t)2 * 32 * (NKX * R::KC + R::EPL)) * sizeof(T);
-  if (smem > 160 * 1024 || DP > FUSED_DPMAX || DP % R::EPL || NKX % R::PD || NKX * R::KC < DP) return 1011;
+  if (smem > 160 * 1024 || DP > FUSED_DPMAX || DP % R::EPL || NKX * R::KC < DP) return 1011;
   if constexpr (R::STATF) {
     // stationary-weight build: W in registers too when the input is at most H wide, else streamed 8 deep
     if (NKX == R::NKC && DP <= H)
       return launch_fwd_fused_w<T, H, SIGM, true>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, st);
-    if (NKX % 8) return 1014;
+    if (NKX % 8 && NKX % 6) return 1014;
+  } else {
+    if (NKX % R::PD) return 1011;       // continuous [W ; U] fragment ring
   }
   return launch_fwd_fused_w<T, H, SIGM, false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, st);
 }
@@ -1381,8 +1384,9 @@ int dj_launch_lstm_pack_wt(int dtype, int H, const float* W, int D, void* out, h
 int dj_lstm_fused_nkx(int dtype, int H, int D) {
   const int kc = dtype == DJ_F32 ? 8 : 16;                                   // RecCfg::KC
   int pd = dtype == DJ_F32 ? 2 : 4;                                          // RecCfg::PD
-  if (dtype != DJ_F32 && H == 128 && RecCfg<bf16_t, 128>::STATF) pd = 8;    // stationary build: 8 = NKC = W ring depth
   int n = (D + kc - 1) / kc;
+  if (dtype != DJ_F32 && H == 128 && RecCfg<bf16_t, 128>::STATF)    // stationary build: W in registers (8 chunks = NKC) or
+    return n <= 8 ? 8 : std::min((n + 7) / 8 * 8, (n + 5) / 6 * 6);  // streamed through a ring of 8 or 6 chunks
   return (n + pd - 1) / pd * pd;
 }
 int dj_launch_lstm_pack_w(int dtype, int H, const float* W, int D, int NKX, void* out, hipStream_t st) {
