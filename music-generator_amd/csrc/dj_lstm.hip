@@ -343,7 +343,7 @@ constexpr int FUSED_DPMAX = 288;   // widest layer input supported by the regist
 
 // WSTAT (stationary-weight builds only): W is held in registers as well (inputs up to H wide); otherwise W
 // is streamed through an 8-deep fragment ring in front of the stationary U product.
-template <typename T, int H, bool SIGM, bool WSTAT>
+template <typename T, int H, bool SIGM, bool WSTAT, bool WLDS>
 __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restrict__ X, int DP, int NKX,
                                                                const T* __restrict__ Wpack,
                                                                const float* __restrict__ bias, T* __restrict__ Zst,
@@ -366,6 +366,15 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
   for (int g = 0; g < 4; ++g) bv[g] = bias[g * H + w * R::UW + l31];
   const Frag* up = (const Frag*)Upack + (int64_t)w * 4 * R::NKC * 64 + lane;
   const Frag* wp = (const Frag*)Wpack + (int64_t)w * 4 * NKX * 64 + lane;
+  // WLDS (streamed-W path of the stationary build, ring of 6): the first 6 k-chunks of this wave's W slice live in
+  // the LDS behind the x tiles -- the W stream is bound by the vector-memory path, LDS reads are not
+  Frag* wl = (Frag*)(xs0 + 2 * 32 * LDX) + (w * 4 * 6) * 64 + lane;
+  if constexpr (WLDS) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int kc = 0; kc < 6; ++kc) wl[(q * 6 + kc) * 64] = wp[(q * NKX + kc) * 64];
+  }
   // stationary weights (bf16, H = 128): U always, W when its NKX k-chunks fit the same 8-chunk budget
   constexpr int NKS = R::STATF ? R::NKC : 1;      // WSTAT: the launcher guarantees NKX == NKC
   constexpr int NKW = (R::STATF && WSTAT) ? R::NKC : 1;
@@ -437,10 +446,17 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
                                 // the ring depth (259 inputs: 18 chunks = 3 x 6 instead of 24 = 3 x 8)
 #define DJ_W_STREAM(PW)                                                                     \
   {                                                                                         \
+    constexpr int k0 = (PW == 6 && WLDS) ? 6 : 0;   /* chunks 0..k0-1 come from LDS */      \
     Frag bw[PW][4];                                                                         \
     _Pragma("unroll") for (int p = 0; p < PW; ++p)                                          \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) bw[p][q] = wp[(q * NKX + p) * 64];    \
-    _Pragma("unroll 1") for (int kc0 = 0; kc0 < NKX; kc0 += PW) {                           \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) bw[p][q] = wp[(q * NKX + k0 + p) * 64]; \
+    if constexpr (k0 > 0) {                                                                 \
+      _Pragma("unroll") for (int kc = 0; kc < 6; ++kc) {                                    \
+        Frag a = dj_lds_frag(xp + kc * R::KC, h);                                           \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) dj_mfma(acc[q], a, wl[(q * 6 + kc) * 64]); \
+      }                                                                                     \
+    }                                                                                       \
+    _Pragma("unroll 1") for (int kc0 = k0; kc0 < NKX; kc0 += PW) {                          \
       _Pragma("unroll") for (int uu = 0; uu < PW; ++uu) {                                   \
         const int kc = kc0 + uu;                                                            \
         Frag a = dj_lds_frag(xp + kc * R::KC, h);                                           \
@@ -450,7 +466,7 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
       }                                                                                     \
     }                                                                                       \
   }
-        if (NKX % 8 == 0) DJ_W_STREAM(8) else DJ_W_STREAM(6)
+        if constexpr (WLDS) DJ_W_STREAM(6) else if (NKX % 8 == 0) DJ_W_STREAM(8) else DJ_W_STREAM(6)
 #undef DJ_W_STREAM
       }
       if (t > 0) {
@@ -1249,21 +1265,35 @@ int launch_pack_w(const float* W, int D, int NKX, void* out, hipStream_t st) {
   hipLaunchKernelGGL((pack_w_fwd_kernel<T, H>), dim3((n + 255) / 256), dim3(256), 0, st, W, D, NKX, (T*)out);
   return (int)hipGetLastError();
 }
-template <typename T, int H, bool SIGM, bool WSTAT>
-int launch_fwd_fused_w(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
+template <typename T, int H, bool SIGM, bool WSTAT, bool WLDS>
+int launch_fwd_fused_k(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
                        void* Zst, const void* Upack, void* Hout, void* Cout, size_t smem, hipStream_t st) {
   using R = RecCfg<T, H>;
   static bool attr_done_dev[DJ_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[dj_current_device()];
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_fused_kernel<T, H, SIGM, WSTAT>,
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_fused_kernel<T, H, SIGM, WSTAT, WLDS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((lstm_fwd_fused_kernel<T, H, SIGM, WSTAT>), dim3(ntiles), dim3(R::NT), smem, st, (const T*)X, DP,
-                     NKX, (const T*)Wpack, bias, (T*)Zst, (const T*)Upack, (T*)Hout, (T*)Cout, steps);
+  hipLaunchKernelGGL((lstm_fwd_fused_kernel<T, H, SIGM, WSTAT, WLDS>), dim3(ntiles), dim3(R::NT), smem, st, (const T*)X,
+                     DP, NKX, (const T*)Wpack, bias, (T*)Zst, (const T*)Upack, (T*)Hout, (T*)Cout, steps);
   return (int)hipGetLastError();
+}
+template <typename T, int H, bool SIGM, bool WSTAT>
+int launch_fwd_fused_w(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
+                       void* Zst, const void* Upack, void* Hout, void* Cout, size_t smem, hipStream_t st) {
+  using R = RecCfg<T, H>;
+  // streamed-W path with the ring of 6: one ring block of W in LDS when it fits (note layer 0: 55 + 96 KB)
+  if constexpr (R::STATF && !WSTAT) {
+    const size_t extra = (size_t)R::NW * 4 * 6 * 1024;
+    if (NKX % 8 && NKX % 6 == 0 && NKX > 6 && smem + extra <= 160 * 1024)
+      return launch_fwd_fused_k<T, H, SIGM, WSTAT, true>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout,
+                                                         smem + extra, st);
+  }
+  return launch_fwd_fused_k<T, H, SIGM, WSTAT, false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem,
+                                                      st);
 }
 template <typename T, int H, bool SIGM>
 int launch_fwd_fused_s(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
