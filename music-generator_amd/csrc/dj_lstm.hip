@@ -18,9 +18,16 @@
 //    continuous fragment stream (no Zx round trip through HBM);
 //  * H = 128 in bf16 (one wave per SIMD, VGPR + AGPR): the wave's slices of U / U^T, of W up to 128 input
 //    columns and of W^T of a <= 128-wide layer are loaded once and stay in registers (STATF / STATB / WSTAT /
-//    DX), so the note-axis recurrence streams no weights; wider inputs stream W 8 fragments deep;
+//    DX), so the note-axis recurrence streams no weights; wider inputs stream W through a ring of 8 or 6
+//    fragments per gate, the first ring block LDS-resident where it fits (WLDS: note layer 0);
 //  * the BPTT kernel can also emit dX = dz W^T (whole, or the last 32-column block with K split over the
-//    waves) from the dz tile it holds in LDS.
+//    waves) from the dz tile it holds in LDS; its streamed-U^T build (H = 256) keeps the first 8 of a wave's
+//    64 k-chunks in the LDS the tiles leave free (BwdUlds);
+//  * lstm_fwd_cluster_kernel (bf16, H = 256, >= 64 tiles): 8 workgroups of one XCD keep the W and U slices of
+//    32 hidden units each in LDS for the whole sweep and exchange h slices through L2 once per step.
+// The weight streams are bound by the CU's vector-memory path (64 B/clk), not by L2 or HBM: every fragment
+// that can live in registers or LDS instead is time won, and every loop bound in these kernels has to be a
+// compile-time constant (run-time variants of the same loops measured +0.4 ... +0.5 ms).
 //
 // Data layouts in HBM:
 //  * Z  (x_t W + b in, pre-activations z_t out, in place) and the cell stash C are
