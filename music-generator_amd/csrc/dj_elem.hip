@@ -295,6 +295,35 @@ __global__ __launch_bounds__(256) void feature_asm_kernel(FeatArgs a, T* __restr
         }
       }
       // the remaining columns: [0, 14) and [14+64, FP)
+      if (nrest == 32) {
+        // fast path (FP = 96): a thread keeps ONE column q = tid & 31 for all its notes, so everything that does not
+        // depend on the note is computed once per (b, t) and no index needs a division
+        const int q = tid & 31, col = q < conv_col0 ? q : q + CONV_O;
+        float add = 0.f;                               // note-independent part of the value
+        if (col > a.octave + 1 && col < a.F) {         // beat, model.py:66
+          const int j = col - conv_col0 - CONV_O;
+          add = a.beat[(int64_t)bt * a.NB + j] * dj_keep(a.d_beat, dj_rowkey(a.d_beat, bt), j);
+        }
+        const float spc = col < a.F ? a.sp0[(int64_t)bt * a.F + col] : 0.f;
+        // pitch_bins quirk (model.py:43-49): flat index f = bt N + n, value bins[((f / BT) % octave) BT + f % BT]
+        const int64_t bT = (int64_t)a.B * a.T, f0 = (int64_t)bt * a.N + n0;
+        int64_t fq = f0 / bT, fr = f0 % bT;            // uniform; advanced per note below
+        for (int nl = tid >> 5; nl < nc; nl += 8) {
+          const int n = n0 + nl;
+          float v = add;
+          if (col == 0) {
+            v = (float)n / (float)a.N;                              // model.py:22-30
+          } else if (col <= a.octave) {
+            v = ((n % a.octave) == col - 1) ? 1.f : 0.f;            // model.py:32-41
+          } else if (col == a.octave + 1) {
+            int64_t q2 = fq, r2 = fr + nl;
+            while (r2 >= bT) { r2 -= bT; ++q2; }
+            v = a.bins[(q2 % a.octave) * bT + r2];
+          }
+          if (col < a.F) v += spc * dj_keep(a.d_style, rks[n], col);
+          xrow[nl * a.FP + col] = dj_from_f32<T>(v);
+        }
+      } else
       for (int i = tid; i < nc * nrest; i += 256) {
         const int nl = i / nrest, q = i - nl * nrest, n = n0 + nl;
         const int col = q < conv_col0 ? q : q + CONV_O;
