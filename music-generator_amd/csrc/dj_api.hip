@@ -172,7 +172,7 @@ int make_plan(const dj_config* cfg, Plan& p) {
 
 DjDrop mkdrop(uint64_t seed, int site, float prob, bool train) {
   DjDrop d;
-  d.key = (uint32_t)(seed & 0xFFFFFFFFu) ^ ((uint32_t)site * 0x9E3779B9u);
+  d.key = dj_dropkey(seed, (uint32_t)site);
   d.thr = (train && prob > 0.f) ? (uint32_t)ceil((double)prob * 65536.0) : 0u;
   d.scale = (float)(1.0 / (1.0 - (double)prob));
   return d;

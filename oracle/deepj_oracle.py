@@ -158,11 +158,14 @@ def drop_threshold(p: float) -> int:
 
 def keep_mask(seed: int, site: int, rows: int, d: int, p: float) -> np.ndarray:
     """Boolean keep mask [rows, d]; one hash serves a pair of columns: with
-    h = lowbias32(lowbias32(row + key) + (c >> 1) * 0x9E3779B9), element (row, c) is kept iff
-    (h >> 16 if c is odd else h & 0xFFFF) >= ceil(p * 2^16)."""
+    key = lowbias32(lowbias32(seed_lo ^ site * 0x9E3779B9) + seed_hi) and
+    h = lowbias32(lowbias32(lowbias32(row) + key) + (c >> 1) * 0x9E3779B9), element (row, c) is kept iff
+    (h >> 16 if c is odd else h & 0xFFFF) >= ceil(p * 2^16).  Seed and row are each hashed before they
+    meet, so the masks of neighbouring seeds / sites are not shifted copies of one another."""
     with np.errstate(over="ignore"):
-        key = np.uint32(seed & 0xFFFFFFFF) ^ (np.uint32(site) * np.uint32(0x9E3779B9))
-        rk = _lowbias32(np.arange(rows, dtype=np.uint32) + key)
+        key = _lowbias32(np.array([(seed & 0xFFFFFFFF) ^ ((site * 0x9E3779B9) & 0xFFFFFFFF)], dtype=np.uint32))
+        key = _lowbias32(key + np.uint32((seed >> 32) & 0xFFFFFFFF))[0]
+        rk = _lowbias32(_lowbias32(np.arange(rows, dtype=np.uint32)) + key)
         cols = np.arange(d, dtype=np.uint32)
         h = _lowbias32(rk[:, None] + ((cols >> np.uint32(1)) * np.uint32(0x9E3779B9))[None, :])
         bits = np.where((cols & np.uint32(1))[None, :] == 1, h >> np.uint32(16), h & np.uint32(0xFFFF))

@@ -118,3 +118,82 @@ def test_dropout_hash_statistics_and_determinism():
     np.testing.assert_array_equal(m, O.keep_mask(11, 4, 4096, 64, 0.5))
     assert (O.keep_mask(12, 4, 64, 64, 0.5) != m[:64]).any()
     assert O.drop_threshold(0.5) == 32768 and O.drop_threshold(0.2) == 13108
+
+
+def test_dropout_masks_of_neighbouring_seeds_and_sites_are_not_shifted_copies():
+    """Product seeds are consecutive integers (step * world + rank) and sites are small integers: the mask of
+    seed s+1 (or site k+1) must not be the mask of seed s slid along the rows.  Agreement of two independent
+    p = 0.5 masks is 0.5 +- 3 sigma at every row shift."""
+    rows, cols, p = 4096, 64, 0.5
+    sigma = 0.5 / np.sqrt((rows - 8) * cols)
+
+    def agreement(a, b, shift):
+        if shift >= 0:
+            return (a[shift:] == b[:rows - shift]).mean()
+        return (a[:rows + shift] == b[-shift:]).mean()
+
+    pairs = [((s, 4), (s + 1, 4)) for s in (0, 7, 1000003, 2 ** 32 - 1, 123456789012)]
+    pairs += [((5, k), (5, k + 1)) for k in (1, 2, 3, 16, 32, 48, 64)]
+    pairs += [((5, 16), (5, 32)), ((9, 4), (9 + 2 ** 32, 4))]
+    for (sa, ka), (sb, kb) in pairs:
+        a, b = O.keep_mask(sa, ka, rows, cols, p), O.keep_mask(sb, kb, rows, cols, p)
+        for shift in range(-8, 9):
+            assert abs(agreement(a, b, shift) - 0.5) < 5 * sigma, ((sa, ka), (sb, kb), shift)
+
+
+def test_lstm_seq_matches_torch_nn_lstm_with_sigmoid_gates():
+    """Independent pin of the restated Keras cell: torch.nn.LSTM implements the same recurrence with gate order
+    i, f, g, o (= Keras i, f, c, o) and sigmoid recurrent activations; with copied weights
+    (weight_ih = W^T, weight_hh = U^T, bias_ih = b, bias_hh = 0) outputs and final state must agree.
+    reference model.py:84,120 (Keras LSTM layers)."""
+    cfg = O.OracleConfig(recurrent_activation="sigmoid")
+    rs = np.random.RandomState(0)
+    for S, L, D, H in [(5, 7, 9, 6), (3, 12, 94, 32)]:
+        W = torch.from_numpy(rs.randn(D, 4 * H).astype(np.float64) * 0.3)
+        U = torch.from_numpy(rs.randn(H, 4 * H).astype(np.float64) * 0.3)
+        b = torch.from_numpy(rs.randn(4 * H).astype(np.float64) * 0.1)
+        x = torch.from_numpy(rs.randn(S, L, D).astype(np.float64))
+        out, h, c = O.lstm_seq(cfg, x, W, U, b, return_state=True)
+        ref = torch.nn.LSTM(D, H, batch_first=True).double()
+        with torch.no_grad():
+            ref.weight_ih_l0.copy_(W.T)
+            ref.weight_hh_l0.copy_(U.T)
+            ref.bias_ih_l0.copy_(b)
+            ref.bias_hh_l0.zero_()
+            rout, (rh, rc) = ref(x)
+        torch.testing.assert_close(out, rout, rtol=1e-10, atol=1e-12)
+        torch.testing.assert_close(h, rh[0], rtol=1e-10, atol=1e-12)
+        torch.testing.assert_close(c, rc[0], rtol=1e-10, atol=1e-12)
+    # and the hard_sigmoid variant differs from it only through the gate nonlinearity: same cell with
+    # clip(0.2 z + 0.5) restated step by step in NumPy
+    cfg_h = O.OracleConfig()
+    S, L, D, H = 4, 6, 5, 3
+    W, U, b = rs.randn(D, 4 * H) * 0.5, rs.randn(H, 4 * H) * 0.5, rs.randn(4 * H) * 0.2
+    x = rs.randn(S, L, D)
+    out = O.lstm_seq(cfg_h, *[torch.from_numpy(a) for a in (x, W, U, b)]).numpy()
+    hs = lambda z: np.clip(0.2 * z + 0.5, 0, 1)
+    h, c = np.zeros((S, H)), np.zeros((S, H))
+    for t in range(L):
+        z = x[:, t] @ W + h @ U + b
+        c = hs(z[:, H:2 * H]) * c + hs(z[:, :H]) * np.tanh(z[:, 2 * H:3 * H])
+        h = hs(z[:, 3 * H:]) * np.tanh(c)
+        np.testing.assert_allclose(out[:, t], h, rtol=1e-12, atol=1e-14)
+
+
+def test_bce_matches_torch_binary_cross_entropy_away_from_the_clip():
+    """Keras/TF1 binary_crossentropy on probabilities = -t log p - (1-t) log(1-p) wherever the 1e-7 clip is
+    inactive; at the clip it saturates at -log(1e-7).  reference model.py:14-20."""
+    rs = np.random.RandomState(1)
+    p = torch.from_numpy(rs.uniform(1e-4, 1 - 1e-4, (64, 48)))
+    t = torch.from_numpy((rs.rand(64, 48) < 0.3).astype(np.float64))
+    ref = torch.nn.functional.binary_cross_entropy(p, t, reduction="none")
+    torch.testing.assert_close(O._bce(t, p), ref, rtol=1e-9, atol=1e-12)
+    soft = torch.from_numpy(rs.rand(64, 48))               # soft targets too (the masked replay term feeds them)
+    ref = -(soft * torch.log(p) + (1 - soft) * torch.log(1 - p))
+    torch.testing.assert_close(O._bce(soft, p), ref, rtol=1e-9, atol=1e-12)
+    edge = O._bce(torch.tensor([1.0, 0.0]), torch.tensor([0.0, 1.0]).double())
+    np.testing.assert_allclose(edge.numpy(), [-np.log(1e-7)] * 2, rtol=1e-6)
+    # the gradient through the restated form is the textbook (p - t) / (p (1 - p))
+    pg = p.clone().requires_grad_(True)
+    O._bce(t, pg).sum().backward()
+    torch.testing.assert_close(pg.grad, (p - t) / (p * (1 - p)), rtol=1e-7, atol=1e-9)
