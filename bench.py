@@ -9,7 +9,10 @@ plus the RCCL gradient all-reduce when N > 1) over one synthetic batch of
 B=64 x T=128 x N=128 per GPU (BASELINE.json configs[1]; weak scaling: global batch
 64*N).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON
 line.  `roofline` is measured live with HIP events recorded by the library around
-every launch (dj_profile_*); `cpu_baseline` times the CPU oracle on a bounded sample.
+every launch (dj_profile_*); `cpu_baseline` times the CPU oracle on a bounded sample
+(1 warm-up + 3 timed steps on 8 of the 64 sequences); `fp32_parity_mode` is the same step in
+the fp32 mode the 1e-3 parity gate runs in; `generation` is BASELINE configs[3] (3 pieces,
+1024 steps).  `--config scaled` times BASELINE configs[4] (3 x 1024 units per axis) instead.
 """
 import argparse
 import ctypes as C
@@ -70,9 +73,10 @@ def category_flops(cfg, B, T, N):
 
 def category_bytes(cfg, B, T, N, esize):
     """ALGORITHMIC HBM bytes per training step of the same categories: activations only (weights
-    stay in L2), esize bytes per element.  Per row of an LSTM layer with input width D and H units:
-    forward reads x (D) and writes the BPTT stash z (4H), h (H), c (H); the unfused variant reads
-    and rewrites z instead of reading x; backward reads z (4H), c (H), dh (H) and writes dz (4H);
+    stay in L2), esize bytes per element, gate stash at s bytes per element (bf16 mode: 8-bit activated gates,
+    s = 1; fp32 mode: z, s = 4).  Per row of an LSTM layer with input width D and H units:
+    forward reads x (D) and writes the gate stash (4H at s), h (H), c (H); the unfused variant reads
+    x W + b (4H) instead of x; backward reads the gate stash (4H at s), c (H), dh (H) and writes dz (4H);
     dW/dU read dz (4H), x (D), h (H); dX reads dz (4H) and writes dx (D)."""
     Ht, Hn = cfg.time_axis_units, cfg.note_axis_units
     rows = B * T * N
@@ -82,12 +86,13 @@ def category_bytes(cfg, B, T, N, esize):
     out = {k: 0 for k in ("gemm_xw", "gemm_dx", "gemm_dw", "lstm_fwd_time", "lstm_bwd_time", "lstm_fwd_note",
                           "lstm_bwd_note")}
     for axis, H, dims in (("time", Ht, t_in), ("note", Hn, n_in)):
+        s = (1 if esize == 2 else 4) if H in (128, 256) else esize     # persistent kernels only (dj_lstm.hip GateEnc)
         for d in dims:
             fused = _fused_xw(cfg, d, H)
-            out["lstm_fwd_" + axis] += rows * esize * ((d + 6 * H) if fused else 10 * H)
+            out["lstm_fwd_" + axis] += rows * (esize * ((d + 2 * H) if fused else 6 * H) + s * 4 * H)
             if not fused:
                 out["gemm_xw"] += rows * esize * (d + 4 * H)
-            out["lstm_bwd_" + axis] += rows * esize * 10 * H
+            out["lstm_bwd_" + axis] += rows * (esize * 6 * H + s * 4 * H)
             out["gemm_dw"] += rows * esize * (5 * H + d)
             if _fused_dx(cfg, d, H):
                 out["lstm_bwd_" + axis] += rows * esize * d          # dx written by the BPTT kernel itself
@@ -122,9 +127,12 @@ def cpu_share():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(cfg, T, N, sample_b, pin, pdr):
-    """CPU oracle (torch-CPU fp32 restatement of the reference) on a bounded sample of the
-    same workload: sample_b sequences of the B=64 batch, one forward + BPTT + Nadam step."""
+def cpu_baseline(cfg, T, N, sample_b, pin, pdr, batch, warmup=1, steps=3):
+    """CPU oracle (torch-CPU fp32 restatement of the reference: "port") on a bounded sample of the same
+    workload: the first sample_b sequences of the `batch`-sequence synthetic batch, `warmup` untimed +
+    `steps` timed training steps (forward + BPTT + Nadam, dropout on) at the full T and N.  note-steps/s of
+    the oracle does not depend on the batch size in this range (3.3 k/s at 2 sequences, 3.7 k/s at 8 on 8
+    cores), so the sample rate is the rate of the full batch."""
     from oracle import deepj_oracle as O
     from music_generator_amd.data import synthetic_batch
     ocfg = O.OracleConfig(num_notes=N, time_steps=T, time_axis_units=cfg.time_axis_units,
@@ -133,18 +141,63 @@ def cpu_baseline(cfg, T, N, sample_b, pin, pdr):
     cores = cpu_share()
     torch.set_num_threads(cores)
     params = O.init_params(ocfg, seed=1234)
-    batch = synthetic_batch(N, T, sample_b, seed=0)
-    masks = O.make_masks(ocfg, sample_b, 0, pin, pdr, T=T)
+    data = [a[:sample_b] for a in synthetic_batch(N, T, batch, seed=0)]
     st = O.NadamState()
-    t0 = time.time()
-    loss, _, grads = O.loss_and_grads(ocfg, params, batch, masks)
     flat = O.flatten_params(ocfg, params)
-    O.nadam_step(flat, O.flatten_params(ocfg, grads), st)
-    dt = time.time() - t0
+    times, loss = [], None
+    for i in range(warmup + steps):
+        masks = O.make_masks(ocfg, sample_b, i, pin, pdr, T=T)
+        t0 = time.time()
+        loss, _, grads = O.loss_and_grads(ocfg, O.unflatten_params(ocfg, flat), data, masks)
+        flat = O.nadam_step(flat, O.flatten_params(ocfg, grads), st)
+        times.append(time.time() - t0)
+    dt = sum(times[warmup:]) / steps
     return {"value": sample_b * T * N / dt, "unit": "note-steps/sec", "cores": cores, "kind": "port",
-            "sample": f"CPU oracle (torch-CPU fp32), 1 train step (fwd+BPTT+Nadam, dropout on) on {sample_b} of the "
-                      f"64 sequences, T={T}, N={N}: {dt:.1f} s",
-            "loss": loss}
+            "sample": f"CPU oracle (torch-CPU fp32, {cores} threads): {warmup} warm-up + {steps} timed train steps "
+                      f"(fwd+BPTT+Nadam, dropout on) on {sample_b} of the {batch} sequences at T={T}, N={N}: "
+                      f"{dt:.1f} s per step; rate taken as the full batch's (note-steps/s is flat in the batch size)",
+            "sample_sequences": sample_b, "warmup_steps": warmup, "timed_steps": steps,
+            "s_per_step": [round(t, 2) for t in times], "loss": loss}
+
+
+def make_step(eng, opt, P, G, batch, world, rank, dist):
+    """THE timed step: forward + BPTT, one all-reduce(sum) of the flat fp32 gradient over RCCL/xGMI when
+    world > 1, Nadam with the 1/world scale folded in.  Factored out so that the 2-rank gloo test
+    (tests/test_bench_cpu.py) runs exactly this function."""
+    notes, chosen, beat, style, target = batch
+
+    def step(i):
+        loss = eng.train_fwd_bwd(P, G, notes, chosen, beat, style, target, seed=i * world + rank)
+        if world > 1:
+            dist.all_reduce(G)                           # one flat fp32 buffer
+        opt.step(P, G, grad_scale=1.0 / world)
+        return loss
+    return step
+
+
+def fp32_parity_mode(cfg_kw, B, T, N, pin, pdr, dev, rank, steps=3, warmup=1):
+    """The same training step in the fp32 mode the 1e-3 parity tests run in (v_mfma_f32_32x32x2_f32)."""
+    from music_generator_amd.data import synthetic_batch
+    from music_generator_amd.engine import DeepJConfig, Engine, Nadam, init_params_numpy
+    cfg = DeepJConfig(dtype="f32", **cfg_kw)
+    eng = Engine(cfg, B, T, device=dev, input_dropout=pin, dropout=pdr)
+    P = torch.from_numpy(init_params_numpy(cfg, seed=1234)).to(dev)
+    G = torch.zeros_like(P)
+    step = make_step(eng, Nadam(P.numel(), dev), P, G,
+                     [torch.from_numpy(a).to(dev) for a in synthetic_batch(N, T, B, seed=rank)], 1, 0, None)
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"ms_per_step": round(dt * 1e3, 3), "value": round(B * T * N / dt, 1), "unit": "note-steps/sec",
+           "steps": steps, "warmup": warmup, "dtype": "f32", "final_loss": round(float(loss.cpu()[0]), 5)}
+    del eng, P, G
+    torch.cuda.empty_cache()
+    return out
 
 
 def generation_bench(dtype, steps):
@@ -174,9 +227,19 @@ def generation_bench(dtype, steps):
                 break
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+    # ALGORITHMIC HBM bytes of one generated time step: the stateless 128-step window through the time axis
+    # (generate.py:106-109; per row and layer: x in, x W + b out and back in, h out = (D + 9 H) elements; layer 1's
+    # input is a glue copy of layer 0's h: + 2 H) plus one pass over the fp32 weights; the note loop runs out of L2
+    K = Gn.__dict__
+    rows = 3 * K["NUM_NOTES"] * K["SEQ_LEN"]
+    F, Ht, e = 94, K["TIME_AXIS_UNITS"], (2 if dtype == "bf16" else 4)
+    gen_bytes = rows * e * ((F + 9 * Ht) + (Ht + 9 * Ht) + 2 * Ht) + 1269476 * 4
     return {"metric": "gen notes/sec", "value": round(3 * 48 * n / dt, 1), "unit": "notes/sec",
             "ms_per_time_step": round(dt / n * 1e3, 3), "pieces": 3, "notes": 48, "window": 128, "steps": n,
-            "dtype": dtype, "path": "dj_generate_step (fused), NumPy MT19937 draws in reference order"}
+            "dtype": dtype, "hbm_gbs": round(gen_bytes / (dt / n) / 1e9, 1), "hbm_bytes_per_step": gen_bytes,
+            "bound": "latency (M = 144 rows, 128 + 48 dependent steps per generated step)",
+            "near_tie_draws": Gn.last_run_stats["near_ties"], "draws": Gn.last_run_stats["draws"],
+            "path": "dj_generate_step_resident (hipGraph replay), NumPy MT19937 draws in reference order"}
 
 
 def main():
@@ -188,11 +251,16 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE: 64)")
     ap.add_argument("--time-steps", type=int, default=128)
     ap.add_argument("--notes", type=int, default=128)
-    ap.add_argument("--cpu-sample", type=int, default=2, help="sequences in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="sequences in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (after 1 warm-up)")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode timing")
+    ap.add_argument("--config", default="baseline", choices=["baseline", "scaled"],
+                    help="baseline = BASELINE configs[1] (2x256 + 2x128, B64 T128 N128); scaled = configs[4] "
+                         "(3x1024 per axis, B128 T256 N128 as micro-batches)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--dropout", type=float, nargs=2, default=None, metavar=("INPUT", "HIDDEN"),
                     help="override the reference's dropout rates 0.2 0.5 (experiments only; the metric uses the defaults)")
-    ap.add_argument("--gen-steps", type=int, default=32, help="generated time steps for the secondary metric (0 = skip)")
+    ap.add_argument("--gen-steps", type=int, default=1024, help="generated time steps for the secondary metric (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -225,13 +293,7 @@ def main():
     notes, chosen, beat, style, target = [torch.from_numpy(a).to(dev)
                                           for a in synthetic_batch(N, T, B, seed=rank)]
     lib = _lib.load()
-
-    def step(i):
-        loss = eng.train_fwd_bwd(P, G, notes, chosen, beat, style, target, seed=i * world + rank)
-        if world > 1:
-            dist.all_reduce(G)                           # one flat fp32 buffer, RCCL over xGMI
-        opt.step(P, G, grad_scale=1.0 / world)
-        return loss
+    step = make_step(eng, opt, P, G, (notes, chosen, beat, style, target), world, rank, dist)
 
     for i in range(args.warmup):
         step(i)
@@ -250,6 +312,14 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     final_loss = float(loss.cpu()[0])
+    faults = eng.cluster_faults()
+    if world > 1:
+        f = torch.tensor([float(faults)], dtype=torch.float64, device=dev)
+        dist.all_reduce(f)
+        faults = int(f.cpu()[0])
+    if faults or not np.isfinite(final_loss):
+        raise SystemExit(f"invalid run: {faults} cluster faults, final loss {final_loss} -- no number is reported "
+                         "(DEEPJ_CLUSTER=0 selects the per-tile kernel)")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -287,7 +357,8 @@ def main():
         else:
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(tflops, 2), "peak": PEAK_TFLOPS[args.dtype],
                     "unit": "TFLOP/s", "frac": round(tflops / PEAK_TFLOPS[args.dtype], 4)}
-        roof.update({"traffic": traffic, "traffic_source": tsrc, "launches_per_step": lps[dom],
+        roof.update({"traffic": traffic, "traffic_committed_pmc": traffic, "traffic_source": tsrc,
+                     "launches_per_step": lps[dom],
                      "avg_launch_ms": round(ms / lps[dom], 4), "bytes_per_launch": by[dom] / lps[dom],
                      "flops_per_launch": fl[dom] / lps[dom],
                      "mfma_tflops": round(tflops, 2), "mfma_frac": round(tflops / PEAK_TFLOPS[args.dtype], 4),
@@ -314,15 +385,17 @@ def main():
             "final_loss": round(final_loss, 5),
             "roofline": roof, "kernel_ms_per_step": kernels, "kernel_rates": roof_all,
         }
+        del eng
+        torch.cuda.empty_cache()
+        if world == 1 and args.dtype != "f32" and not args.no_fp32:
+            out["fp32_parity_mode"] = fp32_parity_mode(dict(num_notes=N, time_steps=T), B, T, N, pin, pdr, dev, rank)
+        if world == 1 and args.gen_steps > 0:
+            out["generation"] = generation_bench(args.dtype, args.gen_steps)
         if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(cfg, T, N, args.cpu_sample, pin, pdr)
+            out["cpu_baseline"] = cpu_baseline(cfg, T, N, min(args.cpu_sample, B), pin, pdr, B, steps=args.cpu_steps)
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         else:
             out["cpu_baseline"] = None
-        if world == 1 and args.gen_steps > 0:
-            del eng
-            torch.cuda.empty_cache()
-            out["generation"] = generation_bench(args.dtype, args.gen_steps)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

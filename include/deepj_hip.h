@@ -107,7 +107,9 @@ int32_t dj_note_model_predict(const dj_config* cfg, const float* params, const f
  * to high with the note-axis state carried from note to note (equivalent to the reference's
  * N note_model.predict calls).  uniforms [2*N*G] (float64, device) are consumed in the
  * reference's draw order (note-major, piece-minor, replay draw only after a successful play
- * draw, generate.py:52-58); *draws_used returns how many were consumed.  temperature [G]
+ * draw, generate.py:52-58); draws_used [2] (int32): [0] = how many were consumed, [1] = how many of them fell
+ * within 1e-5 of the probability they were compared with (decisions that depend on the last digits of p: zero
+ * certifies the sampled notes against every model whose probabilities agree to 1e-5).  temperature [G]
  * (apply_temperature, generate.py:81-91).  next_notes [G,N,3] = (play, replay, volume). */
 int32_t dj_generate_step(const dj_config* cfg, const float* params, const float* notes_win, const float* beat_win,
                          const float* style_win, const double* uniforms, const float* temperature, float* next_notes,
@@ -122,7 +124,8 @@ int32_t dj_generate_step(const dj_config* cfg, const float* params, const float*
 typedef struct dj_gen_state {
   int32_t step;                /* time steps generated so far (index into results)            */
   int32_t draw_off;            /* uniforms consumed so far (index into the pool)              */
-  int32_t pad0, pad1;
+  int32_t near_ties;           /* draws so far with |u - p| < 1e-5 (see dj_generate_step)      */
+  int32_t first_near_step;     /* time step of the first of them; initialise to -1             */
   double temperature[8];       /* per piece, float64 like the reference                        */
   double default_temp[8];
   int32_t silent[8];           /* silent_time, starts at NOTES_PER_BAR (generate.py:24)        */
@@ -157,22 +160,31 @@ int32_t dj_lstm_wgrad(int32_t dtype, int64_t M, int32_t steps, const void* X, in
 /* Pack a Keras recurrent_kernel U[H,4H] (fp32) into MFMA B-fragment order for the
  * forward (U) and backward (U^T) recurrences; each output holds H*4H operand elements. */
 int32_t dj_lstm_pack(int32_t dtype, int32_t H, const float* U, void* upack_fwd, void* upack_bwd, void* stream);
-/* Recurrent sweep over `steps` for ntiles*32 sequences.  Z (fragment-tiled, see dj_gemm_nt
- * c_mode 2; [ntiles*steps*32, 4H] logical) holds x*W+b on entry and the pre-activations on
- * exit; h -> Hout (row-major [rows, H]); c -> Cout (fragment-tiled [rows, H], may be NULL).
- * Row order: ((tile*steps + step)*32 + seq_in_tile). */
-int32_t dj_lstm_fwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, void* Z, const void* upack_fwd,
-                    void* Hout, void* Cout, int32_t recurrent_sigmoid, void* stream);
+/* Gate stash: what a forward sweep leaves for BPTT, [rows, 4H] logical, FRAGMENT-TILED like dj_gemm_nt c_mode 2
+ * (block (rb, cb) at element ((rb*(4H/32) + cb)*64 + lane)*16).  DJ_DTYPE_F32: the pre-activations z as fp32
+ * (BPTT recomputes the activations).  DJ_DTYPE_BF16: the ACTIVATED gates as 8-bit codes, one byte per element --
+ * i, f, o: code = clamp(ceil(254 y), 0, 255), decoded (code - 0.5)/254 clamped to [0,1], codes 0 / 255 reserved for
+ * the saturated hard_sigmoid so that its derivative mask is exact; g: code = round(127 g) + 128 -- half the bytes of a
+ * bf16 z stash on kernels that are HBM-bound on them.  dj_lstm_stash_bytes gives the buffer size for `rows` rows
+ * (-1 for an unsupported dtype / H). */
+int64_t dj_lstm_stash_bytes(int32_t dtype, int32_t H, int64_t rows);
+/* Recurrent sweep over `steps` for ntiles*32 sequences.  Zx (fragment-tiled, operand dtype, see dj_gemm_nt
+ * c_mode 2; [ntiles*steps*32, 4H] logical) holds x*W+b; `stash` receives the gate stash (may be NULL; in fp32 it may
+ * be Zx itself, in bf16 it must not); h -> Hout (row-major [rows, H]); c -> Cout (fragment-tiled [rows, H], may be
+ * NULL).  Row order: ((tile*steps + step)*32 + seq_in_tile). */
+int32_t dj_lstm_fwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Zx, void* stash,
+                    const void* upack_fwd, void* Hout, void* Cout, int32_t recurrent_sigmoid, void* stream);
 /* The same sweep with the input projection fused in (what the training / predict paths use):
  * z_t = x_t W + h_{t-1} U + b with X row-major [rows, DP] (D valid columns), W packed by
  * dj_lstm_pack_w (at most 4H * (roundup(D, 8) + 128) operand elements),
- * bias[4H] fp32.  Zstash (fragment-tiled, may be NULL) receives the pre-activations.  The bf16 build for
- * H = 128 keeps U (and W for D <= 128) in registers. */
+ * bias[4H] fp32.  `stash` (may be NULL) receives the gate stash.  The bf16 build for H = 128 keeps U (and W for
+ * D <= 128) in registers.  cluster_scratch: NULL, or dj_lstm_cluster_scratch_bytes() bytes (128-byte aligned,
+ * zero-initialised once) that enable the weight-stationary cluster kernel below. */
 int32_t dj_lstm_pack_w(int32_t dtype, int32_t H, const float* W, int32_t D, void* wpack, void* stream);
 int32_t dj_lstm_fwd_fused(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* X, int32_t DP,
-                          int32_t D, const void* wpack, const float* bias, void* Zstash, const void* upack_fwd,
-                          void* Hout, void* Cout, int32_t recurrent_sigmoid, void* stream);
-/* BPTT sweep: Z / C = the forward's fragment-tiled pre-activations / cell states; dH = dL/dh
+                          int32_t D, const void* wpack, const float* bias, void* stash, const void* upack_fwd,
+                          void* Hout, void* Cout, int32_t recurrent_sigmoid, void* cluster_scratch, void* stream);
+/* BPTT sweep: Z / C = the forward's gate stash / fragment-tiled cell states; dH = dL/dh
  * per step (row-major [rows, H]); dZ (row-major [rows, 4H]) receives dL/dz;
  * dbias[4H] += column sums of dz. */
 int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack_bwd,
@@ -188,14 +200,19 @@ int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, 
                        const void* C, const void* dH, void* dZ, float* dbias, int32_t recurrent_sigmoid,
                        const void* wtpack, int32_t D, void* dX, int32_t DP, void* stream);
 /* The bf16 H = 256 forward sweep of 64..256 tiles runs as weight-stationary clusters of 8 workgroups that meet
- * once per step through a counter in L2 (dj_lstm.hip); a member that never arrives (grid not co-resident, e.g.
- * the device shared with another stream's kernels) cannot hang the device: the wait expires, the affected
- * tiles carry NaN from there on (so does the loss), and the event is counted.  Returns the number of expired
- * waits since the previous call (synchronises the device; 0 in a healthy run), -1 on a HIP error.
- * The clusters' counters and exchange buffer are per device, not per stream: run at most one such sweep per device
- * at a time (one training stream per device, as one process per GPU does), or set DEEPJ_CLUSTER=0, which selects
- * the per-tile kernel instead. */
-int32_t dj_lstm_cluster_faults(void);
+ * once per step through a counter in L2 (dj_lstm.hip).  Their exchange state (counters, the members' XCC ids, the h
+ * slices) lives in a caller-owned scratch -- part of the workspace for the dj_train / dj_predict calls, one per
+ * workspace and therefore per engine / stream; concurrent sweeps must not share one.  Two things are checked at run
+ * time and can never produce a silent wrong answer or a hung device: a member that never arrives (grid not
+ * co-resident, e.g. the device shared with another stream's kernels) lets the bounded wait expire; a cluster whose
+ * members report different hardware XCC ids (dispatch not round-robin over the XCDs, which the exchange through one
+ * XCD's L2 relies on) is detected in round 0.  In both cases the affected tiles carry NaN from there on (so does the
+ * loss) and the event is counted.  dj_lstm_cluster_faults / dj_workspace_cluster_faults return the number of events
+ * recorded in that scratch / workspace since the previous call (synchronise the device; 0 in a healthy run, -1 on a
+ * HIP error).  DEEPJ_CLUSTER=0 selects the per-tile kernel instead. */
+int64_t dj_lstm_cluster_scratch_bytes(void);
+int32_t dj_lstm_cluster_faults(void* cluster_scratch);
+int32_t dj_workspace_cluster_faults(const dj_config* cfg, void* workspace, int64_t workspace_bytes);
 /* mask[rows, cols] (fp32 0 or 1/(1-p)) of dropout site `site` -- exposes the counter
  * hash so tests can pin it against the oracle. */
 int32_t dj_dropout_mask(uint64_t seed, int32_t site, float p, int64_t rows, int32_t cols, float* mask, void* stream);

@@ -49,15 +49,18 @@ _SIGS = {
     "dj_lstm_wgrad": (C.c_int32, [C.c_int32, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P,
                                   C.c_int32, _P, _P, _P, _P]),
     "dj_lstm_pack": (C.c_int32, [C.c_int32, C.c_int32, _P, _P, _P, _P]),
-    "dj_lstm_fwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, _P]),
+    "dj_lstm_fwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P]),
+    "dj_lstm_stash_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int64]),
     "dj_lstm_pack_w": (C.c_int32, [C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),
     "dj_lstm_fwd_fused": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P, _P,
-                                      _P, _P, C.c_int32, _P]),
+                                      _P, _P, C.c_int32, _P, _P]),
     "dj_lstm_bwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "dj_lstm_bwd_dx": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P,
                                    C.c_int32, _P, C.c_int32, _P]),
     "dj_lstm_pack_wt": (C.c_int32, [C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),
-    "dj_lstm_cluster_faults": (C.c_int32, []),
+    "dj_lstm_cluster_scratch_bytes": (C.c_int64, []),
+    "dj_lstm_cluster_faults": (C.c_int32, [_P]),
+    "dj_workspace_cluster_faults": (C.c_int32, [C.POINTER(DjConfig), _P, C.c_int64]),
     "dj_dropout_mask": (C.c_int32, [C.c_uint64, C.c_int32, C.c_float, C.c_int64, C.c_int32, _P, _P]),
     "dj_profile_enable": (C.c_int32, [C.c_int32]),
     "dj_profile_category_count": (C.c_int32, []),

@@ -70,15 +70,20 @@ struct Plan {
   int64_t w_Wt_n[MAXL], w_Wc_n[MAXL], w_Uf_n[MAXL], w_Ub_n[MAXL], w_Wp_n[MAXL];
   int64_t w_X_t[MAXL], w_Z_t[MAXL], w_H_t[MAXL], w_C_t[MAXL];
   int64_t w_X_n[MAXL], w_Z_n[MAXL], w_H_n[MAXL], w_C_n[MAXL];
-  int64_t w_dH_t, w_dX_t, w_dH_n, w_dX_n, w_featin, w_dZ_t, w_dZ_n, w_zero, w_Xcol, w_Ycol, w_WcT, w_step;
+  int64_t w_dH_t, w_dX_t, w_dH_n, w_dX_n, w_featin, w_dZ_t, w_dZ_n, w_zero, w_Xcol, w_Ycol, w_WcT, w_step, w_cluster;
   int64_t ws_bytes;
 };
 
 inline int64_t up8(int64_t v) { return (v + 7) / 8 * 8; }
-
 // The persistent one-CU-per-sequence-tile recurrent kernels (dj_lstm.hip) exist for the reference's
 // layer widths; any other width runs the per-step GEMM + gate path (dj_step.hip).
 inline bool rec_persistent(int H) { return H == 128 || H == 256; }
+// gate stash of one layer, bytes per row: the persistent kernels keep z (fp32) or 8-bit activated gates (bf16),
+// the per-step path (dj_step.hip) keeps z in the operand dtype
+inline int64_t stash_row_bytes(const Plan& p, int H) {
+  return rec_persistent(H) ? dj_lstm_stash_row_bytes(p.c.dtype, H) : (int64_t)4 * H * p.esz;
+}
+
 
 int make_plan(const dj_config* cfg, Plan& p) {
   if (!cfg) return 1100;
@@ -136,7 +141,7 @@ int make_plan(const dj_config* cfg, Plan& p) {
     p.w_Wt_t[l] = wtake((int64_t)4 * L.H * (L.DP + 128) * p.esz); p.w_Wc_t[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
     p.w_Uf_t[l] = wtake((int64_t)L.H * 4 * L.H * p.esz); p.w_Ub_t[l] = wtake((int64_t)L.H * 4 * L.H * p.esz);
     p.w_Wp_t[l] = wtake((int64_t)(L.D + 31) / 32 * 32 * 4 * L.H * p.esz);
-    p.w_X_t[l] = wtake(p.Mt * L.DP * p.esz); p.w_Z_t[l] = wtake(p.Mt * 4 * L.H * p.esz);
+    p.w_X_t[l] = wtake(p.Mt * L.DP * p.esz); p.w_Z_t[l] = wtake(p.Mt * stash_row_bytes(p, L.H));
     p.w_H_t[l] = wtake(p.Mt * L.H * p.esz); p.w_C_t[l] = wtake(p.Mt * L.H * p.esz);
     if (L.DP > maxDPt) maxDPt = L.DP;
   }
@@ -146,7 +151,7 @@ int make_plan(const dj_config* cfg, Plan& p) {
     p.w_Wt_n[l] = wtake((int64_t)4 * L.H * (L.DP + 128) * p.esz); p.w_Wc_n[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
     p.w_Uf_n[l] = wtake((int64_t)L.H * 4 * L.H * p.esz); p.w_Ub_n[l] = wtake((int64_t)L.H * 4 * L.H * p.esz);
     p.w_Wp_n[l] = wtake((int64_t)(L.D + 31) / 32 * 32 * 4 * L.H * p.esz);
-    p.w_X_n[l] = wtake(p.Mn * L.DP * p.esz); p.w_Z_n[l] = wtake(p.Mn * 4 * L.H * p.esz);
+    p.w_X_n[l] = wtake(p.Mn * L.DP * p.esz); p.w_Z_n[l] = wtake(p.Mn * stash_row_bytes(p, L.H));
     p.w_H_n[l] = wtake(p.Mn * L.H * p.esz); p.w_C_n[l] = wtake(p.Mn * L.H * p.esz);
     if (L.DP > maxDPn) maxDPn = L.DP;
   }
@@ -159,6 +164,8 @@ int make_plan(const dj_config* cfg, Plan& p) {
   p.w_Ycol = wtake(p.Mt * 64 * p.esz);       // conv pre-activation -> tanh(conv) stash -> its gradient in BPTT
   p.w_WcT = wtake(64 * 80 * p.esz);         // conv kernel as the k-contiguous Bt operand [64 outputs][80 taps]
   p.w_zero = wtake(256);                      // a zero line (h_{-1} rows of the fused weight-gradient GEMM)
+  // exchange state of the weight-stationary cluster forward kernel (bf16, H = 256): per workspace, i.e. per engine
+  p.w_cluster = wtake((cfg->dtype == DJ_BF16 && (p.Ht == 256 || p.Hn == 256)) ? dj_lstm_cluster_scratch_bytes_impl() : 0);
   {                                           // fp32 scratch of the per-step path (layers with H not 128/256)
     int64_t fl = 0;
     if (!rec_persistent(p.Ht)) fl = dj_lstm_step_scratch_floats(p.Ht, p.tilesT);
@@ -204,11 +211,15 @@ inline bool fuse_xw(const LstmP& L) {
   const char* e = getenv("DEEPJ_FUSE_XW_MIN_TILES");
   const int64_t min_tiles = e ? atoll(e) : 128;
   // H = 128 in bf16 keeps U (and W up to H columns) in registers: also the 259-wide note layer 0 is cheaper fused
-#ifndef DJ_EXP_DMAX128
-#define DJ_EXP_DMAX128 288
-#endif
-  const int dmax = (L.H == 128 && L.dtype == DJ_BF16) ? DJ_EXP_DMAX128 : 2 * L.H;
+  const int dmax = (L.H == 128 && L.dtype == DJ_BF16) ? 288 : 2 * L.H;
   return rec_persistent(L.H) && L.D <= dmax && L.tiles >= min_tiles;
+}
+
+// DEEPJ_CLUSTER=0 keeps the bf16 H = 256 forward sweep on the per-tile kernel (the host side sets it after a
+// cluster fault: model.py)
+inline bool cluster_enabled() {
+  const char* e = getenv("DEEPJ_CLUSTER");
+  return !(e && e[0] == '0');
 }
 
 // Where the BPTT kernel offers it (bf16, H = 128, D <= H: U^T and W^T both stationary in registers) it also
@@ -260,29 +271,38 @@ int style_proj_all(const Ctx& c, const LstmP* Ls, const int64_t* w_sp, int n) {
 }
 
 int lstm_layer_fwd(const Ctx& c, const LstmP& L, int64_t tiles, int steps, int64_t M, int64_t wX, int64_t wWt,
-                   int64_t wUf, int64_t wZ, int64_t wH, int64_t wC, bool is_note) {
+                   int64_t wUf, int64_t wZ, int64_t wZx, int64_t wH, int64_t wC, bool is_note) {
   const int dt = c.p.c.dtype;
   if (fuse_xw(L)) {
-    // z = x W + h U + b in one persistent kernel (Z receives the pre-activation stash when training)
+    // z = x W + h U + b in one persistent kernel (Z receives the gate stash when training)
     ProfScope ps(is_note ? PC_LSTM_FWD_NOTE : PC_LSTM_FWD_TIME, c.st);
     RUN(dj_launch_lstm_fwd_fused(dt, L.H, (int)tiles, steps, c.at(wX), L.DP, dj_lstm_fused_nkx(dt, L.H, L.D), c.at(wWt),
                                  c.P + L.b, c.train ? c.at(wZ) : nullptr, c.at(wUf), c.at(wH),
-                                 c.train ? c.at(wC) : nullptr, c.p.c.recurrent_sigmoid, c.st));
+                                 c.train ? c.at(wC) : nullptr, c.p.c.recurrent_sigmoid,
+                                 cluster_enabled() ? c.at(c.p.w_cluster) : nullptr, c.st));
     return 0;
   }
-  {
-    ProfScope ps(PC_GEMM_XW, c.st);
-    RUN(dj_launch_gemm_nt(dt, (int)M, 4 * L.H, L.DP, c.at(wX), L.DP, c.at(wWt), L.DP, c.at(wZ), 4 * L.H,
-                          rec_persistent(L.H) ? 2 : 0, c.P + L.b, c.st));
-  }
-  ProfScope ps(is_note ? PC_LSTM_FWD_NOTE : PC_LSTM_FWD_TIME, c.st);
-  if (!rec_persistent(L.H)) {
+  if (!rec_persistent(L.H)) {        // per-step path: z row-major in the operand dtype, in place in the stash buffer
+    {
+      ProfScope ps(PC_GEMM_XW, c.st);
+      RUN(dj_launch_gemm_nt(dt, (int)M, 4 * L.H, L.DP, c.at(wX), L.DP, c.at(wWt), L.DP, c.at(wZ), 4 * L.H, 0, c.P + L.b,
+                            c.st));
+    }
+    ProfScope ps(is_note ? PC_LSTM_FWD_NOTE : PC_LSTM_FWD_TIME, c.st);
     RUN(dj_launch_lstm_step_fwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUf), c.at(wH),
                                 c.train ? c.at(wC) : nullptr, c.at<float>(c.p.w_step), c.p.c.recurrent_sigmoid, c.st));
     return 0;
   }
-  RUN(dj_launch_lstm_fwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUf), c.at(wH), c.train ? c.at(wC) : nullptr,
-                         c.p.c.recurrent_sigmoid, c.train ? 1 : 0, c.st));
+  // x W + b of all steps as one GEMM into the axis' dZ buffer (unused until BPTT), fragment-tiled; the sweep reads it
+  // from there and leaves the gate stash in Z
+  {
+    ProfScope ps(PC_GEMM_XW, c.st);
+    RUN(dj_launch_gemm_nt(dt, (int)M, 4 * L.H, L.DP, c.at(wX), L.DP, c.at(wWt), L.DP, c.at(wZx), 4 * L.H, 2, c.P + L.b,
+                          c.st));
+  }
+  ProfScope ps(is_note ? PC_LSTM_FWD_NOTE : PC_LSTM_FWD_TIME, c.st);
+  RUN(dj_launch_lstm_fwd(dt, L.H, (int)tiles, steps, c.at(wZx), c.train ? c.at(wZ) : nullptr, c.at(wUf), c.at(wH),
+                         c.train ? c.at(wC) : nullptr, c.p.c.recurrent_sigmoid, c.st));
   return 0;
 }
 
@@ -322,7 +342,7 @@ int time_axis_forward(const Ctx& c, const float* notes, const float* beat) {
       ProfScope ps(PC_GLUE_FWD, c.st);
       RUN(dj_launch_glue_fwd(dt, &g, c.at(p.w_H_t[l - 1]), c.at(p.w_X_t[l]), c.st));
     }
-    RUN(lstm_layer_fwd(c, L, p.tilesT, p.T, p.Mt, p.w_X_t[l], p.w_Wt_t[l], p.w_Uf_t[l], p.w_Z_t[l], p.w_H_t[l],
+    RUN(lstm_layer_fwd(c, L, p.tilesT, p.T, p.Mt, p.w_X_t[l], p.w_Wt_t[l], p.w_Uf_t[l], p.w_Z_t[l], p.w_dZ_t, p.w_H_t[l],
                        p.w_C_t[l], false));
   }
   return 0;
@@ -353,7 +373,7 @@ int note_axis_forward(const Ctx& c, int64_t wHin, int in_na, int d_out_site, con
       ProfScope ps(PC_GLUE_FWD, c.st);
       RUN(dj_launch_glue_fwd(dt, &g, c.at(p.w_H_n[l - 1]), c.at(p.w_X_n[l]), c.st));
     }
-    RUN(lstm_layer_fwd(c, L, p.tilesN, p.N, p.Mn, p.w_X_n[l], p.w_Wt_n[l], p.w_Uf_n[l], p.w_Z_n[l], p.w_H_n[l],
+    RUN(lstm_layer_fwd(c, L, p.tilesN, p.N, p.Mn, p.w_X_n[l], p.w_Wt_n[l], p.w_Uf_n[l], p.w_Z_n[l], p.w_dZ_n, p.w_H_n[l],
                        p.w_C_n[l], true));
   }
   HeadArgs h;
@@ -711,11 +731,17 @@ int32_t dj_lstm_pack_w(int32_t dtype, int32_t H, const float* W, int32_t D, void
   return dj_launch_lstm_pack_w(dtype, H, W, D, dj_lstm_fused_nkx(dtype, H, D), wpack, (hipStream_t)stream);
 }
 int32_t dj_lstm_fwd_fused(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* X, int32_t DP,
-                          int32_t D, const void* wpack, const float* bias, void* Zstash, const void* upack_fwd,
-                          void* Hout, void* Cout, int32_t sigm, void* stream) {
+                          int32_t D, const void* wpack, const float* bias, void* stash, const void* upack_fwd,
+                          void* Hout, void* Cout, int32_t sigm, void* cluster_scratch, void* stream) {
   if (D > DP) return 1232;
-  return dj_launch_lstm_fwd_fused(dtype, H, ntiles, steps, X, DP, dj_lstm_fused_nkx(dtype, H, D), wpack, bias, Zstash,
-                                  upack_fwd, Hout, Cout, sigm, (hipStream_t)stream);
+  return dj_launch_lstm_fwd_fused(dtype, H, ntiles, steps, X, DP, dj_lstm_fused_nkx(dtype, H, D), wpack, bias, stash,
+                                  upack_fwd, Hout, Cout, sigm, cluster_enabled() ? cluster_scratch : nullptr,
+                                  (hipStream_t)stream);
+}
+int64_t dj_lstm_cluster_scratch_bytes(void) { return dj_lstm_cluster_scratch_bytes_impl(); }
+int64_t dj_lstm_stash_bytes(int32_t dtype, int32_t H, int64_t rows) {
+  if ((dtype != DJ_F32 && dtype != DJ_BF16) || !rec_persistent(H) || rows < 0) return -1;
+  return rows * dj_lstm_stash_row_bytes(dtype, H);
 }
 
 // ------------------------------------------------------------------ live kernel timing
@@ -760,9 +786,9 @@ int32_t dj_gemm_tn(int32_t dtype, int64_t M, int32_t Ka, int32_t ka_valid, int32
 int32_t dj_lstm_pack(int32_t dtype, int32_t H, const float* U, void* f, void* b, void* stream) {
   return dj_launch_lstm_pack(dtype, H, U, f, b, (hipStream_t)stream);
 }
-int32_t dj_lstm_fwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, void* Z, const void* upack, void* Hout,
-                    void* Cout, int32_t sigm, void* stream) {
-  return dj_launch_lstm_fwd(dtype, H, ntiles, steps, Z, upack, Hout, Cout, sigm, 1, (hipStream_t)stream);
+int32_t dj_lstm_fwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Zx, void* stash,
+                    const void* upack, void* Hout, void* Cout, int32_t sigm, void* stream) {
+  return dj_launch_lstm_fwd(dtype, H, ntiles, steps, Zx, stash, upack, Hout, Cout, sigm, (hipStream_t)stream);
 }
 int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack,
                     const void* C, const void* dH, void* dZ, float* dbias, int32_t sigm, void* stream) {
@@ -775,7 +801,13 @@ int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, 
   return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dbias, sigm, wtpack, D, dX, DP,
                             (hipStream_t)stream);
 }
-int32_t dj_lstm_cluster_faults(void) { return dj_lstm_cluster_faults_impl(); }
+int32_t dj_lstm_cluster_faults(void* cluster_scratch) { return dj_lstm_cluster_faults_impl(cluster_scratch); }
+int32_t dj_workspace_cluster_faults(const dj_config* cfg, void* ws, int64_t ws_bytes) {
+  Plan p;
+  if (make_plan(cfg, p) || check_ws(p, ws, ws_bytes)) return -1;
+  if (!(p.c.dtype == DJ_BF16 && (p.Ht == 256 || p.Hn == 256))) return 0;
+  return dj_lstm_cluster_faults_impl((char*)ws + p.w_cluster);
+}
 int32_t dj_lstm_pack_wt(int32_t dtype, int32_t H, const float* W, int32_t D, void* out, void* stream) {
   return dj_launch_lstm_pack_wt(dtype, H, W, D, out, (hipStream_t)stream);
 }

@@ -16,6 +16,11 @@
 namespace {
 
 constexpr int GEN_MAXG = 8;
+// A Bernoulli decision u <= p is reproduced by ANY implementation whose p agrees with this one's to better than
+// |u - p|.  Draws closer than this band are counted (dj_gen_state.near_ties / draws_used[1]): a run with a count of
+// zero is certified bit-identical to every model within 1e-5 of these probabilities (the fp32 oracle is within
+// ~1e-6); a non-zero count names how many decisions depend on the last digits.
+constexpr double DJ_GEN_TIE_BAND = 1e-5;
 struct DjGenState;
 
 struct GenArgs {
@@ -42,7 +47,8 @@ struct GenArgs {
 struct DjGenState {
   int step;                       // time steps generated so far
   int draw_off;                   // uniforms consumed so far
-  int pad0, pad1;
+  int near_ties;                  // draws so far with |u - p| < DJ_GEN_TIE_BAND (precision-dependent decisions)
+  int first_near_step;            // time step of the first of them, -1 = none
   double temperature[GEN_MAXG];   // MusicGeneration.temperature (float64 like the reference)
   double default_temp[GEN_MAXG];
   int silent[GEN_MAXG];           // MusicGeneration.silent_time
@@ -123,11 +129,14 @@ __global__ __launch_bounds__(MAXT) void gen_sample_kernel(GenArgs a) {
   float* xs = zb + G * C4;                 // [G][Hn]   input of layers >= 1 (h below + style)
   float* chosen = xs + G * Hn;             // [G][4]    previous note (play, replay, volume)
   float* logit = chosen + G * 4;           // [G][4]
-  __shared__ int kdraw;
+  __shared__ int kdraw, knear;
   const int col = threadIdx.x;
   for (int i = threadIdx.x; i < 2 * a.Ln * G * Hn; i += blockDim.x) hs[i] = 0.f;
   for (int i = threadIdx.x; i < G * 4; i += blockDim.x) chosen[i] = 0.f;
-  if (threadIdx.x == 0) kdraw = a.state ? a.state->draw_off : 0;
+  if (threadIdx.x == 0) {
+    kdraw = a.state ? a.state->draw_off : 0;
+    knear = 0;
+  }
   float* out_notes = a.state ? a.results + (int64_t)a.state->step * G * a.N * 3 : a.next_notes;
   __syncthreads();
 
@@ -200,10 +209,14 @@ __global__ __launch_bounds__(MAXT) void gen_sample_kernel(GenArgs a) {
           pr = 1.0f / (1.0f + expf(-x1 / temp));
         }
         float play = 0.f, rep = 0.f, v = 0.f;
-        if (a.uniforms[k++] <= (double)pp) {
+        const double u0 = a.uniforms[k++];
+        knear += fabs(u0 - (double)pp) < DJ_GEN_TIE_BAND;
+        if (u0 <= (double)pp) {
           play = 1.f;
           v = vol;
-          if (a.uniforms[k++] <= (double)pr) rep = 1.f;
+          const double u1 = a.uniforms[k++];
+          knear += fabs(u1 - (double)pr) < DJ_GEN_TIE_BAND;
+          if (u1 <= (double)pr) rep = 1.f;
         }
         chosen[g * 4] = play;
         chosen[g * 4 + 1] = rep;
@@ -218,10 +231,14 @@ __global__ __launch_bounds__(MAXT) void gen_sample_kernel(GenArgs a) {
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    if (a.state)
+    if (a.state) {
       a.state->draw_off = kdraw;
-    else
-      *a.draws_used = kdraw;
+      if (knear && a.state->near_ties == 0) a.state->first_near_step = a.state->step;
+      a.state->near_ties += knear;
+    } else {
+      a.draws_used[0] = kdraw;
+      a.draws_used[1] = knear;
+    }
   }
 }
 

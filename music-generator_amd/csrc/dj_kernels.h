@@ -75,8 +75,11 @@ int dj_launch_lstm_wgrad(int dtype, int64_t M, int steps, const void* X, int DP,
                          const void* dZ, int N, float* dW, float* dU, const void* zeros, hipStream_t st);
 // dj_lstm.hip
 int dj_launch_lstm_pack(int dtype, int H, const float* U, void* fwd, void* bwd, hipStream_t st);
-int dj_launch_lstm_fwd(int dtype, int H, int ntiles, int steps, void* Z, const void* Upack, void* Hout, void* Cout,
-                       int sigm, int store_z, hipStream_t st);
+// Zx: x W + b of all steps (fragment-tiled, operand dtype); Gst: gate stash out (null = inference; fp32 may alias Zx)
+int dj_launch_lstm_fwd(int dtype, int H, int ntiles, int steps, const void* Zx, void* Gst, const void* Upack, void* Hout,
+                       void* Cout, int sigm, hipStream_t st);
+// gate stash bytes per row of a layer with H units: fp32 keeps z (16 H), bf16 the activated gates as 8-bit codes (4 H)
+int64_t dj_lstm_stash_row_bytes(int dtype, int H);
 // WTpack/D/dX/DP: optional fused input gradient dX = dz W^T (WTpack from dj_launch_lstm_pack_wt; null = off;
 // available where dj_lstm_bwd_has_dx says so)
 int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* UTpack, const void* C,
@@ -86,11 +89,15 @@ int dj_lstm_bwd_has_dx(int dtype, int H, int D);
 int dj_launch_lstm_pack_wt(int dtype, int H, const float* W, int D, void* out, hipStream_t st);
 int dj_lstm_fused_nkx(int dtype, int H, int D);
 int dj_launch_lstm_pack_w(int dtype, int H, const float* W, int D, int NKX, void* out, hipStream_t st);
+// cluster_scratch: dj_lstm_cluster_scratch_bytes_impl() bytes, 128-byte aligned, owned by the caller's workspace
+// (null = per-tile kernel only)
 int dj_launch_lstm_fwd_fused(int dtype, int H, int ntiles, int steps, const void* X, int DP, int NKX,
                              const void* Wpack, const float* bias, void* Zst, const void* Upack, void* Hout,
-                             void* Cout, int sigm, hipStream_t st);
-// expired cluster waits since the last call (0 in a healthy run; the affected tiles carry NaN), -1 on a HIP error
-int dj_lstm_cluster_faults_impl();
+                             void* Cout, int sigm, void* cluster_scratch, hipStream_t st);
+int64_t dj_lstm_cluster_scratch_bytes_impl();
+// expired waits + misplaced clusters recorded in that scratch since the last call (0 in a healthy run; the affected
+// tiles carry NaN), -1 on a HIP error; synchronises
+int dj_lstm_cluster_faults_impl(void* cluster_scratch);
 // dj_step.hip -- generic-H path (one GEMM + gate launch per recurrence step)
 int64_t dj_lstm_step_scratch_floats(int H, int64_t ntiles);
 int dj_launch_lstm_step_fwd(int dtype, int H, int ntiles, int steps, void* Z, const void* Ut, void* Hs, void* Cs,

@@ -30,13 +30,14 @@
 // compile-time constant (run-time variants of the same loops measured +0.4 ... +0.5 ms).
 //
 // Data layouts in HBM:
-//  * Z  (x_t W + b in, pre-activations z_t out, in place) and the cell stash C are
+//  * Zx (x_t W + b of the unfused path), the gate stash and the cell stash C are
 //    FRAGMENT-TILED: for 32-row block rb (= tile*steps + step) and 32-col block cb,
 //    the 32x32 block is stored as [lane 0..63][16 accumulator registers], i.e.
 //    element (s, c) of the block sits at ((rb*NCB + cb)*64 + 32*((s>>2)&1) + c)*16
 //    + (s&3) + 4*(s>>3).  dj_gemm_nt writes this layout from its accumulators, and
 //    both recurrent kernels read/write it with 16-byte per-lane accesses that are
-//    perfectly coalesced -- no scalar loads, no partial-line writes.
+//    perfectly coalesced -- no scalar loads, no partial-line writes.  The gate stash
+//    holds z in fp32 mode and 8-bit activated gates in bf16 mode ("gate stash" below).
 //  * h (Hout), dH and dz are ROW-MAJOR [rows, cols] (they feed the GEMMs and the
 //    glue kernels) and go through LDS for wide coalesced rows.
 #include <stdlib.h>
@@ -45,16 +46,6 @@
 
 #include "dj_kernels.h"
 
-#ifdef DJ_EXP_STAMP
-__device__ unsigned long long dj_stamps[2][8][1024];   // [kernel fwd/bwd][phase][step]
-#ifndef DJ_EXP_STAMP_H
-#define DJ_EXP_STAMP_H 256
-#endif
-#define DJ_STAMP(K, P, T) do { if (H == DJ_EXP_STAMP_H && blockIdx.x == 17 && threadIdx.x == 0) dj_stamps[K][P][T] = __builtin_readcyclecounter(); } while (0)
-extern "C" int dj_debug_stamps(void* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dj_stamps), sizeof(dj_stamps)); }
-#else
-#define DJ_STAMP(K, P, T)
-#endif
 namespace {
 
 template <typename T, int H> struct RecCfg {
@@ -71,32 +62,20 @@ template <typename T, int H> struct RecCfg {
   static constexpr int NCB = 4 * H / 32;  // 32-col blocks of Z
   static constexpr int NCBH = H / 32;     // 32-col blocks of C
   static constexpr int VPT = 16 / EPL;    // 16-byte vectors per 16-register fragment (bf16: 2, f32: 4)
-#ifndef DJ_EXP_PD128
-#define DJ_EXP_PD128 4
-#endif
   // weight-fragment prefetch depth in k-chunks (H = 128 runs one wave per SIMD: registers to spare)
-  static constexpr int PD = sizeof(T) == 2 ? (H == 128 ? DJ_EXP_PD128 : 4) : 2;
+  static constexpr int PD = sizeof(T) == 2 ? 4 : 2;
   static constexpr int UNR = PD > 4 ? PD : 4;   // k-chunks per unrolled body (multiple of PD)
   // BPTT product: one MFMA per k-chunk and wave, so the ring must be deeper to cover L2 latency
   // (measured: PD 2 left the 64-iteration loop latency-bound at 9.3 us/step)
-#ifndef DJ_EXP_PDB128
-#define DJ_EXP_PDB128 8
-#endif
-  static constexpr int PDB = sizeof(T) == 2 ? (H == 128 ? DJ_EXP_PDB128 : 8) : 4;
+  static constexpr int PDB = sizeof(T) == 2 ? 8 : 4;
   static constexpr int UNRB = PDB > 8 ? PDB : 8;
   static constexpr bool HOIST = sizeof(T) == 2;   // prefetch Z fragments a step ahead (register budget)
-#ifndef DJ_EXP_STATB
-#define DJ_EXP_STATB 1
-#endif
   // H = 128 in bf16: a wave's whole U^T slice (4H x 32 units = 32 KB = 128 registers per lane) stays in
   // registers for the whole BPTT sweep -- one wave per SIMD has the register file for it -- so the
   // recurrence streams no weights at all
-  static constexpr bool STATB = sizeof(T) == 2 && H == 128 && DJ_EXP_STATB;
-#ifndef DJ_EXP_STATF
-#define DJ_EXP_STATF 1
-#endif
+  static constexpr bool STATB = sizeof(T) == 2 && H == 128;
   // same for the forward kernels: U (and W when the input is at most 128 wide) as 128 registers each
-  static constexpr bool STATF = sizeof(T) == 2 && H == 128 && DJ_EXP_STATF;
+  static constexpr bool STATF = sizeof(T) == 2 && H == 128;
 };
 
 // raw workgroup barrier: waits for this wave's LDS traffic only, so global prefetches
@@ -146,6 +125,83 @@ template <> struct Frag16<bf16_t> {
     v[1] = o.v[1];
   }
 };
+// ---------------------------------------------------------------- gate stash
+// What the forward sweep leaves for BPTT, per 32x32 block (rows x hidden units) and gate, fragment-tiled like the
+// MFMA accumulators ([64 lanes][16 values]; block (rb, cb) at element ((rb*NCB + cb)*64 + lane)*16):
+//   fp32 mode : the pre-activations z (16 floats per lane) -- BPTT recomputes the activations, exact;
+//   bf16 mode : the ACTIVATED gates as 8-bit codes (16 bytes per lane, half of a bf16 z stash: the recurrent
+//               kernels are HBM-bound on exactly these bytes, and BPTT no longer recomputes 4 transcendentals per
+//               element).  i, f, o in [0,1]: code = clamp(ceil(254 y), 0, 255), decoded as the interval midpoint
+//               (code - 1/2)/254 clamped to [0,1] (|error| <= 1/508); codes 0 and 255 are reserved for the
+//               SATURATED hard_sigmoid, so its derivative mask (0.2 inside, 0 outside) is exact.  g = tanh in
+//               (-1,1): code = round(127 g) + 128 (|error| <= 1/254).  The forward values themselves are not
+//               quantised -- only what BPTT reads back.
+template <typename T> struct StashT { using type = float; };
+template <> struct StashT<bf16_t> { using type = uint8_t; };
+template <typename T> using StashElem = typename StashT<T>::type;
+
+template <typename T, bool SIGM> struct GateEnc;
+template <bool SIGM> struct GateEnc<float, SIGM> {
+  static constexpr int STORES = 4;             // 16-byte stores per gate block and lane
+  float z[4][16];
+  __device__ __forceinline__ void put(int r, float zi, float zf, float zg, float zo, float, float, float, float) {
+    z[0][r] = zi; z[1][r] = zf; z[2][r] = zg; z[3][r] = zo;
+  }
+  __device__ __forceinline__ void store(int g, float* p) const { store_frag(p, z[g]); }
+};
+template <bool SIGM> struct GateEnc<bf16_t, SIGM> {
+  static constexpr int STORES = 1;
+  uint32_t w[4][4] = {};
+  static __device__ __forceinline__ float code01(float z, float y) {
+    if constexpr (SIGM) return ceilf(y * 254.f);                                          // y in [0,1]
+    return ceilf(__builtin_amdgcn_fmed3f(fmaf(z, 50.8f, 127.f), 0.f, 255.f));              // 254 (0.2 z + 0.5)
+  }
+  __device__ __forceinline__ void put(int r, float zi, float zf, float, float zo, float ig, float fg, float gg,
+                                      float og) {
+    const int d = r >> 2, b = r & 3;
+    w[0][d] = __builtin_amdgcn_cvt_pk_u8_f32(code01(zi, ig), b, w[0][d]);
+    w[1][d] = __builtin_amdgcn_cvt_pk_u8_f32(code01(zf, fg), b, w[1][d]);
+    w[2][d] = __builtin_amdgcn_cvt_pk_u8_f32(floorf(fmaf(gg, 127.f, 128.5f)), b, w[2][d]);
+    w[3][d] = __builtin_amdgcn_cvt_pk_u8_f32(code01(zo, og), b, w[3][d]);
+  }
+  __device__ __forceinline__ void store(int g, uint8_t* p) const { *(uint4*)p = make_uint4(w[g][0], w[g][1], w[g][2], w[g][3]); }
+};
+
+// the BPTT side: gate values and the derivative factors of the recurrent activation for accumulator register r
+template <typename T, bool SIGM> struct GateDec;
+template <bool SIGM> struct GateDec<float, SIGM> {
+  Frag16<float> z[4];
+  __device__ __forceinline__ void load(int g, const float* p) { z[g].load(p); }
+  __device__ __forceinline__ void get(int r, float& ig, float& fg, float& gg, float& og, float& di, float& df,
+                                      float& dO) const {
+    const float zi = z[0].get(r), zf = z[1].get(r), zg = z[2].get(r), zo = z[3].get(r);
+    ig = dj_ract<SIGM>(zi); fg = dj_ract<SIGM>(zf); gg = dj_tanh(zg); og = dj_ract<SIGM>(zo);
+    di = dj_ract_grad<SIGM>(zi, ig); df = dj_ract_grad<SIGM>(zf, fg); dO = dj_ract_grad<SIGM>(zo, og);
+  }
+};
+template <bool SIGM> struct GateDec<bf16_t, SIGM> {
+  uint4 q[4];
+  __device__ __forceinline__ void load(int g, const uint8_t* p) { q[g] = *(const uint4*)p; }
+  static __device__ __forceinline__ float code(const uint4& v, int r) {
+    const int d = r >> 2;
+    const uint32_t w = d == 0 ? v.x : d == 1 ? v.y : d == 2 ? v.z : v.w;
+    return (float)((w >> (8 * (r & 3))) & 0xFFu);                  // v_cvt_f32_ubyteN
+  }
+  static __device__ __forceinline__ void dec01(float cd, float& y, float& dy) {
+    const float v = fmaf(cd, 1.f / 254.f, -0.5f / 254.f);
+    y = __builtin_amdgcn_fmed3f(v, 0.f, 1.f);
+    if constexpr (SIGM) dy = y * (1.f - y);
+    else dy = (v > 0.f && v < 1.f) ? 0.2f : 0.f;                   // codes 1..254: inside the linear part
+  }
+  __device__ __forceinline__ void get(int r, float& ig, float& fg, float& gg, float& og, float& di, float& df,
+                                      float& dO) const {
+    dec01(code(q[0], r), ig, di);
+    dec01(code(q[1], r), fg, df);
+    gg = fmaf(code(q[2], r), 1.f / 127.f, -128.f / 127.f);
+    dec01(code(q[3], r), og, dO);
+  }
+};
+
 // ---------------------------------------------------------------- weight packing
 // Upack[(((w*4+g)*NJ+j)*NKC + kc)*64 + lane][e] = U[kc*KC + EPL*h + e][g*H + w*UW + j*32 + l31]
 template <typename T, int H>
@@ -193,10 +249,12 @@ __global__ void pack_wt_bwd_kernel(const float* __restrict__ W, int D, int NQ, T
 }
 
 // ---------------------------------------------------------------- forward
+// Zx: x_t W + b of every step, fragment-tiled in T (dj_gemm_nt c_mode 2); Gst: gate stash out (null = inference;
+// in fp32 it may alias Zx: a lane rewrites exactly the fragments it has read).
 template <typename T, int H, bool SIGM>
-__global__ __launch_bounds__(2 * H) void lstm_fwd_kernel(T* __restrict__ Z, const T* __restrict__ Upack,
-                                                       T* __restrict__ Hout, T* __restrict__ Cout, int steps,
-                                                       int store_z) {
+__global__ __launch_bounds__(2 * H) void lstm_fwd_kernel(const T* Zx, StashElem<T>* Gst,
+                                                       const T* __restrict__ Upack, T* __restrict__ Hout,
+                                                       T* __restrict__ Cout, int steps) {
   using R = RecCfg<T, H>;
   using Frag = typename DjFrag<T>::type;
   __shared__ __attribute__((aligned(16))) T hs[2][32 * R::LDH];
@@ -211,9 +269,10 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_kernel(T* __restrict__ Z, cons
 
   const Frag* up = (const Frag*)Upack + (int64_t)w * 4 * R::NJ * R::NKC * 64 + lane;
   // fragment addresses of this lane: Z block (g, j) and C block j of row-block rb
-  auto zaddr = [&](int64_t rb, int g, int j) {
-    return Z + ((rb * R::NCB + (g * H + w * R::UW + j * 32) / 32) * 64 + lane) * 16;
+  auto zoff = [&](int64_t rb, int g, int j) {
+    return ((rb * R::NCB + (g * H + w * R::UW + j * 32) / 32) * 64 + lane) * 16;
   };
+  auto zaddr = [&](int64_t rb, int g, int j) { return Zx + zoff(rb, g, j); };
   auto caddr = [&](int64_t rb, int j) { return Cout + ((rb * R::NCBH + (w * R::UW + j * 32) / 32) * 64 + lane) * 16; };
 
   Frag uf[R::STATF ? R::NKC : 1][4];
@@ -293,25 +352,22 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_kernel(T* __restrict__ Z, cons
     for (int j = 0; j < R::NJ; ++j) {
       const int u = w * R::UW + j * 32 + l31;
       float cv[16];
+      GateEnc<T, SIGM> ge;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = dj_crow(r, lane);
         float zi = acc[0][j][r], zf = acc[1][j][r], zg = acc[2][j][r], zo = acc[3][j][r];
         float ig = dj_ract<SIGM>(zi), fg = dj_ract<SIGM>(zf), gg = dj_tanh(zg), og = dj_ract<SIGM>(zo);
+        ge.put(r, zi, zf, zg, zo, ig, fg, gg, og);
         float cn = fg * c[j][r] + ig * gg;
         c[j][r] = cn;
         cv[r] = cn;
         hn[row * R::LDH + u] = dj_from_f32<T>(og * dj_tanh(cn));
       }
       if (Cout) store_frag(caddr(rb, j), cv);
-      if (store_z) {
+      if (Gst) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float zv[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) zv[r] = acc[g][j][r];
-          store_frag(zaddr(rb, g, j), zv);
-        }
+        for (int g = 0; g < 4; ++g) ge.store(g, Gst + zoff(rb, g, j));
       }
     }
     lds_barrier();
@@ -353,7 +409,8 @@ constexpr int FUSED_DPMAX = 288;   // widest layer input supported by the regist
 template <typename T, int H, bool SIGM, bool WSTAT, bool WLDS>
 __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restrict__ X, int DP, int NKX,
                                                                const T* __restrict__ Wpack,
-                                                               const float* __restrict__ bias, T* __restrict__ Zst,
+                                                               const float* __restrict__ bias,
+                                                               StashElem<T>* __restrict__ Zst,
                                                                const T* __restrict__ Upack, T* __restrict__ Hout,
                                                                T* __restrict__ Cout, int steps) {
   using R = RecCfg<T, H>;
@@ -433,7 +490,6 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
   for (int t = 0; t < steps; ++t) {
     const int64_t rb = tile * steps + t;
     const T* xs = xs0 + (t & 1) * 32 * LDX;
-    DJ_STAMP(0, 0, t);
     f32x16 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -510,44 +566,35 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
         }
       }
     }
-    DJ_STAMP(0, 1, t);
     // next X tile: issued after the weight streams of this step (in-order vmcnt), lands under the gate math
     xr = x_load(t + 1 < steps ? rb + 1 : rb);
     T* hn = hs0 + (cur ^ 1) * 32 * R::LDH;
     const int u = w * R::UW + l31;
     float cv[16];
+    GateEnc<T, SIGM> ge;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float zi = acc[0][r], zf = acc[1][r], zg = acc[2][r], zo = acc[3][r];
       const float ig = dj_ract<SIGM>(zi), fg = dj_ract<SIGM>(zf), gg = dj_tanh(zg), og = dj_ract<SIGM>(zo);
+      ge.put(r, zi, zf, zg, zo, ig, fg, gg, og);
       const float cn = fg * c[r] + ig * gg;
       c[r] = cn;
       cv[r] = cn;
       hn[dj_crow(r, lane) * R::LDH + u] = dj_from_f32<T>(og * dj_tanh(cn));
     }
-    DJ_STAMP(0, 2, t);
     if (Cout) store_frag(caddr(rb), cv);
     if (Zst) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float zv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) zv[r] = acc[g][r];
-        store_frag(zaddr(rb, g), zv);
-      }
+      for (int g = 0; g < 4; ++g) ge.store(g, zaddr(rb, g));
     }
-    DJ_STAMP(0, 3, t);
     if (t + 1 < steps) x_store(xs0 + ((t + 1) & 1) * 32 * LDX, xr);
-    DJ_STAMP(0, 4, t);
     lds_barrier();
-    DJ_STAMP(0, 5, t);
     constexpr int VPR = H / R::EPL;
 #pragma unroll
     for (int v = tid; v < 32 * VPR; v += R::NT) {
       int row = v / VPR, cvv = (v % VPR) * R::EPL;
       *(uint4*)(Hout + (rb * 32 + row) * H + cvv) = *(const uint4*)(hn + row * R::LDH + cvv);
     }
-    DJ_STAMP(0, 6, t);
     cur ^= 1;
   }
 }
@@ -565,39 +612,31 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
 //  * x rows are fetched as full 128-byte lines (8 lanes per row) and turned into A fragments through a 4 KiB
 //    LDS tile per wave, 64 columns per round (fragments read straight from the rows are 32 segments of 32 bytes
 //    per instruction).
-//  * h travels in the MFMA A-fragment image (dj_cluster_hx below), one contiguous 1 KiB load per fragment.
-//  * x_{t+1} is requested during step t, behind the h fragments (loads return in order: in front of them it would
-//    hold the h fragments back); with spilled registers the same idea is a loss.
-// Coherence: members of a cluster run on ONE XCD (round-robin workgroup dispatch, any power-of-two XCD count),
-// whose L2 is the coherence point for their h slices -- stores are acknowledged (vmcnt 0) before the counter is
-// bumped, the exchange loads bypass L1 (sc1).  The wait is bounded: an expired wait (grid not co-resident)
-// poisons the tile's cell state with NaN and is counted (dj_lstm_cluster_faults), never a silent wrong answer
-// and never a hung device; the launcher only uses this kernel when the device has a compute unit per workgroup.
-// where x is requested: 1 (default) = one step ahead, the first half of x_{t+1} right behind the
-// h fragments of step t, the second half once the h product has freed their registers (2.92 ms per training step for
-// the two time-axis layers); 0 = at the start of its own step (2.98); 3 = all of it behind the h fragments (3.00);
-// 2 = a step ahead, before the barrier (slower); 4 = as 1 with the second half of x_t W moved under the h fragments'
-// latency (2.97).  Only without register spills: the step must be unconditional
-// (round 0 of the exchange carries h = 0), a conditional h product costs a second set of accumulators.
-#ifndef DJ_EXP_CL_XAHEAD
-#define DJ_EXP_CL_XAHEAD 1
-#endif
-// experiment switch: 1 = the two halves of a workgroup (waves 0-3 / 4-7) run half a step apart, each with its own
-// cluster counter fed by one atomic per wave, and never meet in a workgroup barrier (tools/memlat.hip: the same
-// memory pattern is 11-20 % faster when the halves alternate between memory and arithmetic)
-#ifndef DJ_EXP_CL_GROUPS
-#define DJ_EXP_CL_GROUPS 0
-#endif
+//  * h travels in the MFMA A-fragment image (the hx region of the scratch), one contiguous 1 KiB load per fragment.
+//  * x_{t+1} is requested during step t: the first half right behind the h fragments (loads return in order: in
+//    front of them it would hold the h fragments back), the second half once the h product has freed their
+//    registers.  Only without register spills: the step must be unconditional (round 0 of the exchange carries
+//    h = 0), a conditional h product costs a second set of accumulators.  (DESIGN.md section 8 has the variants.)
+// Exchange state lives in a CALLER-OWNED scratch (dj_lstm_cluster_scratch_bytes; one per workspace, i.e. per
+// engine / stream -- never shared between concurrent sweeps):
+//     [0, 16 KiB)     per cluster two 128-byte lines: line 0 = the step counter, line 1 = the members' XCC ids
+//                     (zeroed by a memset node in front of every launch)
+//     [16 KiB, +128)  fault words: [0] expired waits, [1] clusters whose members sat on different XCDs (sticky
+//                     until dj_lstm_cluster_faults reads them)
+//     [.., +8 MiB)    hx: [tile][step parity][k-chunk][lane] x 16 bytes
+// Coherence: the members of a cluster must run on ONE XCD, whose L2 is then the coherence point for their h slices
+// (stores acknowledged before the counter moves, exchange loads bypass L1 with sc1).  Round-robin dispatch puts
+// blocks b and b + 8 on one XCD; HIP does not promise it, so it is VERIFIED per launch: every member publishes its
+// hardware XCC id in round 0 and every wave compares the eight of its cluster.  A mismatch, like an expired wait
+// (grid not co-resident), poisons the tile's cell state with NaN and is counted -- never a silent wrong answer,
+// never a hung device; the host side re-runs the step with the per-tile kernel (model.py) or fails (bench.py).
 // one 128-byte line per counter: counters of clusters on different XCDs must not share a line
 constexpr int CL_CNT_STRIDE = 32;
-__device__ int dj_cluster_cnt[64 * 2 * CL_CNT_STRIDE];
-__device__ int dj_cluster_fault;              // expired waits since the last dj_cluster_faults()
-constexpr int CL_M = 8;                      // members (= tiles) per cluster
-// h exchange in the exact MFMA A-fragment image: [tile][step parity][kc][lane] x 16 bytes, so a consumer wave
-// fetches a fragment as ONE contiguous 1 KiB load (row-major h rows would be 32 segments of 32 bytes per
-// fragment: measured 13 k cycles per 16 fragments) and a producer stores its two chunks the same way.  The two
-// parities are reused every other step, so the consumer loads bypass the (non-coherent) L1 with sc1.
-__device__ uint4 dj_cluster_hx[256 * 2 * 16 * 64];
+constexpr int CL_M = 8;                       // members (= tiles) per cluster
+constexpr int CL_CNT_INTS = 64 * 2 * CL_CNT_STRIDE;
+constexpr size_t CL_OFF_FAULT = (size_t)CL_CNT_INTS * sizeof(int);
+constexpr size_t CL_OFF_HX = CL_OFF_FAULT + 128;
+constexpr size_t CL_BYTES = CL_OFF_HX + (size_t)256 * 2 * 16 * 64 * 16;
 __device__ __forceinline__ uint4 ld_sc1(const uint4* p) {
   uint4 v;
   asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
@@ -617,14 +656,25 @@ __device__ __forceinline__ void cl_load_x(ClXRegs<NR>& q, const bf16_t* xb, int 
       q.v[r][i] = ok ? v : make_uint4(0, 0, 0, 0);
     }
 }
+// bounded wait of one wave for its cluster's counter (lane 0 polls); false = expired
+__device__ __forceinline__ bool cl_wait(int* cnt, int target, int lane) {
+  int ok = 1;
+  if (lane == 0) {
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    while ((ok = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) == 0 &&
+           __builtin_readcyclecounter() - t0 < 20000000ull)       // ~10 ms: hang protection only
+      __builtin_amdgcn_s_sleep(2);
+  }
+  return __builtin_amdgcn_readfirstlane(ok) != 0;
+}
 template <bool SIGM, int NKX>
 __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __restrict__ X, int DP,
                                                                const bf16_t* __restrict__ Wpack,
                                                                const float* __restrict__ bias,
-                                                               bf16_t* __restrict__ Zst,
+                                                               StashElem<bf16_t>* __restrict__ Zst,
                                                                const bf16_t* __restrict__ Upack,
                                                                bf16_t* __restrict__ Hout, bf16_t* __restrict__ Cout,
-                                                               int steps) {
+                                                               int steps, int* __restrict__ cl) {
   using T = bf16_t;
   constexpr int H = 256;
   using R = RecCfg<T, H>;
@@ -637,13 +687,11 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, s = j & (CL_M - 1);
   const int cid = xcd + 8 * (j >> 3);                      // cluster id; its tiles are CL_M*cid .. CL_M*cid+7
   const int64_t tile = (int64_t)CL_M * cid + w;            // this wave's tile
-#if DJ_EXP_CL_GROUPS
-  int* cnt = dj_cluster_cnt + (2 * cid + (w >> 2)) * CL_CNT_STRIDE;
-  constexpr int ARRIVALS = 4 * CL_M;          // one per wave of the half, from every member
-#else
-  int* cnt = dj_cluster_cnt + 2 * cid * CL_CNT_STRIDE;
+  int* cnt = cl + 2 * cid * CL_CNT_STRIDE;
+  int* xccs = cnt + CL_CNT_STRIDE;
+  int* fault = cl + CL_CNT_INTS;
+  uint4* hxb = (uint4*)((unsigned char*)cl + CL_OFF_HX);
   constexpr int ARRIVALS = CL_M;
-#endif
 
   // stationary operand slices -> LDS (contiguous in the packed streams)
   {
@@ -659,27 +707,31 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
 #pragma unroll
   for (int g = 0; g < 4; ++g) bv[g] = bias[g * H + s * 32 + l31];
   // round 0 of the exchange: h_{-1} = 0 goes into the parity-1 slots like any h_t, so that step 0 is a step like the
-  // others (a conditional h product costs a second set of accumulators: 64 registers)
+  // others (a conditional h product costs a second set of accumulators: 64 registers); with it every member
+  // publishes the XCD it runs on
+  const int my_xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15) + 1;   // HW_REG_XCC_ID[3:0]
   {
-    uint4* hxo = dj_cluster_hx + ((tile * 2 + 1) * 16 + 2 * s) * 64 + lane;
+    uint4* hxo = hxb + ((tile * 2 + 1) * 16 + 2 * s) * 64 + lane;
     hxo[0] = make_uint4(0, 0, 0, 0);
     hxo[64] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) __hip_atomic_store(xccs + s, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if DJ_EXP_CL_GROUPS
-  __syncthreads();
-  if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
   __syncthreads();
   if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-
-#if DJ_EXP_CL_GROUPS
-  if (w >> 2) {
-    const unsigned long long t00 = __builtin_readcyclecounter();
-    while (__builtin_readcyclecounter() - t00 < 14000ull) __builtin_amdgcn_s_sleep(8);      // about half a step
+  // placement check: once all members have arrived, their XCC ids must be this workgroup's own
+  {
+    bool ok = cl_wait(cnt, ARRIVALS, lane);
+    int other = my_xcc;
+    if (ok && lane < CL_M) other = __hip_atomic_load(xccs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool same = __all(other == my_xcc);
+    if (!ok || !same) {
+      if (lane == 0 && w == 0) atomicAdd(fault + (ok ? 1 : 0), 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[r] = __builtin_nanf("");
+    }
   }
-#endif
+
   unsigned char* xs = (unsigned char*)hto + w * 4096;      // this wave's 4 KiB tile: x rounds, then the h tile
   T* ht = (T*)xs;
   // x rows are fetched as full 128-byte lines, 8 lanes per row (fragments read straight from the rows would be
@@ -688,12 +740,9 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
   const int xr8 = lane >> 3, xc = lane & 7;
   constexpr int NR = (NKX + 3) / 4, NRA = (NR + 1) / 2;   // rounds; those requested with the h fragments
   ClXRegs<NR> xq;
-#if DJ_EXP_CL_XAHEAD
   cl_load_x<NR, 0, NR>(xq, X + (tile * steps * 32 + xr8) * DP + xc * 8, DP, xc);
-#endif
   for (int t = 0; t < steps; ++t) {
     const int64_t rb = tile * steps + t;
-    DJ_STAMP(0, 0, t);
     f32x16 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -701,108 +750,71 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
       for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;   // bias joins in the cell update (a hoisted splat would spill)
     // ---- x_t W: independent of the exchange, so it runs before the wait; x_t (requested during the previous step) is
     // turned into A fragments through this wave's 4 KiB LDS tile, 64 columns per round.
-    {
-#if !DJ_EXP_CL_XAHEAD
-      cl_load_x<NR, 0, NR>(xq, X + (rb * 32 + xr8) * DP + xc * 8, DP, xc);
-#endif
-#define DJ_CL_X_ROUNDS(R0, R1)                                                                            \
-  _Pragma("unroll") for (int r = (R0); r < (R1); ++r) {                                                   \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                         \
-        *(uint4*)(xs + (xr8 + 8 * i) * 128 + ((xc ^ xr8) << 4)) = xq.v[r][i];                             \
-    __builtin_amdgcn_wave_barrier();                                                                      \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                       \
-      const int kc = 4 * r + q;                                                                           \
-      if (kc < NKX) {                                                                                     \
-        const Frag a = *(const Frag*)(xs + l31 * 128 + (((2 * q + h) ^ (l31 & 7)) << 4));                 \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) dj_mfma(acc[g], a, Bw[(g * NKX + kc) * 64 + lane]); \
-      }                                                                                                   \
-    }                                                                                                     \
-    __builtin_amdgcn_wave_barrier();                                                                      \
-  }
-#if DJ_EXP_CL_XAHEAD == 4
-      DJ_CL_X_ROUNDS(0, NRA)      // the rest runs while the h fragments travel (below)
-#else
-      DJ_CL_X_ROUNDS(0, NR)
-#endif
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *(uint4*)(xs + (xr8 + 8 * i) * 128 + ((xc ^ xr8) << 4)) = xq.v[r][i];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kc = 4 * r + q;
+        if (kc < NKX) {
+          const Frag a = *(const Frag*)(xs + l31 * 128 + (((2 * q + h) ^ (l31 & 7)) << 4));
+#pragma unroll
+          for (int g = 0; g < 4; ++g) dj_mfma(acc[g], a, Bw[(g * NKX + kc) * 64 + lane]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    DJ_STAMP(0, 1, t);
-#if DJ_EXP_CL_XAHEAD
     const T* xnext = X + ((tile * steps + (t + 1 < steps ? t + 1 : t)) * 32 + xr8) * DP + xc * 8;
-#endif
     // ---- h_{t-1} U: needs the slices of all members
     {
-      int ok = 1;
-      if (lane == 0) {
-        const int target = ARRIVALS * (t + 1);
-        const unsigned long long t0 = __builtin_readcyclecounter();
-        while ((ok = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) == 0 &&
-               __builtin_readcyclecounter() - t0 < 20000000ull)       // ~10 ms: hang protection only
-          __builtin_amdgcn_s_sleep(2);
-      }
-      if (!__builtin_amdgcn_readfirstlane(ok)) {
+      if (!cl_wait(cnt, ARRIVALS * (t + 1), lane)) {
         // a member never arrived (grid not co-resident): never a silent wrong answer -- count it and poison the
         // cell state, so every later h of this tile, and the loss, is NaN
-        if (lane == 0) atomicAdd(&dj_cluster_fault, 1);
+        if (lane == 0) atomicAdd(fault, 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = __builtin_nanf("");
       }
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
-      DJ_STAMP(0, 2, t);
-      const uint4* hx = dj_cluster_hx + ((tile * 2 + ((t + 1) & 1)) * 16) * 64 + lane;
+      const uint4* hx = hxb + ((tile * 2 + ((t + 1) & 1)) * 16) * 64 + lane;
       uint4 ah[R::NKC];
 #pragma unroll
       for (int kc = 0; kc < R::NKC; ++kc) ah[kc] = ld_sc1(hx + kc * 64);
       asm volatile("" ::: "memory");
-#if DJ_EXP_CL_XAHEAD == 4
-      cl_load_x<NR, 0, NRA>(xq, xnext, DP, xc);     // first half of x_{t+1}, into the registers rounds 0..NRA-1 freed
-      DJ_CL_X_ROUNDS(NRA, NR)                       // second half of x_t W under the h fragments' latency
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NRA) : "memory");
-#elif DJ_EXP_CL_XAHEAD == 3
-      cl_load_x<NR, 0, NR>(xq, xnext, DP, xc);      // all of x_{t+1} right behind the h fragments
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NR) : "memory");
-#elif DJ_EXP_CL_XAHEAD == 1
-      // the first rounds of x_{t+1} go out right behind the h fragments (loads return in order: in front they
-      // would hold the h fragments back), always 4*NRA requests, so the wait below is a constant
+      // the first rounds of x_{t+1} go out right behind the h fragments, always 4*NRA requests, so the wait below
+      // is a constant
       cl_load_x<NR, 0, NRA>(xq, xnext, DP, xc);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NRA) : "memory");
-#else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
 #pragma unroll
       for (int kc = 0; kc < R::NKC; ++kc) {
         Frag a;
         __builtin_memcpy(&a, &ah[kc], 16);
 #pragma unroll
         for (int g = 0; g < 4; ++g) dj_mfma(acc[g], a, Bu[(g * R::NKC + kc) * 64 + lane]);
-#if DJ_EXP_CL_SCHED
-        __builtin_amdgcn_sched_barrier(0);
-#endif
       }
     }
-#if DJ_EXP_CL_XAHEAD == 1 || DJ_EXP_CL_XAHEAD == 4
     cl_load_x<NR, NRA, NR>(xq, xnext, DP, xc);   // the rest once the h fragments' registers are free
-#endif
-    DJ_STAMP(0, 3, t);
     // ---- cell update (lane-local), stash, h slice out
     float cv[16];
+    GateEnc<T, SIGM> ge;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float zi = (acc[0][r] += bv[0]), zf = (acc[1][r] += bv[1]), zg = (acc[2][r] += bv[2]),
-                  zo = (acc[3][r] += bv[3]);
+      const float zi = acc[0][r] + bv[0], zf = acc[1][r] + bv[1], zg = acc[2][r] + bv[2], zo = acc[3][r] + bv[3];
       const float ig = dj_ract<SIGM>(zi), fg = dj_ract<SIGM>(zf), gg = dj_tanh(zg), og = dj_ract<SIGM>(zo);
+      ge.put(r, zi, zf, zg, zo, ig, fg, gg, og);
       const float cn = fg * c[r] + ig * gg;
       c[r] = cn;
       cv[r] = cn;
       ht[dj_crow(r, lane) * 32 + l31] = dj_from_f32<T>(og * dj_tanh(cn));
     }
-    DJ_STAMP(0, 4, t);
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // the exchange copy goes out FIRST: only it has to be acknowledged before the counter moves; chunks 2s, 2s+1 of
     // this tile in fragment image, 1 KiB each
     {
-      uint4* hxo = dj_cluster_hx + ((tile * 2 + (t & 1)) * 16 + 2 * s) * 64 + lane;
+      uint4* hxo = hxb + ((tile * 2 + (t & 1)) * 16 + 2 * s) * 64 + lane;
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) hxo[jj * 64] = *(const uint4*)(ht + l31 * 32 + 16 * jj + 8 * h);
     }
@@ -816,63 +828,44 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
     if (Cout) store_frag(Cout + ((rb * R::NCBH + s) * 64 + lane) * 16, cv);
     if (Zst) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float zv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) zv[r] = acc[g][r];
-        store_frag(Zst + ((rb * R::NCB + (g * H + s * 32) / 32) * 64 + lane) * 16, zv);
-      }
+      for (int g = 0; g < 4; ++g) ge.store(g, Zst + ((rb * R::NCB + (g * H + s * 32) / 32) * 64 + lane) * 16);
     }
-    DJ_STAMP(0, 5, t);
     // stores are acknowledged in order: wait until only the ones issued after the exchange copy are outstanding
-    // (2 h + 2 c + 8 z; they drain under the next step and at the latest at the end of the kernel)
+    // (2 h + 2 c + 4 gate-stash stores; they drain under the next step and at the latest at the end of the kernel)
     asm volatile("" ::: "memory");
+    constexpr int NST = GateEnc<T, SIGM>::STORES;          // 16-byte stores per gate block
     if (Zst && Cout)
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + 4 * NST) : "memory");
     else if (Zst)
-      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + 4 * NST) : "memory");
     else if (Cout)
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    DJ_STAMP(0, 6, t);
-#if DJ_EXP_CL_XAHEAD == 2
-    cl_load_x<NR, 0, NR>(xq, xnext, DP, xc);    // x_{t+1} travels while the members meet
-#endif
-#ifndef DJ_EXP_CL_ASCOPE
-#define DJ_EXP_CL_ASCOPE __HIP_MEMORY_SCOPE_AGENT
-#endif
-#if DJ_EXP_CL_GROUPS
-    if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, DJ_EXP_CL_ASCOPE);
-#else
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, DJ_EXP_CL_ASCOPE);
-#endif
+    if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
 // ---------------------------------------------------------------- backward (BPTT)
-// Z: fragment-tiled pre-activations (read only); dZ: row-major [M,4H] output.
+// Z: the forward's gate stash (GateDec above; read only); dZ: row-major [M,4H] output.
 // DX (stationary-U^T builds only): the kernel also produces the layer's input gradient dX_t = dz_t W^T from
 // the dz tile it holds in LDS -- with no U^T stream the W^T fragments are the only weight traffic of the step
 // and cost less vector-memory time than a separate GEMM pass over dZ in HBM.
 // DX == 2: only the LAST 32-column block of dX (columns 32*(NQ-1) ..., at most 4 of them valid: the `chosen`
 // inputs of note layer 0) is produced here, its K range split over the waves (8 stationary fragments each) and
 // the partial sums folded through LDS one step later; the GEMM then covers a multiple of 256 columns only.
-#ifndef DJ_EXP_ULDS
-#define DJ_EXP_ULDS 8
-#endif
 // LDS-resident part of the streamed U^T (bf16 H = 256 only): KL k-chunks per wave behind the dz and dH tiles
 template <typename T, int H> struct BwdUlds {
   using R = RecCfg<T, H>;
-  static constexpr int KL = (sizeof(T) == 2 && H == 256 && !R::STATB) ? DJ_EXP_ULDS : 0;
+  static constexpr int KL = (sizeof(T) == 2 && H == 256 && !R::STATB) ? 8 : 0;
   static constexpr size_t bytes = (size_t)R::NW * KL * 64 * 16;
   static constexpr size_t offset(int DX) {
     return (size_t)32 * (R::LDZ + (R::HOIST ? R::LDH : 0)) * sizeof(T) + (DX == 2 ? R::NW * 32 * 4 * sizeof(float) : 0);
   }
 };
 template <typename T, int H, bool SIGM, int DX>
-__global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z, const T* __restrict__ UTpack,
+__global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const StashElem<T>* __restrict__ Z, const T* __restrict__ UTpack,
                                                        const T* __restrict__ C, const T* __restrict__ dH,
                                                        T* __restrict__ dZ, float* __restrict__ dbias, int steps,
                                                        const T* __restrict__ WTpack, int NQ, T* __restrict__ dX,
@@ -974,24 +967,22 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
       dh3 = dh_ld((rbv), 3);     \
     }                            \
   } while (0)
-#ifndef DJ_EXP_TAILPF
-#define DJ_EXP_TAILPF 1
-#endif
   // TAILPF (bf16, H = 128 with the stationary U^T): the stash of step t-1 (z_{t-1}, c_{t-2}, dH_{t-1}) is
   // requested at the start of step t's dz U^T product -- there is no weight stream it could delay, and
   // the product, the barriers and the dH staging are its head start (-0.22 ms on the note axis).  With
   // a streamed U^T (H = 256) the same requests issued after the last fragment load made the step
   // slower (+0.16 ms), so that kernel keeps requesting its stash at the top of the step.
-  constexpr bool TAILPF = R::HOIST && R::STATB && DJ_EXP_TAILPF;
+  constexpr bool TAILPF = R::HOIST && R::STATB;
   Frag16<T> cnext[R::NJ];   // c_t of the step being processed (loaded as c_{t-1} one step earlier)
-  Frag16<T> zf[4][R::NJ], cprev[R::NJ];
+  Frag16<T> cprev[R::NJ];
+  GateDec<T, SIGM> gd[R::NJ];
   DJ_DH_LOAD(tile * steps + steps - 1);
 #pragma unroll
   for (int j = 0; j < R::NJ; ++j) {
     cnext[j].load(caddr(tile * steps + steps - 1, j));
     if constexpr (TAILPF) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) zf[g][j].load(zaddr(tile * steps + steps - 1, g, j));
+      for (int g = 0; g < 4; ++g) gd[j].load(g, zaddr(tile * steps + steps - 1, g, j));
       if (steps > 1) cprev[j].load(caddr(tile * steps + steps - 2, j));
     }
   }
@@ -1000,14 +991,13 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
 #pragma unroll
     for (int j = 0; j < R::NJ; ++j) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) zf[g][j].load(zaddr(rb - 1, g, j));
+      for (int g = 0; g < 4; ++g) gd[j].load(g, zaddr(rb - 1, g, j));
       if (t > 1) cprev[j].load(caddr(rb - 2, j));
     }
   };
 
   for (int t = steps - 1; t >= 0; --t) {
     const int64_t rb = tile * steps + t;
-    DJ_STAMP(1, 0, t);
     // stage dH_t into LDS, then pick it up in accumulator layout
     dh_st(0, dh0);
     dh_st(1, dh1);
@@ -1020,15 +1010,13 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
       for (int j = 0; j < R::NJ; ++j) {
         if constexpr (R::HOIST) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) zf[g][j].load(zaddr(rb, g, j));
+          for (int g = 0; g < 4; ++g) gd[j].load(g, zaddr(rb, g, j));
         }
         if (t > 0) cprev[j].load(caddr(rb - 1, j));
       }
       if (t > 0) DJ_DH_LOAD(rb - 1);
     }
-    DJ_STAMP(1, 1, t);
     lds_barrier();
-    DJ_STAMP(1, 2, t);
     if constexpr (DX == 2) {
       if (t < steps - 1) xpart_fold(rb + 1);      // partials of step t+1: every wave wrote them before this barrier
     }
@@ -1039,27 +1027,26 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
       for (int r = 0; r < 16; ++r)
         dhv[j][r] = dj_to_f32(dhs[dj_crow(r, lane) * R::LDH + w * R::UW + j * 32 + l31]) + acc[j][r];
     if constexpr (!SPLIT) lds_barrier();
-    DJ_STAMP(1, 3, t);
 #pragma unroll
     for (int j = 0; j < R::NJ; ++j) {
       const int u = w * R::UW + j * 32 + l31;
       if constexpr (!R::HOIST) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) zf[g][j].load(zaddr(rb, g, j));
+        for (int g = 0; g < 4; ++g) gd[j].load(g, zaddr(rb, g, j));
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = dj_crow(r, lane);
-        float zi = zf[0][j].get(r), zfv = zf[1][j].get(r), zg = zf[2][j].get(r), zo = zf[3][j].get(r);
+        float ig, fg, gg, og, di, df, dO;
+        gd[j].get(r, ig, fg, gg, og, di, df, dO);
         float ct = cnext[j].get(r);
         float cp = (t > 0) ? cprev[j].get(r) : 0.f;
         float dh = dhv[j][r];
-        float ig = dj_ract<SIGM>(zi), fg = dj_ract<SIGM>(zfv), gg = dj_tanh(zg), og = dj_ract<SIGM>(zo);
         float tc = dj_tanh(ct);
-        float dzo = dh * tc * dj_ract_grad<SIGM>(zo, og);
+        float dzo = dh * tc * dO;
         float dc = dcc[j][r] + dh * og * (1.f - tc * tc);
-        float dzi = dc * gg * dj_ract_grad<SIGM>(zi, ig);
-        float dzf = dc * cp * dj_ract_grad<SIGM>(zfv, fg);
+        float dzi = dc * gg * di;
+        float dzf = dc * cp * df;
         float dzg = dc * ig * (1.f - gg * gg);
         dcc[j][r] = dc * fg;
         T* dp = dzs + row * R::LDZ + u;
@@ -1074,9 +1061,7 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
       }
       if (t > 0) cnext[j].copy_from(cprev[j]);
     }
-    DJ_STAMP(1, 4, t);
     lds_barrier();
-    DJ_STAMP(1, 5, t);
     // dz_t tile -> global row-major, coalesced
     constexpr int VPRZ = 4 * H / R::EPL;
 #pragma unroll 4
@@ -1084,7 +1069,6 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
       int row = v / VPRZ, cv = (v % VPRZ) * R::EPL;
       *(uint4*)(dZ + (rb * 32 + row) * (4 * H) + cv) = *(const uint4*)(dzs + row * R::LDZ + cv);
     }
-    DJ_STAMP(1, 6, t);
     if constexpr (DX == 2) {
       const T* apx = dzs + l31 * R::LDZ;
       f32x16 ax;
@@ -1180,7 +1164,6 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const T* __restrict__ Z
         }
       }
     }
-    DJ_STAMP(1, 7, t);
     // (SPLIT) the next step's first barrier already orders this step's dzs reads before its gate writes
     if constexpr (!SPLIT) lds_barrier();
   }
@@ -1210,14 +1193,15 @@ template <typename T, int H> int launch_pack(const float* U, void* fwd, void* bw
   return (int)hipGetLastError();
 }
 template <typename T, int H>
-int launch_fwd(int ntiles, int steps, void* Z, const void* Upack, void* Hout, void* Cout, int sigm, int store_z,
+int launch_fwd(int ntiles, int steps, const void* Zx, void* Gst, const void* Upack, void* Hout, void* Cout, int sigm,
                hipStream_t st) {
+  if (sizeof(T) == 2 && Gst == Zx) return 1017;      // the 8-bit gate stash cannot overwrite the bf16 projections
   if (sigm)
-    hipLaunchKernelGGL((lstm_fwd_kernel<T, H, true>), dim3(ntiles), dim3(RecCfg<T, H>::NT), 0, st, (T*)Z, (const T*)Upack, (T*)Hout,
-                       (T*)Cout, steps, store_z);
+    hipLaunchKernelGGL((lstm_fwd_kernel<T, H, true>), dim3(ntiles), dim3(RecCfg<T, H>::NT), 0, st, (const T*)Zx,
+                       (StashElem<T>*)Gst, (const T*)Upack, (T*)Hout, (T*)Cout, steps);
   else
-    hipLaunchKernelGGL((lstm_fwd_kernel<T, H, false>), dim3(ntiles), dim3(RecCfg<T, H>::NT), 0, st, (T*)Z, (const T*)Upack,
-                       (T*)Hout, (T*)Cout, steps, store_z);
+    hipLaunchKernelGGL((lstm_fwd_kernel<T, H, false>), dim3(ntiles), dim3(RecCfg<T, H>::NT), 0, st, (const T*)Zx,
+                       (StashElem<T>*)Gst, (const T*)Upack, (T*)Hout, (T*)Cout, steps);
   return (int)hipGetLastError();
 }
 template <typename T, int H, int DX>
@@ -1237,10 +1221,10 @@ int launch_bwd_x(int ntiles, int steps, const void* Z, const void* UTpack, const
     attr_done = true;
   }
   if (sigm)
-    hipLaunchKernelGGL((lstm_bwd_kernel<T, H, true, DX>), dim3(ntiles), dim3(R::NT), smem, st, (const T*)Z,
+    hipLaunchKernelGGL((lstm_bwd_kernel<T, H, true, DX>), dim3(ntiles), dim3(R::NT), smem, st, (const StashElem<T>*)Z,
                        (const T*)UTpack, (const T*)C, (const T*)dH, (T*)dZ, dbias, steps, (const T*)WTpack, NQ, (T*)dX, DP);
   else
-    hipLaunchKernelGGL((lstm_bwd_kernel<T, H, false, DX>), dim3(ntiles), dim3(R::NT), smem, st, (const T*)Z,
+    hipLaunchKernelGGL((lstm_bwd_kernel<T, H, false, DX>), dim3(ntiles), dim3(R::NT), smem, st, (const StashElem<T>*)Z,
                        (const T*)UTpack, (const T*)C, (const T*)dH, (T*)dZ, dbias, steps, (const T*)WTpack, NQ, (T*)dX, DP);
   return (int)hipGetLastError();
 }
@@ -1285,7 +1269,7 @@ int launch_fwd_fused_k(int ntiles, int steps, const void* X, int DP, int NKX, co
     attr_done = true;
   }
   hipLaunchKernelGGL((lstm_fwd_fused_kernel<T, H, SIGM, WSTAT, WLDS>), dim3(ntiles), dim3(R::NT), smem, st, (const T*)X,
-                     DP, NKX, (const T*)Wpack, bias, (T*)Zst, (const T*)Upack, (T*)Hout, (T*)Cout, steps);
+                     DP, NKX, (const T*)Wpack, bias, (StashElem<T>*)Zst, (const T*)Upack, (T*)Hout, (T*)Cout, steps);
   return (int)hipGetLastError();
 }
 template <typename T, int H, bool SIGM, bool WSTAT>
@@ -1327,7 +1311,8 @@ int launch_fwd_fused(int ntiles, int steps, const void* X, int DP, int NKX, cons
 
 template <bool SIGM, int NKX>
 int launch_fwd_cluster_k(int ntiles, int steps, const void* X, int DP, const void* Wpack, const float* bias,
-                         void* Zst, const void* Upack, void* Hout, void* Cout, size_t smem, hipStream_t st) {
+                         void* Zst, const void* Upack, void* Hout, void* Cout, size_t smem, void* scratch,
+                         hipStream_t st) {
   static bool attr_done_dev[DJ_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[dj_current_device()];
   if (!attr_done) {
@@ -1337,15 +1322,17 @@ int launch_fwd_cluster_k(int ntiles, int steps, const void* X, int DP, const voi
     attr_done = true;
   }
   hipLaunchKernelGGL((lstm_fwd_cluster_kernel<SIGM, NKX>), dim3(ntiles), dim3(512), smem, st, (const bf16_t*)X, DP,
-                     (const bf16_t*)Wpack, bias, (bf16_t*)Zst, (const bf16_t*)Upack, (bf16_t*)Hout, (bf16_t*)Cout, steps);
+                     (const bf16_t*)Wpack, bias, (uint8_t*)Zst, (const bf16_t*)Upack, (bf16_t*)Hout, (bf16_t*)Cout, steps,
+                     (int*)scratch);
   return (int)hipGetLastError();
 }
 template <bool SIGM>
 int launch_fwd_cluster_s(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
-                         void* Zst, const void* Upack, void* Hout, void* Cout, size_t smem, hipStream_t st) {
+                         void* Zst, const void* Upack, void* Hout, void* Cout, size_t smem, void* scratch,
+                         hipStream_t st) {
   switch (NKX) {   // the input widths the model has (dj_lstm_fused_nkx): 94 -> 8 chunks, 256 -> 16
-    case 8: return launch_fwd_cluster_k<SIGM, 8>(ntiles, steps, X, DP, Wpack, bias, Zst, Upack, Hout, Cout, smem, st);
-    case 16: return launch_fwd_cluster_k<SIGM, 16>(ntiles, steps, X, DP, Wpack, bias, Zst, Upack, Hout, Cout, smem, st);
+    case 8: return launch_fwd_cluster_k<SIGM, 8>(ntiles, steps, X, DP, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st);
+    case 16: return launch_fwd_cluster_k<SIGM, 16>(ntiles, steps, X, DP, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st);
   }
   return 1016;
 }
@@ -1361,21 +1348,17 @@ int cluster_cus() {
   return cus[dev];
 }
 int launch_fwd_cluster(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
-                       void* Zst, const void* Upack, void* Hout, void* Cout, int sigm, hipStream_t st) {
+                       void* Zst, const void* Upack, void* Hout, void* Cout, int sigm, void* scratch, hipStream_t st) {
   using R = RecCfg<bf16_t, 256>;
   // blocks come in groups of 64 = 8 XCDs x 8 members (cluster id = xcd + 8 * group)
-  if (ntiles % 64 || ntiles > 256 || NKX * R::KC > 256 || DP > 256 || DP % 8) return 1016;
+  if (ntiles % 64 || ntiles > 256 || NKX * R::KC > 256 || DP > 256 || DP % 8 || !scratch || ((uintptr_t)scratch & 127))
+    return 1016;
   const size_t smem = (size_t)(4 * NKX * 64 + 4 * R::NKC * 64) * 16 + (size_t)8 * 4096;
-  static void* cnt_addr_dev[DJ_MAX_DEVICES] = {};      // a __device__ symbol has one address per device
-  void*& cnt_addr = cnt_addr_dev[dj_current_device()];
-  if (!cnt_addr) {
-    hipError_t e = hipGetSymbolAddress(&cnt_addr, HIP_SYMBOL(dj_cluster_cnt));
-    if (e != hipSuccess) return (int)e;
-  }
-  hipError_t e = hipMemsetAsync(cnt_addr, 0, sizeof(int) * 64 * 2 * CL_CNT_STRIDE, st);
+  // counters and XCC ids of every cluster start at zero in every launch (a memset node under graph capture)
+  hipError_t e = hipMemsetAsync(scratch, 0, CL_OFF_FAULT, st);
   if (e != hipSuccess) return (int)e;
-  return sigm ? launch_fwd_cluster_s<true>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, st)
-              : launch_fwd_cluster_s<false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, st);
+  return sigm ? launch_fwd_cluster_s<true>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st)
+              : launch_fwd_cluster_s<false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st);
 }
 
 }  // namespace
@@ -1390,11 +1373,14 @@ int launch_fwd_cluster(int ntiles, int steps, const void* X, int DP, int NKX, co
 int dj_launch_lstm_pack(int dtype, int H, const float* U, void* fwd, void* bwd, hipStream_t st) {
   DJ_DISPATCH_TH(launch_pack, U, fwd, bwd, st)
 }
-int dj_launch_lstm_fwd(int dtype, int H, int ntiles, int steps, void* Z, const void* Upack, void* Hout, void* Cout,
-                       int sigm, int store_z, hipStream_t st) {
+int dj_launch_lstm_fwd(int dtype, int H, int ntiles, int steps, const void* Zx, void* Gst, const void* Upack, void* Hout,
+                       void* Cout, int sigm, hipStream_t st) {
   if (ntiles <= 0 || steps <= 0) return 0;
-  DJ_DISPATCH_TH(launch_fwd, ntiles, steps, Z, Upack, Hout, Cout, sigm, store_z, st)
+  DJ_DISPATCH_TH(launch_fwd, ntiles, steps, Zx, Gst, Upack, Hout, Cout, sigm, st)
 }
+// bytes per row of the gate stash of a layer with H units (fragment-tiled; GateEnc above)
+int64_t dj_lstm_stash_row_bytes(int dtype, int H) { return (int64_t)4 * H * (dtype == DJ_F32 ? 4 : 1); }
+int64_t dj_lstm_cluster_scratch_bytes_impl() { return (int64_t)CL_BYTES; }
 int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* UTpack, const void* C,
                        const void* dH, void* dZ, float* dbias, int sigm, const void* WTpack, int D, void* dX, int DP,
                        hipStream_t st) {
@@ -1429,32 +1415,32 @@ int dj_lstm_fused_nkx(int dtype, int H, int D) {
 int dj_launch_lstm_pack_w(int dtype, int H, const float* W, int D, int NKX, void* out, hipStream_t st) {
   DJ_DISPATCH_TH(launch_pack_w, W, D, NKX, out, st)
 }
-int dj_lstm_cluster_faults_impl() {
-  int n = 0, zero = 0;
-  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(dj_cluster_fault), sizeof(int)) != hipSuccess) return -1;
-  if (n && hipMemcpyToSymbol(HIP_SYMBOL(dj_cluster_fault), &zero, sizeof(int)) != hipSuccess) return -1;
-  return n;
+int dj_lstm_cluster_faults_impl(void* scratch) {
+  if (!scratch) return 0;
+  int n[2] = {0, 0};
+  const int zero[2] = {0, 0};
+  char* f = (char*)scratch + CL_OFF_FAULT;
+  if (hipMemcpy(n, f, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if ((n[0] || n[1]) && hipMemcpy(f, zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) return -1;
+  return n[0] + n[1];
 }
 int dj_launch_lstm_fwd_fused(int dtype, int H, int ntiles, int steps, const void* X, int DP, int NKX,
                              const void* Wpack, const float* bias, void* Zst, const void* Upack, void* Hout,
-                             void* Cout, int sigm, hipStream_t st) {
+                             void* Cout, int sigm, void* cluster_scratch, hipStream_t st) {
   if (ntiles <= 0 || steps <= 0) return 0;
-#ifndef DJ_EXP_CLUSTER
-#define DJ_EXP_CLUSTER 1
-#endif
   // weight-stationary cluster kernel, in launches whose whole grid is co-resident (at most one workgroup per
   // compute unit) and splits into groups of 8 clusters of 8 tiles; what is left over takes the per-tile kernel
-  if (DJ_EXP_CLUSTER && dtype == DJ_BF16 && H == 256 && ntiles >= 64 && (NKX == 8 || NKX == 16) && DP <= 256) {
+  if (cluster_scratch && dtype == DJ_BF16 && H == 256 && ntiles >= 64 && (NKX == 8 || NKX == 16) && DP <= 256) {
     const char* e = getenv("DEEPJ_CLUSTER");
     const int cap = cluster_cus() < 256 ? cluster_cus() / 64 * 64 : 256;   // groups of 64 = 8 XCDs x 8 members
     if (!(e && e[0] == '0') && cap >= 64) {
       while (ntiles >= 64) {
         const int n = ntiles < cap ? ntiles / 64 * 64 : cap;
-        const int rc = launch_fwd_cluster(n, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, sigm, st);
+        const int rc = launch_fwd_cluster(n, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, sigm, cluster_scratch, st);
         if (rc) return rc;
         const int64_t rows = (int64_t)n * steps * 32;      // all five buffers are tile-major
         X = (const bf16_t*)X + rows * DP;
-        if (Zst) Zst = (bf16_t*)Zst + rows * 4 * H;
+        if (Zst) Zst = (uint8_t*)Zst + rows * 4 * H;      // 8-bit gate stash
         Hout = (bf16_t*)Hout + rows * H;
         if (Cout) Cout = (bf16_t*)Cout + rows * H;
         ntiles -= n;

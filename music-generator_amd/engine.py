@@ -146,6 +146,24 @@ class Engine:
                        "dj_workspace_init")
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
 
+    def cluster_faults(self) -> int:
+        """Events recorded by the weight-stationary cluster forward kernel in THIS engine's workspace since the last
+        call (expired waits, clusters spread over several XCDs; include/deepj_hip.h dj_lstm_cluster_faults).  Zero
+        in a healthy run; non-zero means the affected tiles -- and the loss -- are NaN.  Synchronises the device."""
+        with torch.cuda.device(self.device):
+            n = int(self.lib.dj_workspace_cluster_faults(C.byref(self.c), self.ws_ptr, self.ws_bytes))
+        if n < 0:
+            raise _lib.DeepJError("dj_workspace_cluster_faults failed")
+        return n
+
+    def raise_on_cluster_faults(self, what):
+        n = self.cluster_faults()
+        if n:
+            raise _lib.DeepJError(
+                "%s: %d cluster faults in the recurrent forward kernel (device shared with other kernels, or "
+                "workgroups not dealt round-robin over the XCDs); the results are NaN.  Set DEEPJ_CLUSTER=0 to use "
+                "the per-tile kernel." % (what, n))
+
     # -- shapes
     def _shapes(self):
         B, T, N = self.batch, self.time_steps, self.cfg.num_notes
@@ -215,14 +233,14 @@ class Engine:
     def generate_step(self, params, notes_win, beat_win, style_win, uniforms, temperature):
         """One generated time step for all `batch` pieces (dj_generate_step).  uniforms:
         float64 device tensor [2*N*G]; temperature: float32 device tensor [G].
-        Returns (next_notes [G,N,3] float32 device, draws_used int32 device [1])."""
+        Returns (next_notes [G,N,3] float32 device, draws_used int32 device [2] = draws consumed, near ties)."""
         s3, sb, ss = self._shapes()
         self._check(notes_win, s3, "notes"); self._check(beat_win, sb, "beat"); self._check(style_win, ss, "style")
         G, N = self.batch, self.cfg.num_notes
         assert uniforms.dtype == torch.float64 and uniforms.numel() >= 2 * N * G
         assert temperature.dtype == torch.float32 and temperature.numel() == G
         out = torch.empty((G, N, 3), dtype=torch.float32, device=self.device)
-        used = torch.zeros(1, dtype=torch.int32, device=self.device)
+        used = torch.zeros(2, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             rc = self.lib.dj_generate_step(C.byref(self.c), _lib.ptr(params), _lib.ptr(notes_win), _lib.ptr(beat_win),
                                            _lib.ptr(style_win), _lib.ptr(uniforms), _lib.ptr(temperature),
@@ -231,7 +249,7 @@ class Engine:
         return out, used
 
 
-GEN_STATE_DTYPE = np.dtype([("step", "<i4"), ("draw_off", "<i4"), ("pad0", "<i4"), ("pad1", "<i4"),
+GEN_STATE_DTYPE = np.dtype([("step", "<i4"), ("draw_off", "<i4"), ("near_ties", "<i4"), ("first_near_step", "<i4"),
                             ("temperature", "<f8", (8,)), ("default_temp", "<f8", (8,)), ("silent", "<i4", (8,))])
 
 
@@ -256,6 +274,7 @@ class ResidentGeneration:
         host["temperature"][0, :G] = default_temp
         host["default_temp"][0, :G] = default_temp
         host["silent"][0, :G] = engine.cfg.notes_per_bar          # generate.py:24
+        host["first_near_step"] = -1
         self.state = torch.from_numpy(host.view(np.uint8).copy()).to(dev)
         self.pool = torch.zeros(2 * N * G * 64, dtype=torch.float64, device=dev)
         self.cur = 0                                              # which window buffer is current

@@ -93,6 +93,12 @@ def process_inputs(ins):
 
 GEN_CHUNK = NOTES_PER_BAR          # time steps per device launch batch of the resident path
 
+# Filled by the fused paths of generate(): how many Bernoulli draws of the last run fell within 1e-5 of the
+# probability they were compared with, and the time step of the first one (-1 = none).  Zero near ties certifies
+# the sampled notes against any model whose probabilities agree with the HIP model's to 1e-5 (DESIGN.md
+# "Sampling parity"); otherwise the rolls are certified up to `first_near_tie_step`.
+last_run_stats = {"draws": 0, "near_ties": 0, "first_near_tie_step": -1}
+
 
 def _fused_engine(models, n_pieces):
     """The fused MI355X path is used when the models are this package's HIP models; any other
@@ -126,7 +132,10 @@ def _fused_step(shared, engine, pieces):
     temps = be.tensor(np.array([g.temperature for g in pieces], np.float32))
     nxt, used = engine.generate_step(shared.params, be.tensor(notes), be.tensor(beat), be.tensor(style), u_dev, temps)
     nxt = be.numpy(nxt)
-    np.random.random_sample(int(used.cpu()[0]))
+    used = used.cpu().numpy()
+    np.random.random_sample(int(used[0]))
+    last_run_stats["draws"] += int(used[0])
+    last_run_stats["near_ties"] += int(used[1])
     for i, g in enumerate(pieces):
         g.next_note[:, :] = nxt[i]
 
@@ -154,8 +163,10 @@ def _generate_resident(shared, engine, pieces, total_steps):
                 g.next_note[:, :] = notes[j, i]
             yield [g.end_time(t + j) for g in pieces]
         assert spent == used, (spent, used)
+        last_run_stats["draws"] += spent
         t += k
     st = run.read_state()                                  # device schedule == host schedule
+    last_run_stats.update(near_ties=int(st["near_ties"]), first_near_tie_step=int(st["first_near_step"]))
     for i, g in enumerate(pieces):
         assert abs(st["temperature"][i] - g.temperature) < 1e-9 and st["silent"][i] == g.silent_time
 
@@ -166,6 +177,7 @@ def generate(models, num_bars, styles):
     print('Generating with styles:', styles)
     _, time_model, note_model = models
     pieces = [MusicGeneration(style) for style in styles]
+    last_run_stats.update(draws=0, near_ties=0, first_near_tie_step=-1)
     fused = _fused_engine(models, len(pieces))
     if fused is not None and not os.environ.get("DEEPJ_GENERATE_STEPWISE"):
         yield from tqdm(_generate_resident(fused[0], fused[1], pieces, NOTES_PER_BAR * num_bars),
@@ -173,7 +185,10 @@ def generate(models, num_bars, styles):
         return
     for t in tqdm(range(NOTES_PER_BAR * num_bars)):
         if fused is not None:
+            ties = last_run_stats["near_ties"]
             _fused_step(fused[0], fused[1], pieces)
+            if ties == 0 and last_run_stats["near_ties"]:
+                last_run_stats["first_near_tie_step"] = t
             yield [g.end_time(t) for g in pieces]
             continue
         # note-invariant features of the whole window, last step only

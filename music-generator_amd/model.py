@@ -124,7 +124,8 @@ class _Shared:
         self.layout = backend.layout(cfg)
         self.nparams = sum(int(np.prod(s)) for _, _, s in self.layout)
         self.params = backend.tensor(backend.init_params(cfg, seed))
-        self.grads = None
+        self.grads = None              # view of grads_ext[:nparams]
+        self.grads_ext = None
         self.optimizer = None
         self.engines = {}
         self.step = 0
@@ -245,7 +246,10 @@ class Model:
             out = eng.time_model_predict(s.params, *t)
         else:
             out = eng.note_model_predict(s.params, *t)
-        return be.numpy(out)
+        out = be.numpy(out)
+        if hasattr(eng, "raise_on_cluster_faults"):
+            eng.raise_on_cluster_faults("predict")
+        return out
 
     def predict(self, x, batch_size=32, verbose=0):
         """Keras Model.predict: inference mode, processed in chunks of `batch_size` (Keras
@@ -289,9 +293,11 @@ class TrainableModel(Model):
         return self._train_step([np.asarray(a) for a in x],
                                 np.asarray(y[0] if isinstance(y, (list, tuple)) else y) if y is not None else None)
 
-    def _train_step(self, x, target, on_device=False):
+    def _train_step(self, x, target, on_device=False, weight=None, total_weight=None):
         """x = [notes, chosen, beat, style] (+ target) as host arrays, or as device fp32 tensors when
-        `on_device` (fit() with a device-resident data set)."""
+        `on_device` (fit() with a device-resident data set).  weight: this rank's share of the global batch
+        (default: its sample count; 0 for a rank that only keeps the collective pattern alive);
+        total_weight: the global batch size when the caller knows it (fit does), else it is all-reduced."""
         s, be = self._s, self._s.backend
         notes, chosen, beat, style = x
         if target is None:
@@ -303,48 +309,65 @@ class TrainableModel(Model):
         # couples samples within a micro-batch only.
         micro = int(os.environ.get("DEEPJ_MICRO_BATCH", "0") or 0)
         parts = B // micro if (micro > 0 and B > micro and B % micro == 0 and hasattr(be, "resident")) else 1
-        eng = s.engine(B // parts, T, train=True)
+        n = s.nparams
         if s.grads is None:
-            s.grads = be.tensor(np.zeros(s.nparams, np.float32))
+            # flat gradient + 4 tail words [weight, weight * loss, cluster faults, 0]: under data parallelism the
+            # whole buffer travels in ONE all-reduce per step
+            s.grads_ext = be.tensor(np.zeros(n + 4, np.float32))
+            s.grads = s.grads_ext[:n]
         if s.optimizer is None:
-            s.optimizer = be.optimizer(s.nparams, **self.optimizer_config)
+            s.optimizer = be.optimizer(n, **self.optimizer_config)
         dist = self._dist()
         rank = dist.get_rank() if dist else 0
         world = dist.get_world_size() if dist else 1
         seed = (s.seed * 1000003 + s.step * world + rank) & 0xFFFFFFFF
         t = [notes, chosen, beat, style, target] if on_device else [be.tensor(a) for a in (notes, chosen, beat, style, target)]
-        if parts == 1:
-            loss = eng.train_fwd_bwd(s.params, s.grads, *t, seed=seed)
-        else:
-            k, loss = B // parts, None
-            for i in range(parts):
-                mb = [x_[i * k:(i + 1) * k].contiguous() for x_ in t]
-                li = eng.train_fwd_bwd(s.params, s.grads, *mb, seed=(seed + 7919 * i) & 0xFFFFFFFF, accumulate=i > 0)
-                loss = li.clone() if loss is None else loss + li
-            loss = loss / parts                              # equal parts: mean of the micro-batch means
-            s.grads.mul_(1.0 / parts)
-        weight = float(B)
+        weight = float(B) if weight is None else float(weight)
+
+        def fwd_bwd():
+            eng = s.engine(B // parts, T, train=True)
+            if parts == 1:
+                loss = eng.train_fwd_bwd(s.params, s.grads, *t, seed=seed)
+            else:
+                k, loss = B // parts, None
+                for i in range(parts):
+                    mb = [x_[i * k:(i + 1) * k].contiguous() for x_ in t]
+                    li = eng.train_fwd_bwd(s.params, s.grads, *mb, seed=(seed + 7919 * i) & 0xFFFFFFFF, accumulate=i > 0)
+                    loss = li.clone() if loss is None else loss + li
+                loss = loss / parts                              # equal parts: mean of the micro-batch means
+                s.grads.mul_(1.0 / parts)
+            return eng, loss
+
+        eng, loss = fwd_bwd()
+        faults = eng.cluster_faults() if hasattr(eng, "cluster_faults") else 0
         if dist:
-            import torch
-            cnt = torch.tensor([weight], dtype=torch.float64, device=s.grads.device)
-            dist.all_reduce(cnt)
-            total = float(cnt.cpu()[0])
-            s.grads.mul_(weight / total)                 # shard-size weighting, then one sum
-            dist.all_reduce(s.grads)
-            lw = loss.detach().clone().double() * (weight / total)
-            dist.all_reduce(lw)
-            loss_value = float(lw.cpu()[0])
+            # shard-size weighting, then ONE sum over ranks of [gradient | weight, weight * loss, faults]
+            tail = s.grads_ext[n:]
+            s.grads.mul_(weight)
+            tail[0] = weight
+            tail[1:2].copy_(loss.detach().reshape(1) * weight)
+            tail[2] = float(faults)
+            dist.all_reduce(s.grads_ext)
+            w_sum, wl_sum, faults = [float(v) for v in be.numpy(tail)[:3]]     # the step's one host read-back
+            total = float(total_weight) if total_weight is not None else w_sum
+            loss_value = wl_sum / total
+            scale = 1.0 / total
         else:
             loss_value = float(be.numpy(loss)[0])
+            scale = 1.0
+        if faults:
+            # a cluster wait expired or a cluster was spread over several XCDs (include/deepj_hip.h): this step's
+            # numbers are NaN.  Nothing has been applied yet: switch every rank to the per-tile kernel and redo it.
+            if os.environ.get("DEEPJ_CLUSTER") == "0":
+                raise RuntimeError("cluster faults reported with the cluster kernel disabled")
+            if rank == 0:
+                print("[deepj] %d cluster faults in the recurrent forward kernel: falling back to the per-tile kernel "
+                      "(DEEPJ_CLUSTER=0) and repeating the step" % int(faults))
+            os.environ["DEEPJ_CLUSTER"] = "0"
+            return self._train_step(x, target, on_device, weight, total_weight)
         if loss_value != loss_value:
-            # a NaN loss can be the mark of an expired cluster wait (include/deepj_hip.h dj_lstm_cluster_faults):
-            # name it, and leave the parameters untouched
-            from . import _lib
-            faults = _lib.load().dj_lstm_cluster_faults()
-            if faults:
-                raise RuntimeError("%d cluster waits of the recurrent forward kernel expired (device shared with other "
-                                   "kernels?); set DEEPJ_CLUSTER=0 to use the per-tile kernel" % faults)
-        s.optimizer.step(s.params, s.grads, 1.0)
+            raise FloatingPointError("training loss is NaN at step %d" % s.step)
+        s.optimizer.step(s.params, s.grads, scale)
         s.step += 1
         return loss_value
 
@@ -360,6 +383,8 @@ class TrainableModel(Model):
             _, loss = eng.predict(self._s.params, be.tensor(notes[sl]), be.tensor(chosen[sl]), be.tensor(beat[sl]),
                                   be.tensor(style[sl]), be.tensor(target[sl]))
             tot += float(be.numpy(loss)[0]) * b
+            if hasattr(eng, "raise_on_cluster_faults"):
+                eng.raise_on_cluster_faults("evaluate")
         return tot / n
 
     def fit(self, x=None, y=None, batch_size=32, epochs=1, verbose=1, callbacks=None, shuffle=True,
@@ -401,18 +426,20 @@ class TrainableModel(Model):
             for bi in range(nb):
                 ids = index[bi * batch_size:(bi + 1) * batch_size]
                 _call(callbacks, "on_batch_begin", bi, {"batch": bi, "size": len(ids)})
+                weight = None
                 if world > 1:
                     per = (len(ids) + world - 1) // world
                     mine = ids[rank * per:(rank + 1) * per]
-                    if len(mine) == 0:                    # keep the collective pattern identical
-                        mine = ids[:1]
+                    weight = float(len(mine))
+                    if len(mine) == 0:                    # keep the collective pattern identical: a sample with
+                        mine = ids[:1]                    # weight 0 adds nothing to the gradient or the loss
                 else:
                     mine = ids
                 if resident is not None:
                     dev = be.take(resident, mine)
-                    loss = self._train_step(dev[:4], dev[4], on_device=True)
+                    loss = self._train_step(dev[:4], dev[4], on_device=True, weight=weight, total_weight=len(ids))
                 else:
-                    loss = self.train_on_batch([a[mine] for a in x], target[mine])
+                    loss = self._train_step([a[mine] for a in x], target[mine], weight=weight, total_weight=len(ids))
                 tot += loss * len(ids)
                 seen += len(ids)
                 _call(callbacks, "on_batch_end", bi, {"batch": bi, "size": len(ids), "loss": loss})

@@ -52,7 +52,7 @@ def test_fit_batches_shuffle_history_and_callbacks(tmp_path):
 
 def test_early_stopping_stops():
     from music_generator_amd.callbacks import EarlyStopping
-    model, _, _ = _tiny_models()
+    model, _, _ = _tiny_models(input_dropout=0.0, dropout=0.0)   # (with dropout the loss would wander with the masks)
     model.optimizer_config["lr"] = 0.0                         # loss cannot improve
     x, y = _data(2)
     hist = model.fit(x, y, epochs=50, batch_size=2, verbose=0, shuffle=False,
@@ -98,9 +98,13 @@ torch.set_num_threads(2)
 dist.init_process_group("gloo")
 cfg = DeepJConfig(num_notes=12, time_steps=4, time_axis_units=128, note_axis_units=128)
 model, _, _ = build_models(time_steps=4, config=cfg, backend=OracleBackend(), seed=3, input_dropout=0.0, dropout=0.0)
-a = synthetic_batch(12, 4, 4, seed=5)
+a = synthetic_batch(12, 4, 5, seed=5)
 np.random.seed(0)
+calls = []
+orig = dist.all_reduce
+dist.all_reduce = lambda *a_, **k_: (calls.append(1), orig(*a_, **k_))[1]
 h = model.fit([a[0], a[1], a[2], a[3]], [a[4]], epochs=2, batch_size=4, verbose=0, shuffle=False)
+assert len(calls) == 4, calls            # ONE all-reduce per step (gradient, weights, loss and fault count packed)
 w = np.concatenate([x.ravel() for x in model.get_weights()])
 np.save(os.path.join({out!r}, "w%d.npy" % dist.get_rank()), w)
 np.save(os.path.join({out!r}, "l%d.npy" % dist.get_rank()), np.array(h.history["loss"]))
@@ -109,8 +113,10 @@ dist.destroy_process_group()
 
 
 def test_data_parallel_two_ranks_gloo(tmp_path):
-    """world_size 2 over gloo: each rank trains on its shard of every batch, one gradient
-    all-reduce per step; replicas stay bit-identical and the loss is the global mean."""
+    """world_size 2 over gloo: each rank trains on its shard of every batch, ONE all-reduce per step;
+    replicas stay bit-identical and the loss is the global mean.  5 samples at batch 4: the last batch of an
+    epoch holds one sample, so rank 1's shard is empty -- it runs a weight-0 step to keep the collective
+    pattern, which must leave gradient and loss exactly those of the one real sample."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
@@ -127,18 +133,20 @@ def test_data_parallel_two_ranks_gloo(tmp_path):
     from music_generator_amd.data import synthetic_batch
     from oracle import deepj_oracle as O
     ocfg = O.OracleConfig(num_notes=12, time_steps=4, time_axis_units=128, note_axis_units=128)
-    a = synthetic_batch(12, 4, 4, seed=5)
+    a = synthetic_batch(12, 4, 5, seed=5)
     flat = O.flatten_params(ocfg, O.init_params(ocfg, 3))
     st = O.NadamState()
     losses = []
     for _ in range(2):
         gs, ls = [], []
-        for r_ in range(2):
+        for r_ in range(2):                                   # batch 0: samples 0..3, two per rank
             sl = slice(2 * r_, 2 * r_ + 2)
             l, _, g = O.loss_and_grads(ocfg, O.unflatten_params(ocfg, flat), [t[sl] for t in a])
             gs.append(O.flatten_params(ocfg, g))
             ls.append(l)
         flat = O.nadam_step(flat, (0.5 * gs[0] + 0.5 * gs[1]).astype(np.float32), st)
-        losses.append(0.5 * ls[0] + 0.5 * ls[1])
+        l4, _, g4 = O.loss_and_grads(ocfg, O.unflatten_params(ocfg, flat), [t[4:5] for t in a])   # batch 1: sample 4
+        flat = O.nadam_step(flat, O.flatten_params(ocfg, g4), st)
+        losses.append((4 * (0.5 * ls[0] + 0.5 * ls[1]) + l4) / 5)                                 # sample-weighted epoch mean
     np.testing.assert_allclose(w0, flat, rtol=2e-5, atol=2e-7)
     np.testing.assert_allclose(np.load(tmp_path / "l0.npy"), losses, rtol=1e-5)

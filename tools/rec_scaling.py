@@ -22,11 +22,12 @@ for H in (128, 256):
     _lib.check(lib.dj_lstm_pack(1, H, p(U), p(upf), p(upb), st()), "pack")
     for tiles in (128, 256, 257, 384, 512):
         R = tiles * steps * 32
-        Z = (torch.randn(R * 4 * H, device=dev) * 0.5).to(torch.bfloat16)
+        Z = (torch.randn(R * 4 * H, device=dev) * 0.5).to(torch.bfloat16)           # x W + b, fragment-tiled
+        G8 = torch.zeros(R * 4 * H, dtype=torch.uint8, device=dev)                 # 8-bit gate stash
         Hd = torch.zeros(R * H, dtype=torch.bfloat16, device=dev); Cd = torch.zeros_like(Hd)
         dH = (torch.randn(R * H, device=dev) * 0.1).to(torch.bfloat16)
         dZ = torch.zeros(R * 4 * H, dtype=torch.bfloat16, device=dev); db = torch.zeros(4 * H, device=dev)
-        f = t_ms(lambda: _lib.check(lib.dj_lstm_fwd(1, H, tiles, steps, p(Z), p(upf), p(Hd), p(Cd), 0, st()), "fwd"))
-        b = t_ms(lambda: _lib.check(lib.dj_lstm_bwd(1, H, tiles, steps, p(Z), p(upb), p(Cd), p(dH), p(dZ), p(db), 0, st()), "bwd"))
+        f = t_ms(lambda: _lib.check(lib.dj_lstm_fwd(1, H, tiles, steps, p(Z), p(G8), p(upf), p(Hd), p(Cd), 0, st()), "fwd"))
+        b = t_ms(lambda: _lib.check(lib.dj_lstm_bwd(1, H, tiles, steps, p(G8), p(upb), p(Cd), p(dH), p(dZ), p(db), 0, st()), "bwd"))
         print(f"H={H} tiles={tiles}: fwd {f:.3f} ms  bwd {b:.3f} ms", flush=True)
-        del Z, Hd, Cd, dH, dZ
+        del Z, G8, Hd, Cd, dH, dZ

@@ -8,10 +8,10 @@ from music_generator_amd import _lib
 import io, contextlib
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
-    q.run("bf16", steps=400)
+    eng = q.run("bf16", steps=400)
 out = buf.getvalue().strip().splitlines()[-1]
 i = out.index("losses ")
 losses = eval(out[i + 7:])
 print(out[:out.index("losses")])
 print("first", losses[:3], "last", losses[-3:], "finite", all(np.isfinite(losses)), "monotone-ish", losses[-1] < losses[0])
-print("cluster faults:", _lib.load().dj_lstm_cluster_faults())
+print("cluster faults:", eng.cluster_faults())
