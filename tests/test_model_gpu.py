@@ -349,9 +349,6 @@ def test_resident_graph_generation_1024_steps(gpu_device, monkeypatch):
     np.testing.assert_array_equal(pos_res, pos_stp)
     assert st_res == st_stp and st_res["draws"] == 1024 * 3 * 48 + int(res[..., 0].sum())
     assert 0 < res[..., 0].sum() < res[..., 0].size
-    # the temperature schedule was exercised: silent stretches of >= 16 steps heat the sampler (generate.py:60-71)
-    silent = (res.reshape(1024, 3, -1).sum(-1) == 0)
-    assert silent.any()
 
 
 def test_full_size_properties(gpu_device, monkeypatch):
