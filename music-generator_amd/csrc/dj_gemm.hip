@@ -493,10 +493,7 @@ struct WgradArgs {
   int ntn, ntiles, xcd_map;
   int64_t rows_per_split;
 };
-#ifndef DJ_EXP_WG_NS
-#define DJ_EXP_WG_NS 4
-#endif
-constexpr int WG_BK = 32, WG_T = 256, WG_TILE_BYTES = WG_BK * WG_T * 2, WG_STAGE = 2 * WG_TILE_BYTES, WG_NS = DJ_EXP_WG_NS;
+constexpr int WG_BK = 32, WG_T = 256, WG_TILE_BYTES = WG_BK * WG_T * 2, WG_STAGE = 2 * WG_TILE_BYTES, WG_NS = 4;
 
 __global__ __launch_bounds__(512) void lstm_wgrad_bf16_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -585,9 +582,7 @@ __global__ __launch_bounds__(512) void lstm_wgrad_bf16_kernel(WgradArgs a) {
     if (s < nkt) issue(s);
   for (int kt = 0; kt < nkt; ++kt) {
     const int rem = nkt - 1 - kt;            // stages issued after kt that may still be in flight: min(rem, NS-2)
-    if (WG_NS >= 5 && rem >= 3)
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (WG_NS >= 4 && rem >= 2)
+    if (rem >= 2)
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (rem >= 1)
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");

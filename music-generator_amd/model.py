@@ -38,6 +38,36 @@ def primary_loss(y_true, y_pred):
     return note + replay + vol
 
 
+class KerasHDF5Error(RuntimeError):
+    """The weight file is a Keras HDF5 checkpoint (the reference's out/model.h5).  Not swallowed by
+    util.build_or_load: generating from random weights because a real checkpoint could not be read would be a
+    silent wrong answer."""
+
+
+# Tensor name of this build -> (Keras layer group, weight name) inside a weights-only HDF5 file written by the
+# reference (train.py:23 ModelCheckpoint(save_weights_only=True)) from a fresh process: Keras 2 auto-names layers
+# <class>_<k> in creation order (model.py:51-169), TimeDistributed wrappers own their inner layer's weights.
+# Layouts are identical (Dense [in, out]; Conv1D [k, c_in, c_out]; LSTM kernel [in, 4H], recurrent_kernel [H, 4H],
+# bias [4H], gate blocks i, f, c, o), so conversion is a pure rename: tools/convert_keras_h5.py.
+def keras_name_map(cfg: DeepJConfig):
+    m = {"style/kernel": ("style", "style/kernel:0"), "style/bias": ("style", "style/bias:0"),
+         "conv/kernel": ("time_distributed_1", "time_distributed_1/kernel:0"),
+         "conv/bias": ("time_distributed_1", "time_distributed_1/bias:0")}
+    dense, td = 0, 2                      # time_distributed_2 = RepeatVector over the beat input (no weights)
+    for axis, layers in (("time", cfg.time_axis_layers), ("note", cfg.note_axis_layers)):
+        for l in range(layers):
+            dense += 1
+            td += 2                       # one wrapper around RepeatVector (no weights), one around the LSTM
+            m["%s_dense%d/kernel" % (axis, l)] = ("dense_%d" % dense, "dense_%d/kernel:0" % dense)
+            m["%s_dense%d/bias" % (axis, l)] = ("dense_%d" % dense, "dense_%d/bias:0" % dense)
+            for w in ("kernel", "recurrent_kernel", "bias"):
+                m["%s_lstm%d/%s" % (axis, l, w)] = ("time_distributed_%d" % td, "time_distributed_%d/%s:0" % (td, w))
+    for n in ("note_dense", "volume_dense"):
+        m[n + "/kernel"] = (n, n + "/kernel:0")
+        m[n + "/bias"] = (n, n + "/bias:0")
+    return m
+
+
 class HipBackend:
     """The product backend: engines and optimizer state on one MI355X."""
 
@@ -204,7 +234,14 @@ class Model:
         os.replace(tmp, path)
 
     def load_weights(self, path):
-        """Raises on any problem -- util.build_or_load (reference util.py:18-22) catches it."""
+        """Raises on any problem -- util.build_or_load (reference util.py:18-22) catches it, except for a Keras
+        HDF5 file (KerasHDF5Error): h5py is not available here, convert it with tools/convert_keras_h5.py."""
+        with open(path, "rb") as f:
+            if f.read(8) == b"\x89HDF\r\n\x1a\n":
+                raise KerasHDF5Error(
+                    "%s is a Keras HDF5 checkpoint; this build reads .npz weight files with the same tensor layouts. "
+                    "Convert it once with `python tools/convert_keras_h5.py %s %s` (needs h5py)."
+                    % (path, path, os.path.splitext(path)[0] + ".npz"))
         with np.load(path) as z:
             ws = []
             for n, _, shape in self._s.layout:

@@ -17,13 +17,18 @@ def build_or_load(allow_load=True, **build_kwargs):
     """Build the three models with default settings, print the summary and try to
     restore MODEL_FILE; any failure to load is reported and ignored, exactly like the
     reference's bare `except` (util.py:13-23)."""
-    from .model import build_models
+    from .model import KerasHDF5Error, build_models
     models = build_models(**build_kwargs)
     models[0].summary()
     if allow_load:
+        # the reference's own checkpoint name (out/model.h5) is looked at too: a Keras HDF5 file there must not be
+        # ignored silently -- load_weights names the converter
+        legacy = os.path.splitext(MODEL_FILE)[0] + '.h5'
         try:
-            models[0].load_weights(MODEL_FILE)
+            models[0].load_weights(MODEL_FILE if os.path.exists(MODEL_FILE) or not os.path.exists(legacy) else legacy)
             print('Loaded model from file.')
+        except KerasHDF5Error:
+            raise
         except Exception:
             print('Unable to load model from file.')
     return models
