@@ -242,6 +242,88 @@ def generation_bench(dtype, steps):
             "path": "dj_generate_step_resident (hipGraph replay), NumPy MT19937 draws in reference order"}
 
 
+def scaled_bench(args, dev, rank, world, dist):
+    """BASELINE configs[4]: 3 x 1024 units per axis, batch 128 x 256 steps x 128 notes per GPU.  The batch runs as
+    `--micro` equal micro-batches through one workspace with gradient accumulation (dj_train_fwd_bwd_acc) and ONE
+    optimizer step; as with data-parallel ranks, pitch_bins couples samples within a micro-batch only."""
+    from music_generator_amd import _lib
+    from music_generator_amd.data import synthetic_batch
+    from music_generator_amd.engine import DeepJConfig, Engine, Nadam, init_params_numpy
+    B, T, N, micro = 128, 256, 128, args.micro
+    pin, pdr = args.dropout or (0.2, 0.5)
+    cfg = DeepJConfig(num_notes=N, time_steps=T, dtype=args.dtype, time_axis_units=1024, note_axis_units=1024,
+                      time_axis_layers=3, note_axis_layers=3)
+    eng = Engine(cfg, B // micro, T, device=dev, input_dropout=pin, dropout=pdr)
+    P = torch.from_numpy(init_params_numpy(cfg, seed=1234)).to(dev)
+    G = torch.zeros_like(P)
+    opt = Nadam(P.numel(), dev)
+    data = [torch.from_numpy(a).to(dev) for a in synthetic_batch(N, T, B, seed=rank)]
+    k = B // micro
+    parts = [[a[m * k:(m + 1) * k].contiguous() for a in data] for m in range(micro)]
+    lib = _lib.load()
+
+    def step(i):
+        for m in range(micro):
+            loss = eng.train_fwd_bwd(P, G, *parts[m], seed=(i * world + rank) * micro + m, accumulate=m > 0)
+        if world > 1:
+            dist.all_reduce(G)
+        opt.step(P, G, grad_scale=1.0 / (micro * world))
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    lib.dj_profile_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    final_loss = float(loss.cpu()[0])
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.cpu()[0])
+    if not np.isfinite(final_loss):
+        raise SystemExit(f"invalid run: final loss {final_loss}")
+    kernels = {}
+    for c in range(lib.dj_profile_category_count()):
+        ms, n = C.c_double(), C.c_int64()
+        _lib.check(lib.dj_profile_read(c, C.byref(ms), C.byref(n)), "dj_profile_read")
+        kernels[lib.dj_profile_category_name(c).decode()] = round(ms.value / args.steps, 3)
+    lib.dj_profile_enable(0)
+    if rank == 0:
+        fl = category_flops(cfg, B, T, N)
+        flops_step = 3 * (fl["gemm_xw"] + fl["lstm_fwd_time"] + fl["lstm_fwd_note"])
+        tf = flops_step * world * args.steps / elapsed / 1e12
+        dom = max(fl, key=lambda c_: kernels.get(c_, 0.0))
+        dom_tf = fl[dom] / (kernels[dom] * 1e-3) / 1e12 if kernels.get(dom) else 0.0
+        print(json.dumps({
+            "metric": "note-steps/sec (train)", "value": round(world * B * T * N * args.steps / elapsed, 1),
+            "unit": "note-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"scaled biaxial-LSTM train step (BASELINE configs[4]): 3x1024 time-axis + 3x1024 "
+                                   f"note-axis LSTM, batch {B}/GPU as {micro} micro-batches x {T} steps x {N} notes, "
+                                   f"dropout {pin}/{pdr}, Nadam; random-init weights",
+                       "global_batch": B * world, "seq_len": T, "num_notes": N, "parallelism": f"dp{world}",
+                       "micro_batches": micro, "workspace_gib": round(eng.ws_bytes / 2 ** 30, 1)},
+            "model_tflops_per_s": round(tf, 1), "final_loss": round(final_loss, 5),
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(dom_tf, 1), "peak": PEAK_TFLOPS[args.dtype],
+                         "unit": "TFLOP/s", "frac": round(dom_tf / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                         "whole_step_mfma_frac": round(tf / world / PEAK_TFLOPS[args.dtype], 4)},
+            "kernel_ms_per_step": kernels, "cpu_baseline": None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,6 +339,7 @@ def main():
     ap.add_argument("--config", default="baseline", choices=["baseline", "scaled"],
                     help="baseline = BASELINE configs[1] (2x256 + 2x128, B64 T128 N128); scaled = configs[4] "
                          "(3x1024 per axis, B128 T256 N128 as micro-batches)")
+    ap.add_argument("--micro", type=int, default=2, help="micro-batches of the scaled config's batch of 128")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--dropout", type=float, nargs=2, default=None, metavar=("INPUT", "HIDDEN"),
                     help="override the reference's dropout rates 0.2 0.5 (experiments only; the metric uses the defaults)")
@@ -278,6 +361,9 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.config == "scaled":
+        return scaled_bench(args, dev, rank, world, dist)
 
     from music_generator_amd import _lib
     from music_generator_amd.data import synthetic_batch

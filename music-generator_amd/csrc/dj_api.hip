@@ -35,7 +35,7 @@ struct Prof {
   std::vector<hipEvent_t> pool;
   hipEvent_t get() {
     if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
-    hipEvent_t e; hipEventCreate(&e); return e;
+    hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
   }
 } g_prof;
 struct ProfScope {
@@ -43,10 +43,10 @@ struct ProfScope {
   ProfScope(int cat, hipStream_t s) : act(g_prof.on), st(s) {
     if (!act) return;
     hipEvent_t a = g_prof.get(); b = g_prof.get();
-    hipEventRecord(a, st);
+    (void)hipEventRecord(a, st);
     g_prof.recs.push_back({cat, a, b});
   }
-  ~ProfScope() { if (act) hipEventRecord(b, st); }
+  ~ProfScope() { if (act) (void)hipEventRecord(b, st); }
 };
 
 struct LstmP {          // parameter offsets (floats) of one LSTM layer + its style Dense
