@@ -228,12 +228,14 @@ def generation_bench(dtype, steps):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     # ALGORITHMIC HBM bytes of one generated time step: the stateless 128-step window through the time axis
-    # (generate.py:106-109; per row and layer: x in, x W + b out and back in, h out = (D + 9 H) elements; layer 1's
-    # input is a glue copy of layer 0's h: + 2 H) plus one pass over the fp32 weights; the note loop runs out of L2
+    # (generate.py:106-109) plus one pass over the fp32 weights; the note loop runs out of L2.  Per row and layer:
+    # bf16 (x W fused into the weight-stationary cluster sweep): x in, h out = (D + H) elements; fp32 (separate
+    # GEMM): x in, x W + b out and back in, h out = (D + 9 H); layer 1's input is a glue copy of layer 0's h: + 2 H
     K = Gn.__dict__
     rows = 3 * K["NUM_NOTES"] * K["SEQ_LEN"]
     F, Ht, e = 94, K["TIME_AXIS_UNITS"], (2 if dtype == "bf16" else 4)
-    gen_bytes = rows * e * ((F + 9 * Ht) + (Ht + 9 * Ht) + 2 * Ht) + 1269476 * 4
+    zx = 0 if dtype == "bf16" else 8 * Ht
+    gen_bytes = rows * e * ((F + Ht + zx) + (Ht + Ht + zx) + 2 * Ht) + 1269476 * 4
     return {"metric": "gen notes/sec", "value": round(3 * 48 * n / dt, 1), "unit": "notes/sec",
             "ms_per_time_step": round(dt / n * 1e3, 3), "pieces": 3, "notes": 48, "window": 128, "steps": n,
             "dtype": dtype, "hbm_gbs": round(gen_bytes / (dt / n) / 1e9, 1), "hbm_bytes_per_step": gen_bytes,

@@ -207,12 +207,17 @@ struct Ctx {
 // sequence tiles (generation: 5) the chip is idle anyway and the recurrence is a pure latency chain:
 // there the projection stays a separate (parallel) GEMM and the chain carries h*U only.
 // DEEPJ_FUSE_XW_MIN_TILES overrides the tile threshold (tests run the fused kernel on small shapes with it).
+inline bool cluster_enabled();
 inline bool fuse_xw(const LstmP& L) {
   const char* e = getenv("DEEPJ_FUSE_XW_MIN_TILES");
   const int64_t min_tiles = e ? atoll(e) : 128;
   // H = 128 in bf16 keeps U (and W up to H columns) in registers: also the 259-wide note layer 0 is cheaper fused
   const int dmax = (L.H == 128 && L.dtype == DJ_BF16) ? 288 : 2 * L.H;
-  return rec_persistent(L.H) && L.D <= dmax && L.tiles >= min_tiles;
+  if (!rec_persistent(L.H) || L.D > dmax) return false;
+  // bf16 H = 256 with the weight-stationary cluster kernel: W and U never leave LDS, so the fused sweep also wins
+  // the latency chain of a few tiles (generation: 5 tiles x 128 steps streamed 1 MB of weights per step before)
+  if (!e && L.H == 256 && L.dtype == DJ_BF16 && L.DP <= 256 && cluster_enabled()) return true;
+  return L.tiles >= min_tiles;
 }
 
 // DEEPJ_CLUSTER=0 keeps the bf16 H = 256 forward sweep on the per-tile kernel (the host side sets it after a

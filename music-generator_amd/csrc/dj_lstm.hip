@@ -674,7 +674,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
                                                                StashElem<bf16_t>* __restrict__ Zst,
                                                                const bf16_t* __restrict__ Upack,
                                                                bf16_t* __restrict__ Hout, bf16_t* __restrict__ Cout,
-                                                               int steps, int* __restrict__ cl) {
+                                                               int steps, int* __restrict__ cl, int ntiles) {
   using T = bf16_t;
   constexpr int H = 256;
   using R = RecCfg<T, H>;
@@ -685,8 +685,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
   T* hto = (T*)(Bu + 4 * R::NKC * 64);                     // [8 waves] 4 KiB: x transposition rounds / h_t tile
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, s = j & (CL_M - 1);
-  const int cid = xcd + 8 * (j >> 3);                      // cluster id; its tiles are CL_M*cid .. CL_M*cid+7
-  const int64_t tile = (int64_t)CL_M * cid + w;            // this wave's tile
+  const int cid = xcd + 8 * (j >> 3);                      // cluster id
+  // wave w of every member works on tile cid + nclusters * w: a launch with fewer tiles than wave slots (generation:
+  // 5 tiles on 8 clusters) spreads them over the clusters, one wave each, instead of filling one cluster; waves
+  // without a tile only keep the workgroup barriers company
+  const int64_t tile = (int64_t)cid + (int64_t)(gridDim.x >> 3) * w;
+  const bool active = tile < ntiles;
   int* cnt = cl + 2 * cid * CL_CNT_STRIDE;
   int* xccs = cnt + CL_CNT_STRIDE;
   int* fault = cl + CL_CNT_INTS;
@@ -711,9 +715,11 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
   // publishes the XCD it runs on
   const int my_xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15) + 1;   // HW_REG_XCC_ID[3:0]
   {
-    uint4* hxo = hxb + ((tile * 2 + 1) * 16 + 2 * s) * 64 + lane;
-    hxo[0] = make_uint4(0, 0, 0, 0);
-    hxo[64] = make_uint4(0, 0, 0, 0);
+    if (active) {
+      uint4* hxo = hxb + ((tile * 2 + 1) * 16 + 2 * s) * 64 + lane;
+      hxo[0] = make_uint4(0, 0, 0, 0);
+      hxo[64] = make_uint4(0, 0, 0, 0);
+    }
     if (tid == 0) __hip_atomic_store(xccs + s, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -740,8 +746,12 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
   const int xr8 = lane >> 3, xc = lane & 7;
   constexpr int NR = (NKX + 3) / 4, NRA = (NR + 1) / 2;   // rounds; those requested with the h fragments
   ClXRegs<NR> xq;
-  cl_load_x<NR, 0, NR>(xq, X + (tile * steps * 32 + xr8) * DP + xc * 8, DP, xc);
+  if (active) cl_load_x<NR, 0, NR>(xq, X + (tile * steps * 32 + xr8) * DP + xc * 8, DP, xc);
   for (int t = 0; t < steps; ++t) {
+    if (!active) {                 // wave without a tile: the step barrier only (the branch is wave-uniform)
+      __syncthreads();
+      continue;
+    }
     const int64_t rb = tile * steps + t;
     f32x16 acc[4];
 #pragma unroll
@@ -1321,9 +1331,10 @@ int launch_fwd_cluster_k(int ntiles, int steps, const void* X, int DP, const voi
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((lstm_fwd_cluster_kernel<SIGM, NKX>), dim3(ntiles), dim3(512), smem, st, (const bf16_t*)X, DP,
+  // whole groups of 64 blocks = 8 XCDs x 8 members; wave slots beyond ntiles stay idle
+  hipLaunchKernelGGL((lstm_fwd_cluster_kernel<SIGM, NKX>), dim3((ntiles + 63) / 64 * 64), dim3(512), smem, st, (const bf16_t*)X, DP,
                      (const bf16_t*)Wpack, bias, (uint8_t*)Zst, (const bf16_t*)Upack, (bf16_t*)Hout, (bf16_t*)Cout, steps,
-                     (int*)scratch);
+                     (int*)scratch, ntiles);
   return (int)hipGetLastError();
 }
 template <bool SIGM>
@@ -1350,8 +1361,7 @@ int cluster_cus() {
 int launch_fwd_cluster(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
                        void* Zst, const void* Upack, void* Hout, void* Cout, int sigm, void* scratch, hipStream_t st) {
   using R = RecCfg<bf16_t, 256>;
-  // blocks come in groups of 64 = 8 XCDs x 8 members (cluster id = xcd + 8 * group)
-  if (ntiles % 64 || ntiles > 256 || NKX * R::KC > 256 || DP > 256 || DP % 8 || !scratch || ((uintptr_t)scratch & 127))
+  if (ntiles < 1 || ntiles > 256 || NKX * R::KC > 256 || DP > 256 || DP % 8 || !scratch || ((uintptr_t)scratch & 127))
     return 1016;
   const size_t smem = (size_t)(4 * NKX * 64 + 4 * R::NKC * 64) * 16 + (size_t)8 * 4096;
   // counters and XCC ids of every cluster start at zero in every launch (a memset node under graph capture)
@@ -1428,14 +1438,14 @@ int dj_launch_lstm_fwd_fused(int dtype, int H, int ntiles, int steps, const void
                              const void* Wpack, const float* bias, void* Zst, const void* Upack, void* Hout,
                              void* Cout, int sigm, void* cluster_scratch, hipStream_t st) {
   if (ntiles <= 0 || steps <= 0) return 0;
-  // weight-stationary cluster kernel, in launches whose whole grid is co-resident (at most one workgroup per
-  // compute unit) and splits into groups of 8 clusters of 8 tiles; what is left over takes the per-tile kernel
-  if (cluster_scratch && dtype == DJ_BF16 && H == 256 && ntiles >= 64 && (NKX == 8 || NKX == 16) && DP <= 256) {
-    const char* e = getenv("DEEPJ_CLUSTER");
-    const int cap = cluster_cus() < 256 ? cluster_cus() / 64 * 64 : 256;   // groups of 64 = 8 XCDs x 8 members
-    if (!(e && e[0] == '0') && cap >= 64) {
-      while (ntiles >= 64) {
-        const int n = ntiles < cap ? ntiles / 64 * 64 : cap;
+  // weight-stationary cluster kernel (bf16, H = 256), in launches whose whole grid is co-resident (at most one
+  // workgroup per compute unit, groups of 64 blocks = 8 clusters of 8 members); any tile count: a sweep of few tiles
+  // (generation) spreads them over the clusters and still keeps every weight byte in LDS
+  if (cluster_scratch && dtype == DJ_BF16 && H == 256 && (NKX == 8 || NKX == 16) && DP <= 256) {
+    const int cap = cluster_cus() < 256 ? cluster_cus() / 64 * 64 : 256;
+    if (cap >= 64) {
+      while (ntiles > 0) {
+        const int n = ntiles < cap ? ntiles : cap;
         const int rc = launch_fwd_cluster(n, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, sigm, cluster_scratch, st);
         if (rc) return rc;
         const int64_t rows = (int64_t)n * steps * 32;      // all five buffers are tile-major
@@ -1445,7 +1455,7 @@ int dj_launch_lstm_fwd_fused(int dtype, int H, int ntiles, int steps, const void
         if (Cout) Cout = (bf16_t*)Cout + rows * H;
         ntiles -= n;
       }
-      if (ntiles == 0) return 0;
+      return 0;
     }
   }
   DJ_DISPATCH_TH(launch_fwd_fused, ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, sigm, st)
