@@ -494,6 +494,7 @@ struct WgradArgs {
   int64_t rows_per_split;
 };
 constexpr int WG_BK = 32, WG_T = 256, WG_TILE_BYTES = WG_BK * WG_T * 2, WG_STAGE = 2 * WG_TILE_BYTES, WG_NS = 4;
+static_assert((WG_NS & (WG_NS - 1)) == 0, "ring slot counter wraps by masking");
 
 __global__ __launch_bounds__(512) void lstm_wgrad_bf16_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -524,26 +525,52 @@ __global__ __launch_bounds__(512) void lstm_wgrad_bf16_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // this lane's DMA duties per stage: 2 pieces of A and 2 of B (1 KiB = 2 rows of 512 B each)
-  auto issue = [&](int kt) {
-    const int64_t mt = ms + (int64_t)kt * WG_BK;
-    const bool step0 = ((mt >> 5) % a.steps) == 0;
-    unsigned char* sa = smem + (kt % WG_NS) * WG_STAGE;
-    unsigned char* sb = sa + WG_TILE_BYTES;
+  // this lane's DMA duties per stage: 2 pieces of A and 2 of B (1 KiB = 2 rows of 512 B each).  Which operand a
+  // lane feeds (X, Hprev or the zero line) and where never changes, so the source pointers are set up once and
+  // advanced by one stage (32 rows) per issue; the recurrence step of a stage is a counter.  (Recomputing them per
+  // stage -- a 64-bit scalar modulo for the step among other things -- cost ~220 scalar instructions per stage and
+  // wave: at one instruction per wave and 4 cycles that is as long as the stage's 16 MFMAs.)
+  const bf16_t* pa[2];
+  const bf16_t* pb[2];
+  int64_t a_stride[2];
+  bool a_is_h[2];
+  unsigned piece_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int piece = w * 2 + i, row = piece * 2 + (lane >> 5), cp = lane & 31;
+    const int c = cp ^ ((row & 3) << 2);
+    const int vcol = v0 + c * 8;
+    const int64_t m = ms + row;
+    piece_off[i] = (unsigned)piece * 1024u;
+    a_is_h[i] = false;
+    if (vcol < a.DP) {
+      pa[i] = a.X + m * a.DP + vcol;
+      a_stride[i] = (int64_t)WG_BK * a.DP;
+    } else if (vcol < a.DP + a.H) {
+      pa[i] = a.Hs + (m - 32) * a.H + (vcol - a.DP);
+      a_stride[i] = (int64_t)WG_BK * a.H;
+      a_is_h[i] = true;
+    } else {
+      pa[i] = a.zeros;
+      a_stride[i] = 0;
+    }
+    pb[i] = a.dZ + m * a.N + n0 + c * 8;
+  }
+  const int64_t b_stride = (int64_t)WG_BK * a.N;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  int sidx = (int)((ms >> 5) % a.steps), islot = 0;      // recurrence step / ring slot of the next stage to issue
+  auto issue = [&](int) {
+    const bool step0 = sidx == 0;                        // h_{-1} = 0: the Hprev rows of this stage are the zero line
+    const unsigned sa = lds0 + (unsigned)islot * WG_STAGE, sb = sa + WG_TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int piece = w * 2 + i, row = piece * 2 + (lane >> 5), cp = lane & 31;
-      const int c = cp ^ ((row & 3) << 2);
-      const int vcol = v0 + c * 8;
-      const int64_t m = mt + row;
-      const bf16_t* src = a.zeros;
-      if (vcol < a.DP)
-        src = a.X + m * a.DP + vcol;
-      else if (vcol < a.DP + a.H && !step0)
-        src = a.Hs + (m - 32) * a.H + (vcol - a.DP);
-      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(sa) + piece * 1024));
-      glds16(a.dZ + m * a.N + n0 + c * 8, __builtin_amdgcn_readfirstlane(lds_addr(sb) + piece * 1024));
+      glds16((a_is_h[i] && step0) ? a.zeros : pa[i], __builtin_amdgcn_readfirstlane(sa + piece_off[i]));
+      glds16(pb[i], __builtin_amdgcn_readfirstlane(sb + piece_off[i]));
+      pa[i] += a_stride[i];
+      pb[i] += b_stride;
     }
+    islot = (islot + 1) & (WG_NS - 1);
+    if (++sidx == a.steps) sidx = 0;
   };
 
   const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, hgrp = g >> 1, colgrp = g & 1;
@@ -664,25 +691,45 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
   const int nstages = my_tiles * nk;
   const bf16_t* zl = (const bf16_t*)dj_zero_line;
 
-  auto issue = [&](int s) {
-    const int tl = s / nk, kt = s - tl * nk;
-    const int m0 = (mt0 + tl * mstride) * NT2_BM, k0 = kt * NT2_BK;
-    unsigned char* sa = smem + (s % NT2_NS) * NT2_STAGE;
-    unsigned char* sb = sa + NT2_ABYTES;
-    const int rsub = lane >> 3, cp = lane & 7;
+  // DMA stream with counters and per-tile row pointers (see gemm_nt_bf16_wide_kernel): the B rows never change (one
+  // column tile per workgroup), the A rows when the m-tile does
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  const int rsub = lane >> 3, cp = lane & 7;
+  const bf16_t* ra[4];
+  const bf16_t* rb[2];
+  int kza[4], kzb[2];
+  bool va[4], vb[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int piece = w * 4 + i, row = piece * 8 + rsub;
-      const int kk = k0 + ((cp ^ ((row >> 1) & 7)) << 3);
-      const bf16_t* src = (m0 + row < M && kk < K) ? A + rbs_row(m0 + row, a_rbs) * lda + kk : zl;
-      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(sa) + piece * 1024));
+  for (int i = 0; i < 2; ++i) {
+    const int row = (w * 2 + i) * 8 + rsub;
+    kzb[i] = (cp ^ ((row >> 1) & 7)) << 3;
+    vb[i] = n0 + row < N;
+    rb[i] = vb[i] ? Bt + (int64_t)(n0 + row) * ldb + kzb[i] : zl;
+  }
+  int i_tl = 0, i_kt = 0, i_slot = 0;
+  auto issue = [&](int) {
+    if (i_kt == 0) {
+      const int m0 = (mt0 + i_tl * mstride) * NT2_BM;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (w * 4 + i) * 8 + rsub;
+        kza[i] = (cp ^ ((row >> 1) & 7)) << 3;
+        va[i] = m0 + row < M;
+        ra[i] = va[i] ? A + rbs_row(m0 + row, a_rbs) * lda + kza[i] : zl;
+      }
     }
+    const int k0 = i_kt * NT2_BK;
+    const unsigned sa = lds0 + (unsigned)i_slot * NT2_STAGE, sb = sa + NT2_ABYTES;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int piece = w * 2 + i, row = piece * 8 + rsub;
-      const int kk = k0 + ((cp ^ ((row >> 1) & 7)) << 3);
-      const bf16_t* src = (n0 + row < N && kk < K) ? Bt + (int64_t)(n0 + row) * ldb + kk : zl;
-      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(sb) + piece * 1024));
+    for (int i = 0; i < 4; ++i)
+      glds16((va[i] && k0 + kza[i] < K) ? ra[i] + k0 : zl, __builtin_amdgcn_readfirstlane(sa + (unsigned)(w * 4 + i) * 1024u));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      glds16((vb[i] && k0 + kzb[i] < K) ? rb[i] + k0 : zl, __builtin_amdgcn_readfirstlane(sb + (unsigned)(w * 2 + i) * 1024u));
+    if (++i_slot == NT2_NS) i_slot = 0;
+    if (++i_kt == nk) {
+      i_kt = 0;
+      ++i_tl;
     }
   };
 
@@ -697,6 +744,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
   };
   zero_acc();
 
+  int c_tl = 0, c_kt = 0, c_slot = 0;       // (tile, k-tile, ring slot) of the stage being multiplied
   if (nstages > 0) issue(0);
   if (nstages > 1) issue(1);
   for (int s = 0; s < nstages; ++s) {
@@ -706,8 +754,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (s + 2 < nstages) issue(s + 2);
-    const unsigned char* sa = smem + (s % NT2_NS) * NT2_STAGE;
+    const unsigned char* sa = smem + c_slot * NT2_STAGE;
     const unsigned char* sb = sa + NT2_ABYTES;
+    if (++c_slot == NT2_NS) c_slot = 0;
 #pragma unroll
     for (int kc = 0; kc < NT2_BK / 16; ++kc) {
       bf16x8 fa[2], fb[2];
@@ -727,9 +776,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
             dj_mfma(acc[i][j], fb[j], fa[i]);      // C^T block: lane <-> output row, registers <-> columns
         }
     }
-    const int tl = s / nk, kt = s - tl * nk;
-    if (kt == nk - 1) {       // tile finished: epilogue (the next tiles' DMA is already in flight)
-      const int m0 = (mt0 + tl * mstride) * NT2_BM;
+    if (++c_kt == nk) {       // tile finished: epilogue (the next tiles' DMA is already in flight)
+      const int m0 = (mt0 + c_tl * mstride) * NT2_BM;
+      c_kt = 0;
+      ++c_tl;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -781,6 +831,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
 // 16 rows) then touches every bank exactly once.  Tile order: the 32 workgroups of one XCD walk
 // (m-tile, n-tile) pairs n-fastest, so the n-tiles of one A panel run side by side on ONE L2.
 constexpr int NT3_BM = 256, NT3_BN = 256, NT3_BK = 32, NT3_NS = 4;
+static_assert((NT3_NS & (NT3_NS - 1)) == 0, "ring slot counter wraps by masking");
 constexpr int NT3_ABYTES = NT3_BM * NT3_BK * 2, NT3_BBYTES = NT3_BN * NT3_BK * 2, NT3_STAGE = NT3_ABYTES + NT3_BBYTES;
 
 
@@ -807,27 +858,44 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, in
     m0 = (xcd + 8 * (q / ntn)) * NT3_BM;
     n0 = (q % ntn) * NT3_BN;
   };
-  auto issue = [&](int s) {
-    const int tl = s / nk, kt = s - tl * nk;
-    int m0, n0;
-    tile_of(tl, m0, n0);
-    const int k0 = kt * NT3_BK;
-    unsigned char* sa = smem + (s % NT3_NS) * NT3_STAGE;
-    unsigned char* sb = sa + NT3_ABYTES;
-    const int rsub = lane >> 2, cp = lane & 3;
+  // DMA stream: stages are issued strictly in order, so (tile, k-tile) are counters and the per-lane row pointers are
+  // recomputed only when the tile changes (per stage that leaves two pointer adds and a bounds select per piece;
+  // recomputing tile, row and address per stage was ~300 scalar + vector instructions per stage and wave -- as much
+  // issue time as the stage's 16 MFMAs)
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+  const int rsub = lane >> 2, cp = lane & 3;
+  const bf16_t* ra[2];
+  const bf16_t* rb[2];
+  int kz[2];                    // this lane's k offset inside a stage (swizzled 16-byte chunk)
+  bool va[2], vb[2];
+  int i_tl = 0, i_kt = 0, i_slot = 0;
+  auto issue = [&](int) {
+    if (i_kt == 0) {
+      int m0, n0;
+      tile_of(i_tl, m0, n0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int piece = w * 2 + i, row = piece * 16 + rsub;
-      const int kk = k0 + ((cp ^ ((row >> 2) & 3)) << 3);
-      const bf16_t* src = (m0 + row < M && kk < K) ? A + rbs_row(m0 + row, a_rbs) * lda + kk : zl;
-      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(sa) + piece * 1024));
+      for (int i = 0; i < 2; ++i) {
+        const int row = (w * 2 + i) * 16 + rsub;
+        kz[i] = (cp ^ ((row >> 2) & 3)) << 3;
+        va[i] = m0 + row < M;
+        vb[i] = n0 + row < N;
+        ra[i] = va[i] ? A + rbs_row(m0 + row, a_rbs) * lda + kz[i] : zl;
+        rb[i] = vb[i] ? Bt + (int64_t)(n0 + row) * ldb + kz[i] : zl;
+      }
     }
+    const int k0 = i_kt * NT3_BK;
+    const unsigned sa = lds0 + (unsigned)i_slot * NT3_STAGE, sb = sa + NT3_ABYTES;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int piece = w * 2 + i, row = piece * 16 + rsub;
-      const int kk = k0 + ((cp ^ ((row >> 2) & 3)) << 3);
-      const bf16_t* src = (n0 + row < N && kk < K) ? Bt + (int64_t)(n0 + row) * ldb + kk : zl;
-      glds16(src, __builtin_amdgcn_readfirstlane(lds_addr(sb) + piece * 1024));
+      const bool kin = k0 + kz[i] < K;
+      const unsigned po = (unsigned)(w * 2 + i) * 1024u;
+      glds16((va[i] && kin) ? ra[i] + k0 : zl, __builtin_amdgcn_readfirstlane(sa + po));
+      glds16((vb[i] && kin) ? rb[i] + k0 : zl, __builtin_amdgcn_readfirstlane(sb + po));
+    }
+    i_slot = (i_slot + 1) & (NT3_NS - 1);
+    if (++i_kt == nk) {
+      i_kt = 0;
+      ++i_tl;
     }
   };
 
@@ -842,6 +910,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, in
   };
   zero_acc();
 
+  int c_tl = 0, c_kt = 0;       // (tile, k-tile) of the stage being multiplied
   if (nstages > 0) issue(0);
   if (nstages > 1) issue(1);
   if (nstages > 2) issue(2);
@@ -879,10 +948,11 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, in
             dj_mfma(acc[i][j], fb[j], fa[i]);      // C^T block: lane <-> output row, registers <-> columns
         }
     }
-    const int tl = s / nk, kt = s - tl * nk;
-    if (kt == nk - 1) {       // tile finished: epilogue (the next tiles' DMA is already in flight)
+    if (++c_kt == nk) {       // tile finished: epilogue (the next tiles' DMA is already in flight)
       int m0, n0;
-      tile_of(tl, m0, n0);
+      tile_of(c_tl, m0, n0);
+      c_kt = 0;
+      ++c_tl;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
