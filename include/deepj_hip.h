@@ -146,6 +146,12 @@ int32_t dj_generate_step_resident(const dj_config* cfg, const float* params, voi
  * (model.py:84,122) and the BPTT input gradient dX = dZ * W^T. */
 int32_t dj_gemm_nt(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* Bt,
                    int32_t ldb, void* C, int32_t ldc, int32_t c_mode, const float* bias, void* stream);
+/* The same with A COLUMN-TILE-MAJOR (bf16): [K/256][M][256], element (m, k) at A + (k >> 8) * a_tile_stride + m * 256 +
+ * (k & 255), a_tile_stride >= M * 256 elements -- the dZ layout the bf16 BPTT sweep writes (dj_lstm_bwd below), so that
+ * dX = dZ * W^T reads what the sweep wrote. */
+int32_t dj_gemm_nt_tiled_a(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int64_t a_tile_stride,
+                           const void* Bt, int32_t ldb, void* C, int32_t ldc, int32_t c_mode, const float* bias,
+                           void* stream);
 /* C[ka_valid,N] += A[M,Ka]^T * B[M,N] (fp32 atomics).  a_shift = 32 with steps > 0 reads
  * A one recurrence step earlier (zeros at step 0): the recurrent-kernel gradient. */
 int32_t dj_gemm_tn(int32_t dtype, int64_t M, int32_t Ka, int32_t ka_valid, int32_t N, const void* A, int32_t lda,
@@ -154,9 +160,12 @@ int32_t dj_gemm_tn(int32_t dtype, int64_t M, int32_t Ka, int32_t ka_valid, int32
  *   dW[D,N] += X[M,:D]^T dZ   (X row-major [M,DP], DP = D padded to a multiple of 8)
  *   dU[H,N] += Hprev^T dZ     (Hs row-major [M,H]; Hprev = Hs one recurrence step (32 rows)
  *                              earlier within a sequence tile, zero at step 0)
- * `zeros` points at >= 16 zero bytes.  TF autodiff of the Keras LSTM kernels (model.py:84,122). */
+ * `zeros` points at >= 16 zero bytes.  dz_tile_stride: 0 = dZ row-major [M, N]; otherwise dZ is column-tile-major
+ * [N/256][M][256] with that many elements between column tiles (bf16 only; see dj_lstm_bwd).
+ * TF autodiff of the Keras LSTM kernels (model.py:84,122). */
 int32_t dj_lstm_wgrad(int32_t dtype, int64_t M, int32_t steps, const void* X, int32_t DP, int32_t D, const void* Hs,
-                      int32_t H, const void* dZ, int32_t N, float* dW, float* dU, const void* zeros, void* stream);
+                      int32_t H, const void* dZ, int32_t N, int64_t dz_tile_stride, float* dW, float* dU,
+                      const void* zeros, void* stream);
 /* Pack a Keras recurrent_kernel U[H,4H] (fp32) into MFMA B-fragment order for the
  * forward (U) and backward (U^T) recurrences; each output holds H*4H operand elements. */
 int32_t dj_lstm_pack(int32_t dtype, int32_t H, const float* U, void* upack_fwd, void* upack_bwd, void* stream);
@@ -185,10 +194,14 @@ int32_t dj_lstm_fwd_fused(int32_t dtype, int32_t H, int32_t ntiles, int32_t step
                           int32_t D, const void* wpack, const float* bias, void* stash, const void* upack_fwd,
                           void* Hout, void* Cout, int32_t recurrent_sigmoid, void* cluster_scratch, void* stream);
 /* BPTT sweep: Z / C = the forward's gate stash / fragment-tiled cell states; dH = dL/dh
- * per step (row-major [rows, H]); dZ (row-major [rows, 4H]) receives dL/dz;
+ * per step (row-major [rows, H]); dZ receives dL/dz: row-major [rows, 4H] when dz_tile_stride == 0, else
+ * column-tile-major [4H/256][rows][256] with dz_tile_stride (>= rows * 256) elements between column tiles -- there
+ * the 32 rows of a step form one contiguous 16 KiB block per tile, which the weight-gradient GEMM streams per stage
+ * (with row-major dZ its 512-byte pieces at 2 KiB stride were fetched from HBM once per row tile: 1.6x the bytes);
  * dbias[4H] += column sums of dz. */
 int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack_bwd,
-                    const void* C, const void* dH, void* dZ, float* dbias, int32_t recurrent_sigmoid, void* stream);
+                    const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias,
+                    int32_t recurrent_sigmoid, void* stream);
 /* Same sweep that also produces the layer's input gradient dX = dz W^T (row-major [rows, DP], columns
  * D..DP-1 zero) from the dz tile it holds in LDS; W is the Keras kernel [D, 4H], wtpack its fragment stream
  * from dj_lstm_pack_wt (roundup(D, 32) * 4H operand elements).  Replaces one dj_gemm_nt pass over dZ per layer
@@ -197,8 +210,8 @@ int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, con
  * left to dj_gemm_nt; code 1015 otherwise. */
 int32_t dj_lstm_pack_wt(int32_t dtype, int32_t H, const float* W, int32_t D, void* wtpack, void* stream);
 int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack_bwd,
-                       const void* C, const void* dH, void* dZ, float* dbias, int32_t recurrent_sigmoid,
-                       const void* wtpack, int32_t D, void* dX, int32_t DP, void* stream);
+                       const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias,
+                       int32_t recurrent_sigmoid, const void* wtpack, int32_t D, void* dX, int32_t DP, void* stream);
 /* The bf16 H = 256 forward sweep of 64..256 tiles runs as weight-stationary clusters of 8 workgroups that meet
  * once per step through a counter in L2 (dj_lstm.hip).  Their exchange state (counters, the members' XCC ids, the h
  * slices) lives in a caller-owned scratch -- part of the workspace for the dj_train / dj_predict calls, one per

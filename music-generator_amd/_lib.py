@@ -47,16 +47,19 @@ _SIGS = {
     "dj_gemm_tn": (C.c_int32, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32,
                                _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "dj_lstm_wgrad": (C.c_int32, [C.c_int32, C.c_int64, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P,
-                                  C.c_int32, _P, _P, _P, _P]),
+                                  C.c_int32, C.c_int64, _P, _P, _P, _P]),
+    "dj_gemm_nt_tiled_a": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P, C.c_int32, _P,
+                                       C.c_int32, C.c_int32, _P, _P]),
     "dj_lstm_pack": (C.c_int32, [C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "dj_lstm_fwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P]),
     "dj_lstm_stash_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int64]),
     "dj_lstm_pack_w": (C.c_int32, [C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),
     "dj_lstm_fwd_fused": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P, _P,
                                       _P, _P, C.c_int32, _P, _P]),
-    "dj_lstm_bwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P]),
-    "dj_lstm_bwd_dx": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_int32, _P,
-                                   C.c_int32, _P, C.c_int32, _P]),
+    "dj_lstm_bwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int32,
+                                _P]),
+    "dj_lstm_bwd_dx": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int32,
+                                   _P, C.c_int32, _P, C.c_int32, _P]),
     "dj_lstm_pack_wt": (C.c_int32, [C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),
     "dj_lstm_cluster_scratch_bytes": (C.c_int64, []),
     "dj_lstm_cluster_faults": (C.c_int32, [_P]),

@@ -398,15 +398,23 @@ int note_axis_forward(const Ctx& c, int64_t wHin, int in_na, int d_out_site, con
   return 0;
 }
 
+// dZ of a bf16 layer on the persistent kernels is column-tile-major ([4H/256][rows][256]: the 32 rows of a recurrence
+// step are one contiguous 16 KiB block per 256-column tile, which is what the weight-gradient GEMM streams per stage;
+// with row-major dZ its 512-byte pieces at 2 KiB stride were fetched from HBM once per row tile: 1.6x the bytes)
+inline int64_t dz_tile_stride(const Ctx& c, const LstmP& L, int64_t M) {
+  return (c.p.c.dtype == DJ_BF16 && rec_persistent(L.H)) ? M * 256 : 0;
+}
+
 int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int steps, int64_t M, int64_t wX,
                    int64_t wWc, int64_t wWp, int64_t wUb, int64_t wZ, int64_t wH, int64_t wC, int64_t wdH, int64_t wdX,
                    int64_t wdZ, bool is_note) {
   const int dt = c.p.c.dtype;
   const int fdx = fuse_dx(L);
+  const int64_t cts = dz_tile_stride(c, L, M);
   {
     ProfScope ps(is_note ? PC_LSTM_BWD_NOTE : PC_LSTM_BWD_TIME, c.st);
     if (rec_persistent(L.H)) {
-      RUN(dj_launch_lstm_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUb), c.at(wC), c.at(wdH), c.at(wdZ), G + L.b,
+      RUN(dj_launch_lstm_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUb), c.at(wC), c.at(wdH), c.at(wdZ), cts, G + L.b,
                              c.p.c.recurrent_sigmoid, fdx ? c.at(wWp) : nullptr, L.D, fdx ? c.at(wdX) : nullptr, L.DP,
                              c.st));
     } else {
@@ -417,14 +425,15 @@ int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int st
   }
   {
     ProfScope ps(PC_GEMM_DW, c.st);
-    RUN(dj_launch_lstm_wgrad(dt, M, steps, c.at(wX), L.DP, L.D, c.at(wH), L.H, c.at(wdZ), 4 * L.H, G + L.W, G + L.U,
+    RUN(dj_launch_lstm_wgrad(dt, M, steps, c.at(wX), L.DP, L.D, c.at(wH), L.H, c.at(wdZ), 4 * L.H, cts, G + L.W, G + L.U,
                              c.at(c.p.w_zero), c.st));
   }
   if (fdx == 1) return 0;
   const void* Bt = dt == DJ_F32 ? (const void*)(c.P + L.W) : (const void*)c.at(wWc);
   const int ncols = fdx == 2 ? L.D - L.D % 32 : L.D;       // the kernel above already wrote the last column block
   ProfScope ps(PC_GEMM_DX, c.st);
-  RUN(dj_launch_gemm_nt(dt, (int)M, ncols, 4 * L.H, c.at(wdZ), 4 * L.H, Bt, 4 * L.H, c.at(wdX), L.DP, 0, nullptr, c.st));
+  RUN(dj_launch_gemm_nt_ex(dt, (int)M, ncols, 4 * L.H, c.at(wdZ), cts ? 256 : 4 * L.H, 1, cts, Bt, 4 * L.H, c.at(wdX), L.DP,
+                           1, 0, nullptr, c.st));
   return 0;
 }
 
@@ -666,10 +675,12 @@ int32_t dj_note_model_predict(const dj_config* cfg, const float* params, const f
 }
 
 int32_t dj_lstm_wgrad(int32_t dtype, int64_t M, int32_t steps, const void* X, int32_t DP, int32_t D, const void* Hs,
-                      int32_t H, const void* dZ, int32_t N, float* dW, float* dU, const void* zeros, void* stream) {
+                      int32_t H, const void* dZ, int32_t N, int64_t dz_tile_stride, float* dW, float* dU, const void* zeros,
+                      void* stream) {
   if (dtype != DJ_F32 && dtype != DJ_BF16) return 1106;
   if ((M % 32) || steps < 1 || D > DP || !zeros) return 1231;
-  return dj_launch_lstm_wgrad(dtype, M, steps, X, DP, D, Hs, H, dZ, N, dW, dU, zeros, (hipStream_t)stream);
+  if (dz_tile_stride && dz_tile_stride < M * 256) return 1233;
+  return dj_launch_lstm_wgrad(dtype, M, steps, X, DP, D, Hs, H, dZ, N, dz_tile_stride, dW, dU, zeros, (hipStream_t)stream);
 }
 
 int32_t dj_generate_step(const dj_config* cfg, const float* params, const float* notes_win, const float* beat_win,
@@ -782,6 +793,15 @@ int32_t dj_gemm_nt(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A
   if (c_mode < 0 || c_mode > 2) return 1005;
   return dj_launch_gemm_nt(dtype, M, N, K, A, lda, Bt, ldb, C, ldc, c_mode, bias, (hipStream_t)stream);
 }
+int32_t dj_gemm_nt_tiled_a(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int64_t a_tile_stride,
+                           const void* Bt, int32_t ldb, void* C, int32_t ldc, int32_t c_mode, const float* bias,
+                           void* stream) {
+  if (dtype != DJ_BF16) return 1106;
+  if (c_mode < 0 || c_mode > 2) return 1005;
+  if (a_tile_stride < (int64_t)M * 256) return 1233;
+  return dj_launch_gemm_nt_ex(dtype, M, N, K, A, 256, 1, a_tile_stride, Bt, ldb, C, ldc, 1, c_mode, bias,
+                              (hipStream_t)stream);
+}
 int32_t dj_gemm_tn(int32_t dtype, int64_t M, int32_t Ka, int32_t ka_valid, int32_t N, const void* A, int32_t lda,
                    const void* B, int32_t ldb, float* C, int32_t ldc, int32_t a_shift, int32_t steps, void* stream) {
   if (dtype != DJ_F32 && dtype != DJ_BF16) return 1106;
@@ -796,14 +816,16 @@ int32_t dj_lstm_fwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, con
   return dj_launch_lstm_fwd(dtype, H, ntiles, steps, Zx, stash, upack, Hout, Cout, sigm, (hipStream_t)stream);
 }
 int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack,
-                    const void* C, const void* dH, void* dZ, float* dbias, int32_t sigm, void* stream) {
-  return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dbias, sigm, nullptr, 0, nullptr, 0, (hipStream_t)stream);
+                    const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias, int32_t sigm,
+                    void* stream) {
+  return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dz_tile_stride, dbias, sigm, nullptr, 0, nullptr,
+                            0, (hipStream_t)stream);
 }
 int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack,
-                       const void* C, const void* dH, void* dZ, float* dbias, int32_t sigm, const void* wtpack, int32_t D,
-                       void* dX, int32_t DP, void* stream) {
+                       const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias, int32_t sigm,
+                       const void* wtpack, int32_t D, void* dX, int32_t DP, void* stream) {
   if (!wtpack) return 1013;
-  return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dbias, sigm, wtpack, D, dX, DP,
+  return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dz_tile_stride, dbias, sigm, wtpack, D, dX, DP,
                             (hipStream_t)stream);
 }
 int32_t dj_lstm_cluster_faults(void* cluster_scratch) { return dj_lstm_cluster_faults_impl(cluster_scratch); }

@@ -487,7 +487,8 @@ struct WgradArgs {
   const bf16_t* X; int DP, D;        // layer input [M, DP], D valid columns -> dW [D, N]
   const bf16_t* Hs; int H;           // layer output [M, H] (row-major), shifted by 32 rows -> dU [H, N]
   int steps;
-  const bf16_t* dZ; int N;           // [M, N]
+  const bf16_t* dZ; int N;           // [M, N]: element (m, k) at dZ + (k >> 8) * dz_cts + m * ldz + (k & 255)
+  int64_t dz_cts; int ldz;           //   row-major: (256, N); column-tile-major [N/256][M][256]: (M * 256, 256)
   float* dW; float* dU;              // fp32, += (atomics)
   const bf16_t* zeros;               // >= 16 zero bytes
   int ntn, ntiles, xcd_map;
@@ -554,9 +555,9 @@ __global__ __launch_bounds__(512) void lstm_wgrad_bf16_kernel(WgradArgs a) {
       pa[i] = a.zeros;
       a_stride[i] = 0;
     }
-    pb[i] = a.dZ + m * a.N + n0 + c * 8;
+    pb[i] = a.dZ + (int64_t)(n0 >> 8) * a.dz_cts + m * a.ldz + c * 8;
   }
-  const int64_t b_stride = (int64_t)WG_BK * a.N;
+  const int64_t b_stride = (int64_t)WG_BK * a.ldz;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
   int sidx = (int)((ms >> 5) % a.steps), islot = 0;      // recurrence step / ring slot of the next stage to issue
   auto issue = [&](int) {
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
                                                                int lda, const bf16_t* __restrict__ Bt, int ldb,
                                                                TC* __restrict__ C, int ldc,
                                                                const float* __restrict__ bias, int ntn, int ntm,
-                                                               int xcd_map, int a_rbs, int c_rbs) {
+                                                               int xcd_map, int a_rbs, int c_rbs, int64_t a_cts) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
@@ -719,10 +720,12 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
       }
     }
     const int k0 = i_kt * NT2_BK;
+    // A may be column-tile-major (a_cts != 0: element (m, k) at (k >> 8) * a_cts + m * lda + (k & 255), lda = 256)
+    const int64_t ka = a_cts ? (int64_t)(k0 >> 8) * a_cts + (k0 & 255) : k0;
     const unsigned sa = lds0 + (unsigned)i_slot * NT2_STAGE, sb = sa + NT2_ABYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      glds16((va[i] && k0 + kza[i] < K) ? ra[i] + k0 : zl, __builtin_amdgcn_readfirstlane(sa + (unsigned)(w * 4 + i) * 1024u));
+      glds16((va[i] && k0 + kza[i] < K) ? ra[i] + ka : zl, __builtin_amdgcn_readfirstlane(sa + (unsigned)(w * 4 + i) * 1024u));
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       glds16((vb[i] && k0 + kzb[i] < K) ? rb[i] + k0 : zl, __builtin_amdgcn_readfirstlane(sb + (unsigned)(w * 2 + i) * 1024u));
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, in
                                                                 int lda, const bf16_t* __restrict__ Bt, int ldb,
                                                                 TC* __restrict__ C, int ldc,
                                                                 const float* __restrict__ bias, int ntn, int ntm,
-                                                                int a_rbs, int c_rbs) {
+                                                                int a_rbs, int c_rbs, int64_t a_cts) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 2, wc = w & 3;
@@ -884,12 +887,14 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, in
       }
     }
     const int k0 = i_kt * NT3_BK;
+    // A may be column-tile-major (a_cts != 0: element (m, k) at (k >> 8) * a_cts + m * lda + (k & 255), lda = 256)
+    const int64_t ka = a_cts ? (int64_t)(k0 >> 8) * a_cts + (k0 & 255) : k0;
     const unsigned sa = lds0 + (unsigned)i_slot * NT3_STAGE, sb = sa + NT3_ABYTES;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool kin = k0 + kz[i] < K;
       const unsigned po = (unsigned)(w * 2 + i) * 1024u;
-      glds16((va[i] && kin) ? ra[i] + k0 : zl, __builtin_amdgcn_readfirstlane(sa + po));
+      glds16((va[i] && kin) ? ra[i] + ka : zl, __builtin_amdgcn_readfirstlane(sa + po));
       glds16((vb[i] && kin) ? rb[i] + k0 : zl, __builtin_amdgcn_readfirstlane(sb + po));
     }
     i_slot = (i_slot + 1) & (NT3_NS - 1);
@@ -999,12 +1004,19 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, in
 // ------------------------------------------------------------------ launchers (internal C++ API)
 int dj_launch_gemm_nt(int dtype, int M, int N, int K, const void* A, int lda, const void* Bt, int ldb, void* C, int ldc,
                       int c_mode, const float* bias, hipStream_t st) {
-  return dj_launch_gemm_nt_rbs(dtype, M, N, K, A, lda, 1, Bt, ldb, C, ldc, 1, c_mode, bias, st);
+  return dj_launch_gemm_nt_ex(dtype, M, N, K, A, lda, 1, 0, Bt, ldb, C, ldc, 1, c_mode, bias, st);
 }
-
 int dj_launch_gemm_nt_rbs(int dtype, int M, int N, int K, const void* A, int lda, int a_rbs, const void* Bt, int ldb,
                           void* C, int ldc, int c_rbs, int c_mode, const float* bias, hipStream_t st) {
+  return dj_launch_gemm_nt_ex(dtype, M, N, K, A, lda, a_rbs, 0, Bt, ldb, C, ldc, c_rbs, c_mode, bias, st);
+}
+
+// a_cts != 0: A is column-tile-major, [K/256][rows][256] with a_cts elements between column tiles and lda = 256
+// (the dZ layout of the bf16 persistent BPTT kernels); bf16 only
+int dj_launch_gemm_nt_ex(int dtype, int M, int N, int K, const void* A, int lda, int a_rbs, int64_t a_cts, const void* Bt,
+                         int ldb, void* C, int ldc, int c_rbs, int c_mode, const float* bias, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (a_cts && (dtype != DJ_BF16 || lda != 256 || a_rbs != 1)) return 1008;
   if (a_rbs < 1 || c_rbs < 1 || (c_mode == 2 && c_rbs != 1)) return 1006;
   const int epl = dtype == DJ_F32 ? 4 : 8;
   if ((K % epl) || (lda % epl) || (ldb % epl)) return 1001;
@@ -1016,10 +1028,10 @@ int dj_launch_gemm_nt_rbs(int dtype, int M, int N, int K, const void* A, int lda
     if (rem > 0 && rem <= 128 && N > NT3_BN && !c_frag) {
       const int Nw = N - rem;
       const size_t cesz = c_is_f32 ? 4 : 2;
-      int rc = dj_launch_gemm_nt_rbs(dtype, M, Nw, K, A, lda, a_rbs, Bt, ldb, C, ldc, c_rbs, c_mode, bias, st);
+      int rc = dj_launch_gemm_nt_ex(dtype, M, Nw, K, A, lda, a_rbs, a_cts, Bt, ldb, C, ldc, c_rbs, c_mode, bias, st);
       if (rc) return rc;
-      return dj_launch_gemm_nt_rbs(dtype, M, rem, K, A, lda, a_rbs, (const bf16_t*)Bt + (int64_t)Nw * ldb, ldb,
-                                   (char*)C + Nw * cesz, ldc, c_rbs, c_mode, bias ? bias + Nw : nullptr, st);
+      return dj_launch_gemm_nt_ex(dtype, M, rem, K, A, lda, a_rbs, a_cts, (const bf16_t*)Bt + (int64_t)Nw * ldb, ldb,
+                                  (char*)C + Nw * cesz, ldc, c_rbs, c_mode, bias ? bias + Nw : nullptr, st);
     }
     const int ntn3 = (N + NT3_BN - 1) / NT3_BN, ntm3 = (M + NT3_BM - 1) / NT3_BM;
     int grid3 = 256;
@@ -1040,13 +1052,13 @@ int dj_launch_gemm_nt_rbs(int dtype, int M, int N, int K, const void* A, int lda
     if (ldc % 4) return 1007;
     if (c_frag)
       hipLaunchKernelGGL((gemm_nt_bf16_wide_kernel<bf16_t, true>), dim3(grid3), dim3(512), smem, st, M, N, K,
-                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs);
+                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs, a_cts);
     else if (c_is_f32)
       hipLaunchKernelGGL((gemm_nt_bf16_wide_kernel<float, false>), dim3(grid3), dim3(512), smem, st, M, N, K,
-                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs);
+                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs, a_cts);
     else
       hipLaunchKernelGGL((gemm_nt_bf16_wide_kernel<bf16_t, false>), dim3(grid3), dim3(512), smem, st, M, N, K,
-                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs);
+                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs, a_cts);
     return (int)hipGetLastError();
   }
   if (dtype == DJ_BF16) {
@@ -1080,15 +1092,15 @@ int dj_launch_gemm_nt_rbs(int dtype, int M, int N, int K, const void* A, int lda
     if (c_frag)
       hipLaunchKernelGGL((gemm_nt_bf16_dma_kernel<bf16_t, true>), dim3(grid2), dim3(512), smem, st, M, N, K,
                          (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn2, ntm2, xcd_map,
-                         a_rbs, c_rbs);
+                         a_rbs, c_rbs, a_cts);
     else if (c_is_f32)
       hipLaunchKernelGGL((gemm_nt_bf16_dma_kernel<float, false>), dim3(grid2), dim3(512), smem, st, M, N, K,
                          (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn2, ntm2, xcd_map,
-                         a_rbs, c_rbs);
+                         a_rbs, c_rbs, a_cts);
     else
       hipLaunchKernelGGL((gemm_nt_bf16_dma_kernel<bf16_t, false>), dim3(grid2), dim3(512), smem, st, M, N, K,
                          (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn2, ntm2, xcd_map,
-                         a_rbs, c_rbs);
+                         a_rbs, c_rbs, a_cts);
     return (int)hipGetLastError();
   }
   // fp32 (parity mode): register-staged 128 x 128 kernel on v_mfma_f32_32x32x2_f32
@@ -1143,10 +1155,14 @@ int dj_launch_gemm_tn(int dtype, int64_t M, int Ka, int ka_valid, int N, const v
 
 // dW [D,N] += X^T dZ, dU [H,N] += Hprev^T dZ.  bf16: one fused DMA-ring kernel; fp32: two generic launches.
 int dj_launch_lstm_wgrad(int dtype, int64_t M, int steps, const void* X, int DP, int D, const void* Hs, int H,
-                         const void* dZ, int N, float* dW, float* dU, const void* zeros, hipStream_t st) {
+                         const void* dZ, int N, int64_t dz_cts, float* dW, float* dU, const void* zeros, hipStream_t st) {
   if (M <= 0) return 0;
+  if (dz_cts && !(dtype == DJ_BF16 && (N % WG_T) == 0 && (M % 32) == 0 && (DP % 8) == 0 && (H % 8) == 0 && zeros))
+    return 1009;        // the column-tile-major dZ exists for the fused bf16 kernel only
   if (dtype == DJ_BF16 && (N % WG_T) == 0 && (M % 32) == 0 && (DP % 8) == 0 && (H % 8) == 0 && zeros) {
     WgradArgs a;
+    a.dz_cts = dz_cts ? dz_cts : 256;
+    a.ldz = dz_cts ? 256 : N;
     a.M = M; a.X = (const bf16_t*)X; a.DP = DP; a.D = D; a.Hs = (const bf16_t*)Hs; a.H = H; a.steps = steps;
     a.dZ = (const bf16_t*)dZ; a.N = N; a.dW = dW; a.dU = dU; a.zeros = (const bf16_t*)zeros;
     a.ntn = N / WG_T;

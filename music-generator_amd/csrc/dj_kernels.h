@@ -69,10 +69,14 @@ int dj_launch_gemm_nt(int dtype, int M, int N, int K, const void* A, int lda, co
 // same with row-block strides on A and C (dj_gemm.hip rbs_row): per-step views of sequence-tiled buffers
 int dj_launch_gemm_nt_rbs(int dtype, int M, int N, int K, const void* A, int lda, int a_rbs, const void* Bt, int ldb,
                           void* C, int ldc, int c_rbs, int c_mode, const float* bias, hipStream_t st);
+// A column-tile-major (a_cts != 0; bf16, lda = 256): element (m, k) at A + (k >> 8) * a_cts + m * 256 + (k & 255)
+int dj_launch_gemm_nt_ex(int dtype, int M, int N, int K, const void* A, int lda, int a_rbs, int64_t a_cts, const void* Bt,
+                         int ldb, void* C, int ldc, int c_rbs, int c_mode, const float* bias, hipStream_t st);
 int dj_launch_gemm_tn(int dtype, int64_t M, int Ka, int ka_valid, int N, const void* A, int lda, const void* B, int ldb, float* C,
                       int ldc, int a_shift, int steps, hipStream_t st);
+// dz_cts: 0 = dZ row-major [M, N]; else column-tile-major [N/256][M][256] with dz_cts elements between tiles
 int dj_launch_lstm_wgrad(int dtype, int64_t M, int steps, const void* X, int DP, int D, const void* Hs, int H,
-                         const void* dZ, int N, float* dW, float* dU, const void* zeros, hipStream_t st);
+                         const void* dZ, int N, int64_t dz_cts, float* dW, float* dU, const void* zeros, hipStream_t st);
 // dj_lstm.hip
 int dj_launch_lstm_pack(int dtype, int H, const float* U, void* fwd, void* bwd, hipStream_t st);
 // Zx: x W + b of all steps (fragment-tiled, operand dtype); Gst: gate stash out (null = inference; fp32 may alias Zx)
@@ -82,9 +86,10 @@ int dj_launch_lstm_fwd(int dtype, int H, int ntiles, int steps, const void* Zx, 
 int64_t dj_lstm_stash_row_bytes(int dtype, int H);
 // WTpack/D/dX/DP: optional fused input gradient dX = dz W^T (WTpack from dj_launch_lstm_pack_wt; null = off;
 // available where dj_lstm_bwd_has_dx says so)
+// dz_cts: layout of the dZ output, as for dj_launch_lstm_wgrad (0 = row-major [rows, 4H])
 int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* UTpack, const void* C,
-                       const void* dH, void* dZ, float* dbias, int sigm, const void* WTpack, int D, void* dX, int DP,
-                       hipStream_t st);
+                       const void* dH, void* dZ, int64_t dz_cts, float* dbias, int sigm, const void* WTpack, int D, void* dX,
+                       int DP, hipStream_t st);
 int dj_lstm_bwd_has_dx(int dtype, int H, int D);
 int dj_launch_lstm_pack_wt(int dtype, int H, const float* W, int D, void* out, hipStream_t st);
 int dj_lstm_fused_nkx(int dtype, int H, int D);

@@ -879,7 +879,7 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const StashElem<T>* __r
                                                        const T* __restrict__ C, const T* __restrict__ dH,
                                                        T* __restrict__ dZ, float* __restrict__ dbias, int steps,
                                                        const T* __restrict__ WTpack, int NQ, T* __restrict__ dX,
-                                                       int DP) {
+                                                       int DP, int64_t dz_cts, int ldz) {
   using R = RecCfg<T, H>;
   using Frag = typename DjFrag<T>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1072,12 +1072,15 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const StashElem<T>* __r
       if (t > 0) cnext[j].copy_from(cprev[j]);
     }
     lds_barrier();
-    // dz_t tile -> global row-major, coalesced
+    // dz_t tile -> global, coalesced: element (m, k) at dZ + (k >> 8) * dz_cts + m * ldz + (k & 255) -- row-major
+    // (dz_cts 256, ldz 4H) or column-tile-major [4H/256][rows][256] (dz_cts rows * 256, ldz 256), where the 32 rows of
+    // a step are one contiguous 16 KiB block per column tile: what the weight-gradient GEMM streams per stage
     constexpr int VPRZ = 4 * H / R::EPL;
 #pragma unroll 4
     for (int v = tid; v < 32 * VPRZ; v += R::NT) {
       int row = v / VPRZ, cv = (v % VPRZ) * R::EPL;
-      *(uint4*)(dZ + (rb * 32 + row) * (4 * H) + cv) = *(const uint4*)(dzs + row * R::LDZ + cv);
+      *(uint4*)(dZ + (int64_t)(cv >> 8) * dz_cts + (rb * 32 + row) * ldz + (cv & 255)) =
+          *(const uint4*)(dzs + row * R::LDZ + cv);
     }
     if constexpr (DX == 2) {
       const T* apx = dzs + l31 * R::LDZ;
@@ -1216,8 +1219,11 @@ int launch_fwd(int ntiles, int steps, const void* Zx, void* Gst, const void* Upa
 }
 template <typename T, int H, int DX>
 int launch_bwd_x(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
-                 float* dbias, int sigm, const void* WTpack, int NQ, void* dX, int DP, hipStream_t st) {
+                 int64_t dz_cts_in, float* dbias, int sigm, const void* WTpack, int NQ, void* dX, int DP, hipStream_t st) {
   using R = RecCfg<T, H>;
+  const int64_t dz_cts = dz_cts_in ? dz_cts_in : 256;
+  const int ldz = dz_cts_in ? 256 : 4 * H;
+  if (dz_cts_in && dz_cts_in < (int64_t)ntiles * steps * 32 * 256) return 1018;
   size_t smem = BwdUlds<T, H>::offset(DX) + BwdUlds<T, H>::bytes;
   static bool attr_done_dev[DJ_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[dj_current_device()];
@@ -1232,26 +1238,28 @@ int launch_bwd_x(int ntiles, int steps, const void* Z, const void* UTpack, const
   }
   if (sigm)
     hipLaunchKernelGGL((lstm_bwd_kernel<T, H, true, DX>), dim3(ntiles), dim3(R::NT), smem, st, (const StashElem<T>*)Z,
-                       (const T*)UTpack, (const T*)C, (const T*)dH, (T*)dZ, dbias, steps, (const T*)WTpack, NQ, (T*)dX, DP);
+                       (const T*)UTpack, (const T*)C, (const T*)dH, (T*)dZ, dbias, steps, (const T*)WTpack, NQ, (T*)dX, DP,
+                       dz_cts, ldz);
   else
     hipLaunchKernelGGL((lstm_bwd_kernel<T, H, false, DX>), dim3(ntiles), dim3(R::NT), smem, st, (const StashElem<T>*)Z,
-                       (const T*)UTpack, (const T*)C, (const T*)dH, (T*)dZ, dbias, steps, (const T*)WTpack, NQ, (T*)dX, DP);
+                       (const T*)UTpack, (const T*)C, (const T*)dH, (T*)dZ, dbias, steps, (const T*)WTpack, NQ, (T*)dX, DP,
+                       dz_cts, ldz);
   return (int)hipGetLastError();
 }
 template <typename T, int H>
 int launch_bwd(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
-               float* dbias, int sigm, const void* WTpack, int NQ, void* dX, int DP, hipStream_t st) {
+               int64_t dz_cts, float* dbias, int sigm, const void* WTpack, int NQ, void* dX, int DP, hipStream_t st) {
   if (WTpack) {
     if constexpr (RecCfg<T, H>::STATB) {
       if (NQ <= RecCfg<T, H>::NW)                  // one stationary 32-column block per wave: D <= H
-        return launch_bwd_x<T, H, 1>(ntiles, steps, Z, UTpack, C, dH, dZ, dbias, sigm, WTpack, NQ, dX, DP, st);
+        return launch_bwd_x<T, H, 1>(ntiles, steps, Z, UTpack, C, dH, dZ, dz_cts, dbias, sigm, WTpack, NQ, dX, DP, st);
       if (DP < (NQ - 1) * 32 + 4) return 1015;     // remainder mode stores 4 columns of the last block
-      return launch_bwd_x<T, H, 2>(ntiles, steps, Z, UTpack, C, dH, dZ, dbias, sigm, WTpack, NQ, dX, DP, st);
+      return launch_bwd_x<T, H, 2>(ntiles, steps, Z, UTpack, C, dH, dZ, dz_cts, dbias, sigm, WTpack, NQ, dX, DP, st);
     } else {
       return 1015;      // fused dX exists for the stationary-U^T build only (bf16, H = 128)
     }
   }
-  return launch_bwd_x<T, H, 0>(ntiles, steps, Z, UTpack, C, dH, dZ, dbias, sigm, nullptr, 0, nullptr, 0, st);
+  return launch_bwd_x<T, H, 0>(ntiles, steps, Z, UTpack, C, dH, dZ, dz_cts, dbias, sigm, nullptr, 0, nullptr, 0, st);
 }
 template <typename T, int H> int launch_pack_wt(const float* W, int D, int NQ, void* out, hipStream_t st) {
   int n = NQ * 32 * 4 * H;
@@ -1392,12 +1400,12 @@ int dj_launch_lstm_fwd(int dtype, int H, int ntiles, int steps, const void* Zx, 
 int64_t dj_lstm_stash_row_bytes(int dtype, int H) { return (int64_t)4 * H * (dtype == DJ_F32 ? 4 : 1); }
 int64_t dj_lstm_cluster_scratch_bytes_impl() { return (int64_t)CL_BYTES; }
 int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* UTpack, const void* C,
-                       const void* dH, void* dZ, float* dbias, int sigm, const void* WTpack, int D, void* dX, int DP,
-                       hipStream_t st) {
+                       const void* dH, void* dZ, int64_t dz_cts, float* dbias, int sigm, const void* WTpack, int D, void* dX,
+                       int DP, hipStream_t st) {
   if (ntiles <= 0 || steps <= 0) return 0;
   const int NQ = (D + 31) / 32;
   if (WTpack && (!dX || D < 1 || DP < 8 || (DP % 8) || NQ * 32 < DP)) return 1013;
-  DJ_DISPATCH_TH(launch_bwd, ntiles, steps, Z, UTpack, C, dH, dZ, dbias, sigm, WTpack, NQ, dX, DP, st)
+  DJ_DISPATCH_TH(launch_bwd, ntiles, steps, Z, UTpack, C, dH, dZ, dz_cts, dbias, sigm, WTpack, NQ, dX, DP, st)
 }
 // does the BPTT kernel of this (dtype, H) offer the fused input gradient?
 // 1: the whole dX (D <= H); 2: only the last 32-column block, for inputs whose width is 1..4 columns past a

@@ -127,6 +127,13 @@ def test_gemm_nt(gpu_device, dtype, M, N, K):
     torch.testing.assert_close(Cd.float().cpu()[:, :N], ref, rtol=rt, atol=at * K ** 0.5)
     if ldc > N:
         assert float(Cd[:, N:].abs().max()) == 0.0
+    if dtype == "bf16" and K % 256 == 0:
+        # A column-tile-major [K/256][M][256] (the BPTT sweep's dZ): same product
+        At = Ad.reshape(M, K // 256, 256).permute(1, 0, 2).contiguous()
+        Ct = torch.zeros_like(Cd)
+        L.check(lib.dj_gemm_nt_tiled_a(DT[dtype], M, N, K, L.ptr(At), M * 256, L.ptr(Bd), K, L.ptr(Ct), ldc, 0,
+                                       L.ptr(bias.to(gpu_device)), _st()), "gemm_nt tiled A")
+        assert torch.equal(Ct, Cd)
     if M % 32 == 0 and N % 32 == 0:
         Cf = torch.zeros(M * N, dtype=Ad.dtype, device=gpu_device)
         L.check(lib.dj_gemm_nt(DT[dtype], M, N, K, L.ptr(Ad), K, L.ptr(Bd), K, L.ptr(Cf), N, 2,
@@ -174,8 +181,19 @@ def test_lstm_wgrad_fused(gpu_device, dtype, tiles, steps, DP, D, H, N):
     dW = torch.full((D, N), 0.25, dtype=torch.float32, device=gpu_device)
     dU = torch.full((H, N), -0.5, dtype=torch.float32, device=gpu_device)
     zeros = torch.zeros(64, dtype=torch.float32, device=gpu_device)
-    L.check(lib.dj_lstm_wgrad(DT[dtype], M, steps, L.ptr(Xd), DP, D, L.ptr(Hd), H, L.ptr(Zd), N, L.ptr(dW), L.ptr(dU),
+    L.check(lib.dj_lstm_wgrad(DT[dtype], M, steps, L.ptr(Xd), DP, D, L.ptr(Hd), H, L.ptr(Zd), N, 0, L.ptr(dW), L.ptr(dU),
                               L.ptr(zeros), _st()), "wgrad")
+    if dtype == "bf16":
+        # the same product from a column-tile-major dZ ([N/256][M][256]; what the bf16 BPTT sweep writes)
+        Zt = Zd.reshape(M, N // 256, 256).permute(1, 0, 2).contiguous()
+        dW2, dU2 = torch.full_like(dW, 0.25), torch.full_like(dU, -0.5)
+        L.check(lib.dj_lstm_wgrad(DT[dtype], M, steps, L.ptr(Xd), DP, D, L.ptr(Hd), H, L.ptr(Zt), N, M * 256, L.ptr(dW2),
+                                  L.ptr(dU2), L.ptr(zeros), _st()), "wgrad tiled")
+        torch.testing.assert_close(dW2, dW, rtol=1e-5, atol=1e-4)       # same products, atomics in another order
+        torch.testing.assert_close(dU2, dU, rtol=1e-5, atol=1e-4)
+    else:
+        assert lib.dj_lstm_wgrad(DT[dtype], M, steps, L.ptr(Xd), DP, D, L.ptr(Hd), H, L.ptr(Zd), N, M * 256, L.ptr(dW),
+                                 L.ptr(dU), L.ptr(zeros), _st()) >= 1000
     Hp = torch.zeros(M, H)
     Hp[32:] = Hd.float().cpu()[:-32]
     Hp[((torch.arange(M) // 32) % steps) == 0] = 0
@@ -248,8 +266,18 @@ def test_lstm_fwd_bwd(gpu_device, dtype, H, S, Ls, sigm):
     dHd = _op(to_rows(dH)[0], dtype).to(gpu_device)
     db = torch.zeros(4 * H, dtype=torch.float32, device=gpu_device)
     dZd = torch.zeros(R, 4 * H, dtype=Zd.dtype, device=gpu_device)
-    L.check(lib.dj_lstm_bwd(DT[dtype], H, tiles, Ls, L.ptr(Gd), L.ptr(upb), L.ptr(Cd), L.ptr(dHd), L.ptr(dZd),
+    L.check(lib.dj_lstm_bwd(DT[dtype], H, tiles, Ls, L.ptr(Gd), L.ptr(upb), L.ptr(Cd), L.ptr(dHd), L.ptr(dZd), 0,
                             L.ptr(db), sigm, _st()), "bwd")
+    # column-tile-major dZ ([4H/256][rows][256], with slack between the tiles): the same numbers elsewhere
+    cts = R * 256 + 512
+    dZt = torch.zeros((4 * H // 256) * cts, dtype=Zd.dtype, device=gpu_device)
+    db2 = torch.zeros_like(db)
+    L.check(lib.dj_lstm_bwd(DT[dtype], H, tiles, Ls, L.ptr(Gd), L.ptr(upb), L.ptr(Cd), L.ptr(dHd), L.ptr(dZt), cts,
+                            L.ptr(db2), sigm, _st()), "bwd tiled")
+    back = dZt.reshape(4 * H // 256, cts)[:, :R * 256].reshape(4 * H // 256, R, 256).permute(1, 0, 2).reshape(R, 4 * H)
+    assert torch.equal(back, dZd)
+    assert lib.dj_lstm_bwd(DT[dtype], H, tiles, Ls, L.ptr(Gd), L.ptr(upb), L.ptr(Cd), L.ptr(dHd), L.ptr(dZt), R * 256 - 1,
+                           L.ptr(db2), sigm, _st()) >= 1000
     dz = from_rows(dZd.float().cpu(), S, Ls)
     torch.testing.assert_close(dz, zx_ref.grad, rtol=rt * 2, atol=at * 5)
     torch.testing.assert_close(db.cpu(), zx_ref.grad.sum(dim=(0, 1)), rtol=rt * 2, atol=at * 20)
@@ -372,7 +400,7 @@ def test_lstm_bwd_fused_input_gradient(gpu_device, D):
     dZ = torch.zeros(R, 4 * H, dtype=torch.bfloat16, device=gpu_device)
     dX = torch.full((R, DP), 7.0, dtype=torch.bfloat16, device=gpu_device)
     db = torch.zeros(4 * H, device=gpu_device)
-    L.check(lib.dj_lstm_bwd_dx(1, H, tiles, Ls, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ), L.ptr(db), 0,
+    L.check(lib.dj_lstm_bwd_dx(1, H, tiles, Ls, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ), 0, L.ptr(db), 0,
                                L.ptr(wt), D, L.ptr(dX), DP, _st()), "bwd_dx")
     assert float(dZ.float().abs().max()) > 0
     ref = dZ.float().cpu() @ W.to(torch.bfloat16).float().cpu().T
@@ -382,7 +410,7 @@ def test_lstm_bwd_fused_input_gradient(gpu_device, D):
         assert float(got[:, D:].abs().max()) == 0.0
     # the same sweep without the fused gradient writes the same dZ
     dZ2 = torch.zeros_like(dZ); db2 = torch.zeros_like(db)
-    L.check(lib.dj_lstm_bwd(1, H, tiles, Ls, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ2), L.ptr(db2), 0,
+    L.check(lib.dj_lstm_bwd(1, H, tiles, Ls, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ2), 0, L.ptr(db2), 0,
                             _st()), "bwd")
     assert torch.equal(dZ, dZ2)
 
@@ -408,7 +436,7 @@ def test_lstm_bwd_remainder_input_gradient(gpu_device):
     dZ = torch.zeros(R, 4 * H, dtype=torch.bfloat16, device=gpu_device)
     dX = torch.full((R, DP), 7.0, dtype=torch.bfloat16, device=gpu_device)
     db = torch.zeros(4 * H, device=gpu_device)
-    L.check(lib.dj_lstm_bwd_dx(1, H, tiles, Ls, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ), L.ptr(db), 0,
+    L.check(lib.dj_lstm_bwd_dx(1, H, tiles, Ls, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ), 0, L.ptr(db), 0,
                                L.ptr(wt), D, L.ptr(dX), DP, _st()), "bwd_dx")
     ref = dZ.float().cpu() @ W.to(torch.bfloat16).float().cpu().T          # [R, 259]
     got = dX.float().cpu()

@@ -28,6 +28,6 @@ for H in (128, 256):
         dH = (torch.randn(R * H, device=dev) * 0.1).to(torch.bfloat16)
         dZ = torch.zeros(R * 4 * H, dtype=torch.bfloat16, device=dev); db = torch.zeros(4 * H, device=dev)
         f = t_ms(lambda: _lib.check(lib.dj_lstm_fwd(1, H, tiles, steps, p(Z), p(G8), p(upf), p(Hd), p(Cd), 0, st()), "fwd"))
-        b = t_ms(lambda: _lib.check(lib.dj_lstm_bwd(1, H, tiles, steps, p(G8), p(upb), p(Cd), p(dH), p(dZ), p(db), 0, st()), "bwd"))
+        b = t_ms(lambda: _lib.check(lib.dj_lstm_bwd(1, H, tiles, steps, p(G8), p(upb), p(Cd), p(dH), p(dZ), 0, p(db), 0, st()), "bwd"))
         print(f"H={H} tiles={tiles}: fwd {f:.3f} ms  bwd {b:.3f} ms", flush=True)
         del Z, G8, Hd, Cd, dH, dZ
