@@ -560,65 +560,109 @@ __global__ __launch_bounds__(512) void lstm_wgrad_bf16_kernel(WgradArgs a) {
   const int64_t b_stride = (int64_t)WG_BK * a.ldz;
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
   int sidx = (int)((ms >> 5) % a.steps), islot = 0;      // recurrence step / ring slot of the next stage to issue
-  auto issue = [&](int) {
+  // one A piece + one B piece of the next stage (i = 0, 1: the stage's two halves)
+  auto dma_pair = [&](int i) {
     const bool step0 = sidx == 0;                        // h_{-1} = 0: the Hprev rows of this stage are the zero line
     const unsigned sa = lds0 + (unsigned)islot * WG_STAGE, sb = sa + WG_TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      glds16((a_is_h[i] && step0) ? a.zeros : pa[i], __builtin_amdgcn_readfirstlane(sa + piece_off[i]));
-      glds16(pb[i], __builtin_amdgcn_readfirstlane(sb + piece_off[i]));
-      pa[i] += a_stride[i];
-      pb[i] += b_stride;
-    }
+    glds16((a_is_h[i] && step0) ? a.zeros : pa[i], __builtin_amdgcn_readfirstlane(sa + piece_off[i]));
+    glds16(pb[i], __builtin_amdgcn_readfirstlane(sb + piece_off[i]));
+    pa[i] += a_stride[i];
+    pb[i] += b_stride;
+  };
+  auto dma_advance = [&]() {
     islot = (islot + 1) & (WG_NS - 1);
     if (++sidx == a.steps) sidx = 0;
+  };
+  auto issue = [&](int) {
+    dma_pair(0);
+    dma_pair(1);
+    dma_advance();
   };
 
   const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, hgrp = g >> 1, colgrp = g & 1;
   const int rowl = 8 * hgrp + q, chl = 2 * colgrp + (p >> 1), sub = (p & 1) * 8;
-  auto compute = [&](int kt) {
+  // operand fragments of one half stage (16 of the 32 k-rows): 2 A blocks + 4 B blocks, transposed LDS reads
+  struct Half { TrFrag a[2], b[4]; };
+  auto read_half = [&](int kt, int ks) {
+    Half f;
     const unsigned char* sa = smem + (kt % WG_NS) * WG_STAGE;
     const unsigned char* sb = sa + WG_TILE_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      TrFrag fa[2], fb[4];
+    for (int rd = 0; rd < 2; ++rd) {
+      const int row = 16 * ks + 4 * rd + rowl;
 #pragma unroll
-      for (int rd = 0; rd < 2; ++rd) {
-        const int row = 16 * ks + 4 * rd + rowl;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const int c = ((wr * 64 + mi * 32) >> 3) + chl;
-          fa[mi].h[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)(sa + row * (WG_T * 2) + ((c ^ (q << 2)) << 4) + sub));
-        }
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int c = ((wc * 128 + ni * 32) >> 3) + chl;
-          fb[ni].h[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (s16x4 __attribute__((address_space(3)))*)(sb + row * (WG_T * 2) + ((c ^ (q << 2)) << 4) + sub));
-        }
+      for (int mi = 0; mi < 2; ++mi) {
+        const int c = ((wr * 64 + mi * 32) >> 3) + chl;
+        f.a[mi].h[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4 __attribute__((address_space(3)))*)(sa + row * (WG_T * 2) + ((c ^ (q << 2)) << 4) + sub));
       }
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) dj_mfma(acc[mi][ni], fa[mi].v, fb[ni].v);
+      for (int ni = 0; ni < 4; ++ni) {
+        const int c = ((wc * 128 + ni * 32) >> 3) + chl;
+        f.b[ni].h[rd] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4 __attribute__((address_space(3)))*)(sb + row * (WG_T * 2) + ((c ^ (q << 2)) << 4) + sub));
+      }
     }
+    return f;
+  };
+  // 8 MFMAs of one half stage with one DMA pair (an A piece + a B piece of a later stage) issued between them: a
+  // global_load_lds costs its wave ~120 cycles of issue time, under the MFMAs it is free
+  auto mma_half = [&](const Half& f, bool dma, int pair) {
+    __builtin_amdgcn_sched_barrier(0);
+    dj_mfma(acc[0][0], f.a[0].v, f.b[0].v);
+    dj_mfma(acc[0][1], f.a[0].v, f.b[1].v);
+    __builtin_amdgcn_sched_barrier(0);
+    if (dma) dma_pair(pair);
+    __builtin_amdgcn_sched_barrier(0);
+    dj_mfma(acc[0][2], f.a[0].v, f.b[2].v);
+    dj_mfma(acc[0][3], f.a[0].v, f.b[3].v);
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) dj_mfma(acc[1][ni], f.a[1].v, f.b[ni].v);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
+  // Software pipeline at half-stage granularity (cycle stamps of the plain loop -- every wave reading, then every
+  // wave multiplying, behind one barrier per stage, the four DMA instructions in a block of their own -- showed the
+  // MFMA pipe busy for 1.0 k of a stage's 2.2 k cycles): the LDS reads of one half stage fly under the MFMAs of the
+  // previous half, and the DMA of a later stage is issued between those MFMAs.  All four ring slots are filled before
+  // the loop; slot kt % 4 is refilled with stage kt+4 as soon as every wave holds its last fragment of stage kt.
+  //   stage kt:  read(kt, half 1) | MFMA(half 0) + DMA pair 1 of stage kt+3 | stage kt+1 landed? (counted vmcnt) |
+  //              own reads of slot kt done (lgkmcnt 0) | barrier | read(kt+1, half 0) | MFMA(half 1) + DMA pair 0 of
+  //              stage kt+4
+  // RAW: a stage is read only behind the counted wait that retires its DMA AND the barrier after it.  WAR: a slot is
+  // refilled only behind the barrier every wave passes after its lgkmcnt(0).  The counted wait: the DMAs younger than
+  // stage kt+1 are those of stages kt+2 and kt+3 (4 per stage and wave, both pairs of kt+3 issued by then).
 #pragma unroll
-  for (int s = 0; s < WG_NS - 1; ++s)
+  for (int s = 0; s < WG_NS; ++s)
     if (s < nkt) issue(s);
+  if (nkt >= 4)
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (nkt == 3)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nkt == 2)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  Half f0 = read_half(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
-    const int rem = nkt - 1 - kt;            // stages issued after kt that may still be in flight: min(rem, NS-2)
-    if (rem >= 2)
+    Half f1 = read_half(kt, 1);
+    const bool second = kt >= 1 && kt + 3 < nkt;       // second pair of stage kt+3 (its first went out last iteration)
+    mma_half(f0, second, 1);
+    if (second) dma_advance();
+    const int rem = nkt - 1 - kt;                      // stages after kt
+    if (rem >= 3)
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (rem >= 1)
+    else if (rem == 2)
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the builtin, not inline asm: hipcc then knows that f1 has arrived and does not make MFMA(f1) wait for the
+    // reads of the next half stage (its own lgkmcnt bookkeeping saturates at 15 outstanding operations)
+    __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0), vmcnt / expcnt untouched
     __builtin_amdgcn_s_barrier();
-    if (kt + WG_NS - 1 < nkt) issue(kt + WG_NS - 1);
-    compute(kt);
+    if (rem >= 1) f0 = read_half(kt + 1, 0);
+    mma_half(f1, kt + 4 < nkt, 0);                     // first pair of stage kt+4 into the slot just vacated
   }
 
   const int l31 = lane & 31;
@@ -872,36 +916,41 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, in
   int kz[2];                    // this lane's k offset inside a stage (swizzled 16-byte chunk)
   bool va[2], vb[2];
   int i_tl = 0, i_kt = 0, i_slot = 0;
-  auto issue = [&](int) {
-    if (i_kt == 0) {
+  // one A piece + one B piece (i = 0, 1) of the stage the DMA stream stands at; dma_advance() moves it on
+  auto dma_pair = [&](int i) {
+    if (i_kt == 0 && i == 0) {
       int m0, n0;
       tile_of(i_tl, m0, n0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = (w * 2 + i) * 16 + rsub;
-        kz[i] = (cp ^ ((row >> 2) & 3)) << 3;
-        va[i] = m0 + row < M;
-        vb[i] = n0 + row < N;
-        ra[i] = va[i] ? A + rbs_row(m0 + row, a_rbs) * lda + kz[i] : zl;
-        rb[i] = vb[i] ? Bt + (int64_t)(n0 + row) * ldb + kz[i] : zl;
+      for (int ii = 0; ii < 2; ++ii) {
+        const int row = (w * 2 + ii) * 16 + rsub;
+        kz[ii] = (cp ^ ((row >> 2) & 3)) << 3;
+        va[ii] = m0 + row < M;
+        vb[ii] = n0 + row < N;
+        ra[ii] = va[ii] ? A + rbs_row(m0 + row, a_rbs) * lda + kz[ii] : zl;
+        rb[ii] = vb[ii] ? Bt + (int64_t)(n0 + row) * ldb + kz[ii] : zl;
       }
     }
     const int k0 = i_kt * NT3_BK;
     // A may be column-tile-major (a_cts != 0: element (m, k) at (k >> 8) * a_cts + m * lda + (k & 255), lda = 256)
     const int64_t ka = a_cts ? (int64_t)(k0 >> 8) * a_cts + (k0 & 255) : k0;
     const unsigned sa = lds0 + (unsigned)i_slot * NT3_STAGE, sb = sa + NT3_ABYTES;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool kin = k0 + kz[i] < K;
-      const unsigned po = (unsigned)(w * 2 + i) * 1024u;
-      glds16((va[i] && kin) ? ra[i] + ka : zl, __builtin_amdgcn_readfirstlane(sa + po));
-      glds16((vb[i] && kin) ? rb[i] + k0 : zl, __builtin_amdgcn_readfirstlane(sb + po));
-    }
+    const bool kin = k0 + kz[i] < K;
+    const unsigned po = (unsigned)(w * 2 + i) * 1024u;
+    glds16((va[i] && kin) ? ra[i] + ka : zl, __builtin_amdgcn_readfirstlane(sa + po));
+    glds16((vb[i] && kin) ? rb[i] + k0 : zl, __builtin_amdgcn_readfirstlane(sb + po));
+  };
+  auto dma_advance = [&]() {
     i_slot = (i_slot + 1) & (NT3_NS - 1);
     if (++i_kt == nk) {
       i_kt = 0;
       ++i_tl;
     }
+  };
+  auto issue = [&](int) {
+    dma_pair(0);
+    dma_pair(1);
+    dma_advance();
   };
 
   f32x16 acc[4][2];
@@ -916,43 +965,79 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, in
   zero_acc();
 
   int c_tl = 0, c_kt = 0;       // (tile, k-tile) of the stage being multiplied
-  if (nstages > 0) issue(0);
-  if (nstages > 1) issue(1);
-  if (nstages > 2) issue(2);
-  for (int s = 0; s < nstages; ++s) {
-    if (s + 2 < nstages)
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (s + 1 < nstages)
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (s + 3 < nstages) issue(s + 3);
+  // operand fragments of one half stage (16 of the 32 k): 4 A row blocks + 2 B row blocks
+  struct Half { bf16x8 a[4], b[2]; };
+  auto read_half = [&](int s, int kc) {
+    Half f;
     const unsigned char* sa = smem + (s % NT3_NS) * NT3_STAGE;
     const unsigned char* sb = sa + NT3_ABYTES;
 #pragma unroll
-    for (int kc = 0; kc < NT3_BK / 16; ++kc) {
-      bf16x8 fa[4], fb[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ra = wr * 128 + i * 32 + l31;
-        fa[i] = *(const bf16x8*)(sa + ra * 64 + (((2 * kc + h) ^ ((ra >> 2) & 3)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int rb = wc * 64 + j * 32 + l31;
-        fb[j] = *(const bf16x8*)(sb + rb * 64 + (((2 * kc + h) ^ ((rb >> 2) & 3)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if constexpr (CFRAG)
-            dj_mfma(acc[i][j], fa[i], fb[j]);
-          else
-            dj_mfma(acc[i][j], fb[j], fa[i]);      // C^T block: lane <-> output row, registers <-> columns
-        }
+    for (int i = 0; i < 4; ++i) {
+      const int ra_ = wr * 128 + i * 32 + l31;
+      f.a[i] = *(const bf16x8*)(sa + ra_ * 64 + (((2 * kc + h) ^ ((ra_ >> 2) & 3)) << 4));
     }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rb_ = wc * 64 + j * 32 + l31;
+      f.b[j] = *(const bf16x8*)(sb + rb_ * 64 + (((2 * kc + h) ^ ((rb_ >> 2) & 3)) << 4));
+    }
+    return f;
+  };
+  auto mm = [&](f32x16& c, const bf16x8& fa, const bf16x8& fb) {
+    if constexpr (CFRAG)
+      dj_mfma(c, fa, fb);
+    else
+      dj_mfma(c, fb, fa);          // C^T block: lane <-> output row, registers <-> columns
+  };
+  // 8 MFMAs of one half stage with one DMA pair of a later stage issued between them (lstm_wgrad_bf16_kernel)
+  auto mma_half = [&](const Half& f, bool dma, int pair) {
+    __builtin_amdgcn_sched_barrier(0);
+    mm(acc[0][0], f.a[0], f.b[0]);
+    mm(acc[0][1], f.a[0], f.b[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (dma) dma_pair(pair);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) mm(acc[i][j], f.a[i], f.b[j]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // Half-stage software pipeline, the template of lstm_wgrad_bf16_kernel: LDS reads of one half stage under the MFMAs
+  // of the previous half, DMA of later stages between the MFMAs, all four ring slots filled up front.
+  //   stage s:  read(s, half 1) | MFMA(half 0) + DMA pair 1 of stage s+3 | stage s+1 landed? (counted vmcnt) | own
+  //             reads done (lgkmcnt 0) | barrier | read(s+1, half 0) | MFMA(half 1) + DMA pair 0 of stage s+4 | epilogue
+  //             if the tile is complete (its stores count in vmcnt behind the DMAs: the next wait over-waits, never under)
+#pragma unroll
+  for (int s = 0; s < NT3_NS; ++s)
+    if (s < nstages) issue(s);
+  if (nstages >= 4)
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (nstages == 3)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nstages == 2)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  Half f0;
+  if (nstages > 0) f0 = read_half(0, 0);
+  for (int s = 0; s < nstages; ++s) {
+    Half f1 = read_half(s, 1);
+    const bool second = s >= 1 && s + 3 < nstages;     // second pair of stage s+3 (its first went out last iteration)
+    mma_half(f0, second, 1);
+    if (second) dma_advance();
+    const int rem = nstages - 1 - s;                   // stages after s
+    if (rem >= 3)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (rem == 2)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0) as a builtin: hipcc then knows f1 has arrived
+    __builtin_amdgcn_s_barrier();
+    if (rem >= 1) f0 = read_half(s + 1, 0);
+    mma_half(f1, s + 4 < nstages, 0);                  // first pair of stage s+4 into the slot just vacated
     if (++c_kt == nk) {       // tile finished: epilogue (the next tiles' DMA is already in flight)
       int m0, n0;
       tile_of(c_tl, m0, n0);
