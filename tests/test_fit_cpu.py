@@ -200,3 +200,48 @@ def test_checkpoint_name_map_and_hdf5_detection(tmp_path, monkeypatch, capsys):
     os.remove(os.path.join("out", "model.h5"))
     util.build_or_load(backend=OracleBackend(), time_steps=4, config=DeepJConfig(**TINY))
     assert "Unable to load model from file." in capsys.readouterr().out
+
+
+def test_cluster_fault_repeats_the_step_on_the_per_tile_kernel(monkeypatch, capsys):
+    """A cluster fault (expired wait / misplaced cluster, include/deepj_hip.h) makes the step's numbers NaN.  The
+    host side must notice BEFORE the optimizer step, switch to the per-tile kernel (DEEPJ_CLUSTER=0) and repeat the
+    step, so that the result equals a fault-free step; a fault with the cluster kernel already off is an error."""
+    os.environ.pop("DEEPJ_CLUSTER", None)
+    x, y = _data(2)
+
+    def run(faulty):
+        model, _, _ = _tiny_models(input_dropout=0.0, dropout=0.0)
+        calls = {"n": 0}
+        orig_engine = model._s.backend.engine
+
+        def engine(*a, **k):
+            e = orig_engine(*a, **k)
+            def cluster_faults():
+                calls["n"] += 1
+                return 3 if (faulty and calls["n"] == 1) else 0
+            e.cluster_faults = cluster_faults
+            return e
+        model._s.backend.engine = engine
+        loss = model.train_on_batch(x, y)
+        return loss, model.get_weights(), calls["n"]
+
+    l0, w0, n0 = run(False)
+    assert n0 == 1 and os.environ.get("DEEPJ_CLUSTER") is None
+    l1, w1, n1 = run(True)
+    assert n1 == 2 and os.environ.get("DEEPJ_CLUSTER") == "0"
+    assert "falling back to the per-tile kernel" in capsys.readouterr().out
+    assert l1 == l0 and all(np.array_equal(a, b) for a, b in zip(w0, w1))
+    # cluster kernel already disabled and still a fault: not recoverable
+    model, _, _ = _tiny_models(input_dropout=0.0, dropout=0.0)
+    orig_engine = model._s.backend.engine
+
+    def bad_engine(*a, **k):
+        e = orig_engine(*a, **k)
+        e.cluster_faults = lambda: 1
+        return e
+    model._s.backend.engine = bad_engine
+    before = [w.copy() for w in model.get_weights()]
+    with pytest.raises(RuntimeError, match="cluster faults"):
+        model.train_on_batch(x, y)
+    assert all(np.array_equal(a, b) for a, b in zip(before, model.get_weights()))     # nothing was applied
+    os.environ.pop("DEEPJ_CLUSTER", None)              # set by the product code, not through monkeypatch
