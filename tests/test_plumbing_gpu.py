@@ -64,11 +64,12 @@ def test_generate_main_writes_decodable_files(gpu_device, tmp_path, monkeypatch,
         on = np.nonzero(roll[:, :, 0].any(axis=1))[0]
         if len(on):
             L = on.max() + 1
-            # the wire format carries int(volume * 127) & 0x7F (midi_util.py:43,66; volumes are the raw, unclipped
-            # output of the volume head, generate.py:55): a played note whose velocity byte comes out 0 is a note-off on
-            # the wire, exactly as in the reference -- with random-init weights that happens for a few notes
-            vel = (roll[:L, :, 2] * 127).astype(np.int64) & 0x7F
-            sounding = (roll[:L, :, 0] > 0) & (vel != 0)
-            assert sounding.sum() > 0
-            np.testing.assert_array_equal(got[:L, 36:84, 0][sounding], 1.0)
+            # the file holds what midi_encode makes of the roll (the SMF writer / reader add nothing) ...
+            from music_generator_amd.dataset import unclamp_midi
+            want = midi_util.midi_decode(midi_util.midi_encode(unclamp_midi(roll)))
+            np.testing.assert_array_equal(got, want)
+            # ... and that is the sampled roll, except where the wire format cannot carry it: the velocity byte is
+            # int(volume * 127) & 0x7F of the raw, unclipped volume head (midi_util.py:43,66; generate.py:55), and a
+            # velocity of 0 is a note-off -- with random-init weights a few notes come out that way, as in the reference
             assert got[:L, 36:84, 0][roll[:L, :, 0] == 0].sum() == 0
+            assert got[:L, 36:84, 0].sum() >= 0.8 * roll[:L, :, 0].sum()
