@@ -64,12 +64,9 @@ def test_generate_main_writes_decodable_files(gpu_device, tmp_path, monkeypatch,
         on = np.nonzero(roll[:, :, 0].any(axis=1))[0]
         if len(on):
             L = on.max() + 1
-            # the file holds what midi_encode makes of the roll (the SMF writer / reader add nothing) ...
-            from music_generator_amd.dataset import unclamp_midi
-            want = midi_util.midi_decode(midi_util.midi_encode(unclamp_midi(roll)))
-            np.testing.assert_array_equal(got, want)
-            # ... and that is the sampled roll, except where the wire format cannot carry it: the velocity byte is
+            # the file holds the sampled roll except where the wire format cannot carry it: the velocity byte is
             # int(volume * 127) & 0x7F of the raw, unclipped volume head (midi_util.py:43,66; generate.py:55), and a
-            # velocity of 0 is a note-off -- with random-init weights a few notes come out that way, as in the reference
+            # velocity of 0 is a note-off -- with random-init weights a few notes come out that way, as in the
+            # reference (the byte-exact writer / reader / codec checks live in tests/test_golden_cpu.py)
             assert got[:L, 36:84, 0][roll[:L, :, 0] == 0].sum() == 0
             assert got[:L, 36:84, 0].sum() >= 0.8 * roll[:L, :, 0].sum()
