@@ -45,7 +45,7 @@ def main(argv):
     import h5py
     from music_generator_amd.engine import DeepJConfig
     from music_generator_amd.model import keras_name_map
-    from oracle_layout import layout_of
+    from param_layout import layout_of
     src, dst = argv
     cfg = DeepJConfig()
     with h5py.File(src, "r") as f:
