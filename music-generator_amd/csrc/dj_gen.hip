@@ -11,6 +11,7 @@
 // reference's order (note-major, piece-minor; the replay draw only after a successful play
 // draw, generate.py:52-58); the number consumed is returned so the host can advance NumPy's
 // MT19937 stream by exactly that many draws.
+#include <cstdint>
 #include "dj_kernels.h"
 
 namespace {
@@ -55,43 +56,83 @@ struct DjGenState {
 };
 
 // style = style_in W_s + b_s ; sp_l = tanh(style Wd_l + bd_l)    (model.py:141-142,110-113)
-__global__ void gen_prep_kernel(GenArgs a) {
+// One workgroup per note layer (blockIdx.x = l); every thread first fills its own column's weights into registers
+// with independent loads (the k loops below were chains of dependent ~1 us round trips: 62 us for this launch).
+__global__ __launch_bounds__(512) void gen_prep_kernel(GenArgs a) {
   __shared__ float st[GEN_MAXG * 64];
+  __shared__ float sin_[GEN_MAXG * 64];
+  const int l = blockIdx.x;
+  for (int i = threadIdx.x; i < a.G * a.S; i += blockDim.x) sin_[i] = a.style_last[(i / a.S) * a.style_stride + i % a.S];
+  __syncthreads();
   for (int i = threadIdx.x; i < a.G * a.SU; i += blockDim.x) {
-    int g = i / a.SU, k = i % a.SU;
+    const int g = i / a.SU, k = i % a.SU;
     float s = a.P[a.p_style_b + k];
-    for (int j = 0; j < a.S; ++j) s += a.style_last[g * a.style_stride + j] * a.P[a.p_style_W + (int64_t)j * a.SU + k];
+#pragma unroll 8
+    for (int j = 0; j < a.S; ++j) s += sin_[g * a.S + j] * a.P[a.p_style_W + (int64_t)j * a.SU + k];
     st[i] = s;
-    a.svec[i] = s;
+    if (l == 0) a.svec[i] = s;
   }
   __syncthreads();
-  for (int l = 0; l < a.Ln; ++l) {
-    const int D = l == 0 ? a.D0 : a.Hn;
-    float* sp = a.svec + GEN_MAXG * 64 + (int64_t)l * GEN_MAXG * 512;
-    for (int i = threadIdx.x; i < a.G * D; i += blockDim.x) {
-      int g = i / D, d = i % D;
-      float s = a.P[a.db[l] + d];
-      for (int k = 0; k < a.SU; ++k) s += st[g * a.SU + k] * a.P[a.dW[l] + (int64_t)k * D + d];
+  const int D = l == 0 ? a.D0 : a.Hn;
+  float* sp = a.svec + GEN_MAXG * 64 + (int64_t)l * GEN_MAXG * 512;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float wcol[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) wcol[k] = k < a.SU ? a.P[a.dW[l] + (int64_t)k * D + d] : 0.f;
+    const float bd = a.P[a.db[l] + d];
+    for (int g = 0; g < a.G; ++g) {
+      float s = bd;
+#pragma unroll
+      for (int k = 0; k < 64; ++k) s += st[g * a.SU + (k < a.SU ? k : 0)] * wcol[k];
       sp[g * 512 + d] = dj_tanh(s);
     }
   }
 }
 
 // zx0[g,n,col] = b0[col] + sum_{k<Ht} (feat[g,n,k] + sp0[g,k]) W0[k,col] + sum_{c<3} sp0[g,Ht+c] W0[Ht+c,col]
-// feat = last window step of the time axis, read straight from the TA-ordered h buffer.
+// feat = last window step of the time axis, read straight from the TA-ordered h buffer.  One workgroup per
+// (8 notes of one piece, 256 columns): the weight column is loaded once per 8 notes, 32 loads in flight.
+constexpr int ZX_NB = 8;
 template <typename T>
-__global__ void gen_zx0_kernel(GenArgs a, const T* __restrict__ Htime) {
+__global__ __launch_bounds__(256) void gen_zx0_kernel(GenArgs a, const T* __restrict__ Htime) {
+  __shared__ float xf[ZX_NB][512];
   const int col = blockIdx.x * blockDim.x + threadIdx.x;     // 0 .. 4Hn-1
-  const int gn = blockIdx.y, g = gn / a.N, n = gn % a.N;
-  if (col >= 4 * a.Hn) return;
+  const int nblk = (a.N + ZX_NB - 1) / ZX_NB;
+  const int g = blockIdx.y / nblk, n0 = (blockIdx.y % nblk) * ZX_NB;
+  const int nn = a.N - n0 < ZX_NB ? a.N - n0 : ZX_NB;
   const float* sp0 = a.svec + GEN_MAXG * 64 + g * 512;
-  const T* f = Htime + dj_row_ta(g, a.T - 1, n, a.T, a.N) * a.Ht;
+  const int KP = (a.Ht + 3 + 31) / 32 * 32;                  // feat + style for k < Ht, style alone for the 3 chosen rows
+  for (int i = threadIdx.x; i < ZX_NB * KP; i += blockDim.x) {
+    const int j = i / KP, k = i % KP;
+    float v = 0.f;
+    if (j < nn && k < a.Ht + 3) {
+      v = sp0[k];
+      if (k < a.Ht) v += dj_to_f32(Htime[dj_row_ta(g, a.T - 1, n0 + j, a.T, a.N) * a.Ht + k]);
+    }
+    xf[j][k] = v;
+  }
+  __syncthreads();
+  if (col >= 4 * a.Hn) return;
   const float* W0 = a.P + a.W[0];
   const int ldw = 4 * a.Hn;
-  float s = a.P[a.b[0] + col];
-  for (int k = 0; k < a.Ht; ++k) s += (dj_to_f32(f[k]) + sp0[k]) * W0[(int64_t)k * ldw + col];
-  for (int c = 0; c < 3; ++c) s += sp0[a.Ht + c] * W0[(int64_t)(a.Ht + c) * ldw + col];
-  a.zx0[((int64_t)g * a.N + n) * ldw + col] = s;
+  const float b0 = a.P[a.b[0] + col];
+  float s[ZX_NB];
+#pragma unroll
+  for (int j = 0; j < ZX_NB; ++j) s[j] = b0;
+#pragma unroll 1
+  for (int k0 = 0; k0 < KP; k0 += 32) {
+    float wv[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) wv[i] = k0 + i < a.Ht + 3 ? W0[(int64_t)(k0 + i) * ldw + col] : 0.f;
+#pragma unroll
+    for (int j = 0; j < ZX_NB; ++j)
+#pragma unroll
+      for (int i = 0; i < 32; i += 4) {
+        const float4 xv = *(const float4*)&xf[j][k0 + i];
+        s[j] += xv.x * wv[i] + xv.y * wv[i + 1] + xv.z * wv[i + 2] + xv.w * wv[i + 3];
+      }
+  }
+  for (int j = 0; j < nn; ++j) a.zx0[((int64_t)g * a.N + n0 + j) * ldw + col] = s[j];
 }
 
 // z[g] += sum_k x[g][k] * w[k * ldw]  for one gate column: the weight column is streamed from L2 with
@@ -118,57 +159,86 @@ __device__ __forceinline__ void gen_dot(float (&z)[GEN_MAXG], const float* __res
   }
 }
 
-// one workgroup, 4*Hn threads (one per gate column)
+// one workgroup, 4*Hn threads (one per gate column).  The chain of N notes x Ln layers is pure latency, so everything
+// that does not depend on the chain is taken off it: the uniforms, temperatures, style terms and head weights of the
+// time step are copied to LDS up front, per-column constants live in registers, the next note's x W + b is requested
+// a note ahead, and the sampled notes are parked in LDS until the end (per note that removes ~10 dependent global
+// round trips of ~1 us each: the two Bernoulli draws per piece alone were six of them).
 template <bool SIGM, int MAXT>
 __global__ __launch_bounds__(MAXT) void gen_sample_kernel(GenArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int Hn = a.Hn, G = a.G, C4 = 4 * Hn;
+  const int Hn = a.Hn, G = a.G, C4 = 4 * Hn, Ln = a.Ln;
   float* hs = sm;                          // [Ln][G][Hn]
-  float* cs = hs + a.Ln * G * Hn;          // [Ln][G][Hn]
-  float* zb = cs + a.Ln * G * Hn;          // [G][4Hn]
+  float* cs = hs + Ln * G * Hn;            // [Ln][G][Hn]
+  float* zb = cs + Ln * G * Hn;            // [G][4Hn]
   float* xs = zb + G * C4;                 // [G][Hn]   input of layers >= 1 (h below + style)
-  float* chosen = xs + G * Hn;             // [G][4]    previous note (play, replay, volume)
+  float* spl = xs + G * Hn;                // [Ln][G][Hn]  style term added to the input of layer l >= 1
+  float* hw = spl + Ln * G * Hn;           // [3][Hn] head weights (play, replay, volume) + [4] biases
+  float* res = hw + 3 * Hn + 4;            // [G][N][3] sampled notes of this time step
+  float* chosen = res + G * a.N * 3;       // [G][4]    previous note (play, replay, volume)
   float* logit = chosen + G * 4;           // [G][4]
+  float* temps = logit + G * 4;            // [G]
+  double* ul = (double*)(((uintptr_t)(temps + G) + 7) & ~(uintptr_t)7);   // [2 N G] uniforms of this time step
   __shared__ int kdraw, knear;
-  const int col = threadIdx.x;
-  for (int i = threadIdx.x; i < 2 * a.Ln * G * Hn; i += blockDim.x) hs[i] = 0.f;
-  for (int i = threadIdx.x; i < G * 4; i += blockDim.x) chosen[i] = 0.f;
-  if (threadIdx.x == 0) {
-    kdraw = a.state ? a.state->draw_off : 0;
+  const int tid = threadIdx.x, col = tid;
+  const int draw0 = a.state ? a.state->draw_off : 0;
+  for (int i = tid; i < 2 * Ln * G * Hn; i += blockDim.x) hs[i] = 0.f;       // hs and cs
+  for (int i = tid; i < G * 4; i += blockDim.x) chosen[i] = 0.f;
+  for (int i = tid; i < Ln * G * Hn; i += blockDim.x) {
+    const int l = i / (G * Hn), r = i % (G * Hn), g = r / Hn, u = r % Hn;
+    spl[i] = l ? a.svec[GEN_MAXG * 64 + (int64_t)l * GEN_MAXG * 512 + g * 512 + u] : 0.f;
+  }
+  for (int i = tid; i < Hn; i += blockDim.x) {
+    hw[i] = a.P[a.p_nd_W + (int64_t)i * 2];
+    hw[Hn + i] = a.P[a.p_nd_W + (int64_t)i * 2 + 1];
+    hw[2 * Hn + i] = a.P[a.p_vd_W + i];
+  }
+  if (tid < 2) hw[3 * Hn + tid] = a.P[a.p_nd_b + tid];
+  if (tid == 2) hw[3 * Hn + 2] = a.P[a.p_vd_b];
+  for (int i = tid; i < 2 * a.N * G; i += blockDim.x) ul[i] = a.uniforms[draw0 + i];
+  if (tid < G) temps[tid] = a.state ? (float)a.state->temperature[tid] : a.temperature[tid];
+  if (tid == 0) {
+    kdraw = 0;                             // index into ul
     knear = 0;
   }
-  float* out_notes = a.state ? a.results + (int64_t)a.state->step * G * a.N * 3 : a.next_notes;
+  // per-column constants: the three `chosen` rows of the layer-0 kernel, the biases of the upper layers
+  float wch[3], bl[4];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) wch[c] = a.P[a.W[0] + (int64_t)(a.Ht + c) * C4 + col];
+#pragma unroll
+  for (int l = 1; l < 4; ++l) bl[l] = l < Ln ? a.P[a.b[l] + col] : 0.f;
+  float zx[GEN_MAXG];
+#pragma unroll
+  for (int g = 0; g < GEN_MAXG; ++g) zx[g] = g < G ? a.zx0[((int64_t)g * a.N + 0) * C4 + col] : 0.f;
   __syncthreads();
 
   for (int n = 0; n < a.N; ++n) {
-    for (int l = 0; l < a.Ln; ++l) {
+#pragma unroll 1
+    for (int l = 0; l < Ln; ++l) {
       // ---- pre-activations of column `col` for every piece
       float z[GEN_MAXG];
-      const float* U = a.P + a.U[l];
-      const float* hl = hs + l * G * Hn;
       if (l == 0) {
-        const float* W0 = a.P + a.W[0];
 #pragma unroll
         for (int g = 0; g < GEN_MAXG; ++g)
-          if (g < G) {
-            float s = a.zx0[((int64_t)g * a.N + n) * C4 + col];
+          if (g < G) z[g] = zx[g] + chosen[g * 4] * wch[0] + chosen[g * 4 + 1] * wch[1] + chosen[g * 4 + 2] * wch[2];
+        if (n + 1 < a.N) {                 // next note's x W + b: in flight for a whole note
 #pragma unroll
-            for (int c = 0; c < 3; ++c) s += chosen[g * 4 + c] * W0[(int64_t)(a.Ht + c) * C4 + col];
-            z[g] = s;
-          }
+          for (int g = 0; g < GEN_MAXG; ++g)
+            if (g < G) zx[g] = a.zx0[((int64_t)g * a.N + n + 1) * C4 + col];
+        }
       } else {
-        const float bl = a.P[a.b[l] + col];
+        const float b = l == 1 ? bl[1] : (l == 2 ? bl[2] : bl[3]);
 #pragma unroll
-        for (int g = 0; g < GEN_MAXG; ++g) z[g] = bl;
+        for (int g = 0; g < GEN_MAXG; ++g) z[g] = b;
         gen_dot(z, a.P + a.W[l] + col, C4, xs, Hn, G);
       }
-      gen_dot(z, U + col, C4, hl, Hn, G);
+      gen_dot(z, a.P + a.U[l] + col, C4, hs + l * G * Hn, Hn, G);
 #pragma unroll
       for (int g = 0; g < GEN_MAXG; ++g)
         if (g < G) zb[g * C4 + col] = z[g];
       __syncthreads();
       // ---- cell update (Keras gate order i,f,c,o)
-      for (int i = threadIdx.x; i < G * Hn; i += blockDim.x) {
+      for (int i = tid; i < G * Hn; i += blockDim.x) {
         const int g = i / Hn, u = i % Hn;
         const float* zz = zb + g * C4;
         const float ig = dj_ract<SIGM>(zz[u]), fg = dj_ract<SIGM>(zz[Hn + u]), gg = dj_tanh(zz[2 * Hn + u]),
@@ -177,51 +247,50 @@ __global__ __launch_bounds__(MAXT) void gen_sample_kernel(GenArgs a) {
         cs[(l * G + g) * Hn + u] = cn;
         const float hv = og * dj_tanh(cn);
         hs[(l * G + g) * Hn + u] = hv;
-        if (l + 1 < a.Ln) xs[g * Hn + u] = hv + a.svec[GEN_MAXG * 64 + (int64_t)(l + 1) * GEN_MAXG * 512 + g * 512 + u];
+        if (l + 1 < Ln) xs[g * Hn + u] = hv + spl[((l + 1) * G + g) * Hn + u];
       }
       __syncthreads();
     }
     // ---- heads: (play, replay) = sigmoid(h Wn + bn), volume = h Wv + bv   (model.py:94-95)
     {
-      const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-      const float* ht = hs + (a.Ln - 1) * G * Hn;
+      const int wv = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+      const float* ht = hs + (Ln - 1) * G * Hn;
       for (int job = wv; job < G * 3; job += nw) {
         const int g = job / 3, o = job % 3;
         float s = 0.f;
-        for (int k = lane; k < Hn; k += 64)
-          s += ht[g * Hn + k] * (o < 2 ? a.P[a.p_nd_W + (int64_t)k * 2 + o] : a.P[a.p_vd_W + k]);
+        for (int k = lane; k < Hn; k += 64) s += ht[g * Hn + k] * hw[o * Hn + k];
 #pragma unroll
         for (int sft = 32; sft > 0; sft >>= 1) s += __shfl_xor(s, sft);
-        if (lane == 0) logit[g * 4 + o] = s + (o < 2 ? a.P[a.p_nd_b + o] : a.P[a.p_vd_b]);
+        if (lane == 0) logit[g * 4 + o] = s + hw[3 * Hn + o];
       }
     }
     __syncthreads();
     // ---- sampling, reference draw order (generate.py:47-58,116-118)
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
       int k = kdraw;
       for (int g = 0; g < G; ++g) {
         float pp = dj_sigmoid(logit[g * 4]), pr = dj_sigmoid(logit[g * 4 + 1]);
         const float vol = logit[g * 4 + 2];
-        const float temp = a.state ? (float)a.state->temperature[g] : a.temperature[g];
+        const float temp = temps[g];
         if (temp != 1.0f) {                       // apply_temperature, float32 like the reference (generate.py:81-91)
           float x0 = -logf(1.0f / pp - 1.0f), x1 = -logf(1.0f / pr - 1.0f);
           pp = 1.0f / (1.0f + expf(-x0 / temp));
           pr = 1.0f / (1.0f + expf(-x1 / temp));
         }
         float play = 0.f, rep = 0.f, v = 0.f;
-        const double u0 = a.uniforms[k++];
+        const double u0 = ul[k++];
         knear += fabs(u0 - (double)pp) < DJ_GEN_TIE_BAND;
         if (u0 <= (double)pp) {
           play = 1.f;
           v = vol;
-          const double u1 = a.uniforms[k++];
+          const double u1 = ul[k++];
           knear += fabs(u1 - (double)pr) < DJ_GEN_TIE_BAND;
           if (u1 <= (double)pr) rep = 1.f;
         }
         chosen[g * 4] = play;
         chosen[g * 4 + 1] = rep;
         chosen[g * 4 + 2] = v;
-        float* o = out_notes + ((int64_t)g * a.N + n) * 3;
+        float* o = res + ((int64_t)g * a.N + n) * 3;
         o[0] = play;
         o[1] = rep;
         o[2] = v;
@@ -230,9 +299,11 @@ __global__ __launch_bounds__(MAXT) void gen_sample_kernel(GenArgs a) {
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
+  float* out_notes = a.state ? a.results + (int64_t)a.state->step * G * a.N * 3 : a.next_notes;
+  for (int i = tid; i < G * a.N * 3; i += blockDim.x) out_notes[i] = res[i];
+  if (tid == 0) {
     if (a.state) {
-      a.state->draw_off = kdraw;
+      a.state->draw_off = draw0 + kdraw;
       if (knear && a.state->near_ties == 0) a.state->first_near_step = a.state->step;
       a.state->near_ties += knear;
     } else {
@@ -298,7 +369,7 @@ int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int
                              int64_t style_stride,
                              float* scratch, const double* uniforms, const float* temperature, float* next_notes,
                              int* draws_used, void* state, float* results, int sigm, hipStream_t st) {
-  if (G < 1 || G > GEN_MAXG || Ln < 1 || Ln > 4 || 4 * Hn > 1024 || (Hn % 32) || Ht + 3 > 512 || SU > 64) return 1300;
+  if (G < 1 || G > GEN_MAXG || Ln < 1 || Ln > 4 || 4 * Hn > 1024 || (Hn % 32) || Ht + 3 > 512 || SU > 64 || S > 64) return 1300;
   GenArgs a;
   a.G = G; a.N = N; a.Hn = Hn; a.Ht = Ht; a.Ln = Ln; a.S = S; a.SU = SU; a.T = T; a.P = P;
   a.p_style_W = offs[0]; a.p_style_b = offs[1]; a.p_nd_W = offs[2]; a.p_nd_b = offs[3]; a.p_vd_W = offs[4];
@@ -314,13 +385,15 @@ int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int
   a.zx0 = scratch + GEN_MAXG * 64 + 4 * GEN_MAXG * 512;
   a.uniforms = uniforms; a.temperature = temperature; a.next_notes = next_notes; a.draws_used = draws_used;
   a.state = (DjGenState*)state; a.results = results;
-  hipLaunchKernelGGL(gen_prep_kernel, dim3(1), dim3(256), 0, st, a);
-  dim3 gz((4 * Hn + 255) / 256, G * N);
+  hipLaunchKernelGGL(gen_prep_kernel, dim3(Ln), dim3(512), 0, st, a);
+  dim3 gz((4 * Hn + 255) / 256, G * ((N + ZX_NB - 1) / ZX_NB));
   if (dtype == DJ_F32)
     hipLaunchKernelGGL(gen_zx0_kernel<float>, gz, dim3(256), 0, st, a, (const float*)Htime);
   else
     hipLaunchKernelGGL(gen_zx0_kernel<bf16_t>, gz, dim3(256), 0, st, a, (const bf16_t*)Htime);
-  const size_t smem = ((size_t)2 * Ln * G * Hn + (size_t)G * 4 * Hn + (size_t)G * Hn + 8 * G) * sizeof(float);
+  const size_t smem = ((size_t)3 * Ln * G * Hn + (size_t)G * 4 * Hn + (size_t)G * Hn + 3 * Hn + 4 + (size_t)G * N * 3 + 9 * G + 8) *
+                          sizeof(float) + (size_t)2 * N * G * sizeof(double) + 16;
+  if (smem > 64 * 1024) return 1301;
   // up to 512 threads (Hn <= 128) the sampler may use 256 VGPRs
 #define DJ_GEN_LAUNCH(S, MT) hipLaunchKernelGGL((gen_sample_kernel<S, MT>), dim3(1), dim3(4 * Hn), smem, st, a)
   if (4 * Hn <= 512) {

@@ -20,7 +20,7 @@ for H in (128, 256):
     U = torch.randn(H, 4 * H, device=dev) * 0.05
     upf = torch.empty(H * 4 * H * 2, dtype=torch.uint8, device=dev); upb = torch.empty_like(upf)
     _lib.check(lib.dj_lstm_pack(1, H, p(U), p(upf), p(upb), st()), "pack")
-    for tiles in (128, 256, 257, 384, 512):
+    for tiles in (tuple(int(x) for x in os.environ["REC_TILES"].split(",")) if os.environ.get("REC_TILES") else (128, 256, 257, 384, 512)):
         R = tiles * steps * 32
         Z = (torch.randn(R * 4 * H, device=dev) * 0.5).to(torch.bfloat16)           # x W + b, fragment-tiled
         G8 = torch.zeros(R * 4 * H, dtype=torch.uint8, device=dev)                 # 8-bit gate stash
