@@ -12,6 +12,7 @@
 // draw, generate.py:52-58); the number consumed is returned so the host can advance NumPy's
 // MT19937 stream by exactly that many draws.
 #include <cstdint>
+#include <cstdlib>
 #include "dj_kernels.h"
 
 namespace {
@@ -314,6 +315,192 @@ __global__ __launch_bounds__(MAXT) void gen_sample_kernel(GenArgs a) {
 }
 
 
+// The same walk for G <= 4 pieces and 4 Hn <= 512 (the reference shape) with the dot products split over K: thread =
+// (4 adjacent gate columns, one quarter of K).  With one thread per column every thread read the whole x vector of
+// every piece from LDS -- 288 broadcast ds_read_b128 per wave and note, ~0.68 of the 0.74 ms the walk took WITHOUT
+// its weight loads; here a thread reads a quarter of x, loads its weights 16 bytes at a time, and the cell-update
+// thread of unit (g, u) adds the four partial sums of its four gates.
+template <bool SIGM>
+__global__ __launch_bounds__(512) void gen_sample_ks_kernel(GenArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Hn = a.Hn, G = a.G, C4 = 4 * Hn, Ln = a.Ln, KQ = Hn / 4;
+  float* hs = sm;                          // [Ln][G][Hn]
+  float* cs = hs + Ln * G * Hn;            // [Ln][G][Hn]
+  float* zp = cs + Ln * G * Hn;            // [4][G][4Hn] partial pre-activations per K quarter
+  float* xs = zp + 4 * G * C4;             // [G][Hn]   input of layers >= 1 (h below + style)
+  float* spl = xs + G * Hn;                // [Ln][G][Hn]  style term added to the input of layer l >= 1
+  float* hw = spl + Ln * G * Hn;           // [3][Hn] head weights (play, replay, volume) + [4] biases
+  float* res = hw + 3 * Hn + 4;            // [G][N][3] sampled notes of this time step
+  float* chosen = res + G * a.N * 3;       // [G][4]    previous note (play, replay, volume)
+  float* logit = chosen + G * 4;           // [G][4]
+  float* temps = logit + G * 4;            // [G]
+  double* ul = (double*)(((uintptr_t)(temps + G) + 7) & ~(uintptr_t)7);   // [2 N G] uniforms of this time step
+  __shared__ int kdraw, knear;
+  const int tid = threadIdx.x;
+  const int cg = tid % Hn, ks = tid / Hn;              // columns 4 cg .. 4 cg + 3, k in [ks KQ, (ks + 1) KQ)
+  const int cu_g = tid / Hn, cu_u = tid % Hn;          // cell-update role: unit (g, u), valid while tid < G Hn
+  const bool cell = tid < G * Hn;
+  const int draw0 = a.state ? a.state->draw_off : 0;
+  for (int i = tid; i < 2 * Ln * G * Hn; i += blockDim.x) hs[i] = 0.f;       // hs and cs
+  for (int i = tid; i < G * 4; i += blockDim.x) chosen[i] = 0.f;
+  for (int i = tid; i < Ln * G * Hn; i += blockDim.x) {
+    const int l = i / (G * Hn), r = i % (G * Hn), g = r / Hn, u = r % Hn;
+    spl[i] = l ? a.svec[GEN_MAXG * 64 + (int64_t)l * GEN_MAXG * 512 + g * 512 + u] : 0.f;
+  }
+  for (int i = tid; i < Hn; i += blockDim.x) {
+    hw[i] = a.P[a.p_nd_W + (int64_t)i * 2];
+    hw[Hn + i] = a.P[a.p_nd_W + (int64_t)i * 2 + 1];
+    hw[2 * Hn + i] = a.P[a.p_vd_W + i];
+  }
+  if (tid < 2) hw[3 * Hn + tid] = a.P[a.p_nd_b + tid];
+  if (tid == 2) hw[3 * Hn + 2] = a.P[a.p_vd_b];
+  for (int i = tid; i < 2 * a.N * G; i += blockDim.x) ul[i] = a.uniforms[draw0 + i];
+  if (tid < G) temps[tid] = a.state ? (float)a.state->temperature[tid] : a.temperature[tid];
+  if (tid == 0) {
+    kdraw = 0;                             // index into ul
+    knear = 0;
+  }
+  // cell-update constants of unit (g, u), per gate: the three `chosen` rows of the layer-0 kernel, the upper biases,
+  // and this note's x W + b
+  float wch[3][4], bl[4][4], zx[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) wch[c][q] = cell ? a.P[a.W[0] + (int64_t)(a.Ht + c) * C4 + q * Hn + cu_u] : 0.f;
+#pragma unroll
+    for (int l = 1; l < 4; ++l) bl[l][q] = (cell && l < Ln) ? a.P[a.b[l] + q * Hn + cu_u] : 0.f;
+    zx[q] = cell ? a.zx0[((int64_t)cu_g * a.N + 0) * C4 + q * Hn + cu_u] : 0.f;
+  }
+  __syncthreads();
+
+  // partial[g][c] += sum over this thread's K quarter of x[g][k] W[k][4 cg + c]
+  auto dot4 = [&](float (&acc)[4][4], const float* __restrict__ Wm, const float* x) {
+#pragma unroll 1
+    for (int k0 = 0; k0 < KQ; k0 += 8) {
+      float4 wv[8];
+      const float* wsrc = Wm + (int64_t)(ks * KQ + k0) * C4 + 4 * cg;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wv[i] = *(const float4*)(wsrc + (int64_t)i * C4);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (g < G) {
+          const float4 x0 = *(const float4*)(x + g * Hn + ks * KQ + k0), x1 = *(const float4*)(x + g * Hn + ks * KQ + k0 + 4);
+          const float xe[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            acc[g][0] += xe[i] * wv[i].x;
+            acc[g][1] += xe[i] * wv[i].y;
+            acc[g][2] += xe[i] * wv[i].z;
+            acc[g][3] += xe[i] * wv[i].w;
+          }
+        }
+    }
+  };
+
+  for (int n = 0; n < a.N; ++n) {
+#pragma unroll 1
+    for (int l = 0; l < Ln; ++l) {
+      float acc[4][4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[g][c] = 0.f;
+      if (l > 0) dot4(acc, a.P + a.W[l], xs);
+      dot4(acc, a.P + a.U[l], hs + l * G * Hn);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (g < G) *(float4*)(zp + ((int64_t)(ks * G + g)) * C4 + 4 * cg) = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+      __syncthreads();
+      // ---- cell update (Keras gate order i,f,c,o): unit (g, u) = (cu_g, cu_u)
+      if (cell) {
+        float z[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float b;
+          if (l == 0)
+            b = zx[q] + chosen[cu_g * 4] * wch[0][q] + chosen[cu_g * 4 + 1] * wch[1][q] + chosen[cu_g * 4 + 2] * wch[2][q];
+          else
+            b = l == 1 ? bl[1][q] : (l == 2 ? bl[2][q] : bl[3][q]);
+          const float* zq = zp + (int64_t)cu_g * C4 + q * Hn + cu_u;
+          z[q] = b + ((zq[0] + zq[(int64_t)G * C4]) + (zq[(int64_t)2 * G * C4] + zq[(int64_t)3 * G * C4]));
+        }
+        if (l == 0 && n + 1 < a.N) {       // next note's x W + b: in flight for a whole note
+#pragma unroll
+          for (int q = 0; q < 4; ++q) zx[q] = a.zx0[((int64_t)cu_g * a.N + n + 1) * C4 + q * Hn + cu_u];
+        }
+        const float ig = dj_ract<SIGM>(z[0]), fg = dj_ract<SIGM>(z[1]), gg = dj_tanh(z[2]), og = dj_ract<SIGM>(z[3]);
+        const int si = (l * G + cu_g) * Hn + cu_u;
+        const float cn = fg * cs[si] + ig * gg;
+        cs[si] = cn;
+        const float hv = og * dj_tanh(cn);
+        hs[si] = hv;
+        if (l + 1 < Ln) xs[cu_g * Hn + cu_u] = hv + spl[((l + 1) * G + cu_g) * Hn + cu_u];
+      }
+      __syncthreads();
+    }
+    // ---- heads: (play, replay) = sigmoid(h Wn + bn), volume = h Wv + bv   (model.py:94-95)
+    {
+      const int wv = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+      const float* ht = hs + (Ln - 1) * G * Hn;
+      for (int job = wv; job < G * 3; job += nw) {
+        const int g = job / 3, o = job % 3;
+        float s = 0.f;
+        for (int k = lane; k < Hn; k += 64) s += ht[g * Hn + k] * hw[o * Hn + k];
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) s += __shfl_xor(s, sft);
+        if (lane == 0) logit[g * 4 + o] = s + hw[3 * Hn + o];
+      }
+    }
+    __syncthreads();
+    // ---- sampling, reference draw order (generate.py:47-58,116-118)
+    if (tid == 0) {
+      int k = kdraw;
+      for (int g = 0; g < G; ++g) {
+        float pp = dj_sigmoid(logit[g * 4]), pr = dj_sigmoid(logit[g * 4 + 1]);
+        const float vol = logit[g * 4 + 2];
+        const float temp = temps[g];
+        if (temp != 1.0f) {                       // apply_temperature, float32 like the reference (generate.py:81-91)
+          float x0 = -logf(1.0f / pp - 1.0f), x1 = -logf(1.0f / pr - 1.0f);
+          pp = 1.0f / (1.0f + expf(-x0 / temp));
+          pr = 1.0f / (1.0f + expf(-x1 / temp));
+        }
+        float play = 0.f, rep = 0.f, v = 0.f;
+        const double u0 = ul[k++];
+        knear += fabs(u0 - (double)pp) < DJ_GEN_TIE_BAND;
+        if (u0 <= (double)pp) {
+          play = 1.f;
+          v = vol;
+          const double u1 = ul[k++];
+          knear += fabs(u1 - (double)pr) < DJ_GEN_TIE_BAND;
+          if (u1 <= (double)pr) rep = 1.f;
+        }
+        chosen[g * 4] = play;
+        chosen[g * 4 + 1] = rep;
+        chosen[g * 4 + 2] = v;
+        float* o = res + ((int64_t)g * a.N + n) * 3;
+        o[0] = play;
+        o[1] = rep;
+        o[2] = v;
+      }
+      kdraw = k;
+    }
+    __syncthreads();
+  }
+  float* out_notes = a.state ? a.results + (int64_t)a.state->step * G * a.N * 3 : a.next_notes;
+  for (int i = tid; i < G * a.N * 3; i += blockDim.x) out_notes[i] = res[i];
+  if (tid == 0) {
+    if (a.state) {
+      a.state->draw_off = draw0 + kdraw;
+      if (knear && a.state->near_ties == 0) a.state->first_near_step = a.state->step;
+      a.state->near_ties += knear;
+    } else {
+      a.draws_used[0] = kdraw;
+      a.draws_used[1] = knear;
+    }
+  }
+}
+
+
 // end_time() of the reference on the device (generate.py:60-79): silence / temperature schedule,
 // then the windows slide by one step: dst[:, t] = src[:, t+1], dst[:, T-1] = new notes / beat(t).
 __global__ void gen_advance_kernel(DjGenState* st, const float* __restrict__ results, const float* __restrict__ nsrc,
@@ -394,6 +581,15 @@ int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int
   const size_t smem = ((size_t)3 * Ln * G * Hn + (size_t)G * 4 * Hn + (size_t)G * Hn + 3 * Hn + 4 + (size_t)G * N * 3 + 9 * G + 8) *
                           sizeof(float) + (size_t)2 * N * G * sizeof(double) + 16;
   if (smem > 64 * 1024) return 1301;
+  static const bool ks_off = getenv("DEEPJ_GEN_KSPLIT") && atoi(getenv("DEEPJ_GEN_KSPLIT")) == 0;
+  if (!ks_off && G <= 4 && 4 * Hn <= 512 && smem + (size_t)3 * G * 4 * Hn * sizeof(float) <= 64 * 1024) {
+    const size_t smem_ks = smem + (size_t)3 * G * 4 * Hn * sizeof(float);      // zp is 4 x the size of zb
+    if (sigm)
+      hipLaunchKernelGGL((gen_sample_ks_kernel<true>), dim3(1), dim3(4 * Hn), smem_ks, st, a);
+    else
+      hipLaunchKernelGGL((gen_sample_ks_kernel<false>), dim3(1), dim3(4 * Hn), smem_ks, st, a);
+    return (int)hipGetLastError();
+  }
   // up to 512 threads (Hn <= 128) the sampler may use 256 VGPRs
 #define DJ_GEN_LAUNCH(S, MT) hipLaunchKernelGGL((gen_sample_kernel<S, MT>), dim3(1), dim3(4 * Hn), smem, st, a)
   if (4 * Hn <= 512) {
