@@ -335,6 +335,19 @@ int time_axis_forward(const Ctx& c, const float* notes, const float* beat) {
                           c.P + p.p_conv_b, c.st));
     RUN(dj_launch_feature_asm(dt, &fa, c.at(p.w_X_t[0]), c.at(p.w_Ycol), c.train ? 1 : 0, c.st));
   }
+  // inference with the reference's two 256-unit layers and few tiles (generation: 5): both layers in ONE launch, the
+  // upper one a few steps behind the lower one, which writes the upper layer's input itself (dj_lstm.hip, ClPair) --
+  // the two latency chains of T steps overlap instead of following each other
+  if (!c.train && p.Lt == 2 && dt == DJ_BF16 && p.tl[0].H == 256 && p.tl[1].H == 256 && p.tl[0].DP <= 128 &&
+      p.tl[1].D == 256 && p.tl[1].DP == 256 && p.tilesT <= 64 && fuse_xw(p.tl[0]) && fuse_xw(p.tl[1]) && cluster_enabled() &&
+      dj_lstm_fused_nkx(dt, 256, p.tl[0].D) == 8 && !(getenv("DEEPJ_CLUSTER_PAIR") && getenv("DEEPJ_CLUSTER_PAIR")[0] == '0')) {
+    ProfScope ps(PC_LSTM_FWD_TIME, c.st);
+    const int rc = dj_launch_lstm_fwd_cluster_pair(
+        (int)p.tilesT, p.T, c.at(p.w_X_t[0]), p.tl[0].DP, c.at(p.w_Wt_t[0]), c.P + p.tl[0].b, c.at(p.w_Uf_t[0]),
+        c.at(p.w_X_t[1]), c.at(p.w_Wt_t[1]), c.P + p.tl[1].b, c.at(p.w_Uf_t[1]), c.at(p.w_H_t[1]),
+        c.at<float>(p.w_sp_t[1]), p.tl[1].D, p.N, p.B, p.c.recurrent_sigmoid, c.at(p.w_cluster), c.st);
+    if (rc != 1017) return rc;          // 1017: the device cannot hold both halves -- layer by layer below
+  }
   for (int l = 0; l < p.Lt; ++l) {
     const LstmP& L = p.tl[l];
     if (l > 0) {

@@ -667,14 +667,38 @@ __device__ __forceinline__ bool cl_wait(int* cnt, int target, int lane) {
   }
   return __builtin_amdgcn_readfirstlane(ok) != 0;
 }
+// Wavefront pairing (inference, two stacked layers in ONE launch; lstm_fwd_cluster_pair_kernel): the blocks of the second
+// half of the grid run the upper layer one to three steps behind the lower one.  The lower layer (`sp_out` set) writes,
+// instead of its raw h, the upper layer's INPUT x = bf16(h + style term) -- the inter-layer glue of inference, where
+// dropout is the identity -- and moves its counter once more after its last stores; the upper layer (`gate` set) asks
+// for the rows of step t only once the lower cluster of the SAME tile has closed step t + 1 (stores are acknowledged in
+// order, so the rows of step t have then reached the L2 both clusters share: cluster c and c + 8 sit on one XCD, which
+// the upper layer verifies against the XCC ids the lower one published).  The lower layer never waits for the upper one.
+struct ClPair {
+  const float* sp_out;      // lower layer: [B * steps, sp_D] style term of the upper layer's input; null = plain h out
+  int sp_D, n_seq, n_b;     // its row length; sequences per batch element (N) and batch elements (rows (b, n) -> b)
+  int* gate;                // upper layer: counter line of the producing cluster; null = X is ready at launch
+  int role;                 // 0 / 1: half of the grid (cluster ids and hx slots of the halves are disjoint)
+};
+// bounded wait that returns the counter value it saw (0 = expired)
+__device__ __forceinline__ int cl_wait_val(int* cnt, int target, int lane) {
+  int v = 0;
+  if (lane == 0) {
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    while ((v = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target &&
+           __builtin_readcyclecounter() - t0 < 20000000ull)
+      __builtin_amdgcn_s_sleep(2);
+    if (v < target) v = 0;
+  }
+  return __builtin_amdgcn_readfirstlane(v);
+}
 template <bool SIGM, int NKX>
-__global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __restrict__ X, int DP,
-                                                               const bf16_t* __restrict__ Wpack,
-                                                               const float* __restrict__ bias,
-                                                               StashElem<bf16_t>* __restrict__ Zst,
-                                                               const bf16_t* __restrict__ Upack,
-                                                               bf16_t* __restrict__ Hout, bf16_t* __restrict__ Cout,
-                                                               int steps, int* __restrict__ cl, int ntiles) {
+__device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__ X, int DP,
+                                                      const bf16_t* __restrict__ Wpack, const float* __restrict__ bias,
+                                                      StashElem<bf16_t>* __restrict__ Zst,
+                                                      const bf16_t* __restrict__ Upack, bf16_t* __restrict__ Hout,
+                                                      bf16_t* __restrict__ Cout, int steps, int* __restrict__ cl,
+                                                      int ntiles, const ClPair pr, int nblocks) {
   using T = bf16_t;
   constexpr int H = 256;
   using R = RecCfg<T, H>;
@@ -684,13 +708,16 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
   Frag* Bu = Bw + 4 * NKX * 64;                            // [4][NKC][64]  U slice
   T* hto = (T*)(Bu + 4 * R::NKC * 64);                     // [8 waves] 4 KiB: x transposition rounds / h_t tile
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, s = j & (CL_M - 1);
-  const int cid = xcd + 8 * (j >> 3);                      // cluster id
-  // wave w of every member works on tile cid + nclusters * w: a launch with fewer tiles than wave slots (generation:
+  const int bidx = (int)blockIdx.x - pr.role * nblocks;    // block index within this layer's half of the grid
+  const int xcd = bidx & 7, j = bidx >> 3, s = j & (CL_M - 1);
+  const int lcid = xcd + 8 * (j >> 3);                     // cluster id within the layer
+  const int cid = lcid + pr.role * (nblocks >> 6) * 8;     // cluster id within the launch (counter lines)
+  // wave w of every member works on tile lcid + nclusters * w: a launch with fewer tiles than wave slots (generation:
   // 5 tiles on 8 clusters) spreads them over the clusters, one wave each, instead of filling one cluster; waves
   // without a tile only keep the workgroup barriers company
-  const int64_t tile = (int64_t)cid + (int64_t)(gridDim.x >> 3) * w;
+  const int64_t tile = (int64_t)lcid + (int64_t)(nblocks >> 3) * w;
   const bool active = tile < ntiles;
+  const int64_t hx_tile = tile + (int64_t)pr.role * 128;   // exchange slots of the two layers of a pair are disjoint
   int* cnt = cl + 2 * cid * CL_CNT_STRIDE;
   int* xccs = cnt + CL_CNT_STRIDE;
   int* fault = cl + CL_CNT_INTS;
@@ -716,7 +743,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
   const int my_xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15) + 1;   // HW_REG_XCC_ID[3:0]
   {
     if (active) {
-      uint4* hxo = hxb + ((tile * 2 + 1) * 16 + 2 * s) * 64 + lane;
+      uint4* hxo = hxb + ((hx_tile * 2 + 1) * 16 + 2 * s) * 64 + lane;
       hxo[0] = make_uint4(0, 0, 0, 0);
       hxo[64] = make_uint4(0, 0, 0, 0);
     }
@@ -738,6 +765,32 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
     }
   }
 
+  // upper layer of a pair: the producing cluster (same tile, lower half of the grid) must sit on this XCD too
+  int* gate = pr.gate ? cl + 2 * lcid * CL_CNT_STRIDE : nullptr;
+  int seen = 0;                                            // last value of the producer's counter this wave saw
+  if (gate && active) {
+    seen = cl_wait_val(gate, ARRIVALS * 3, lane);          // rows of step 0 are out once the producer has closed step 1
+    int other = my_xcc;
+    if (seen && lane < CL_M) other = __hip_atomic_load(gate + CL_CNT_STRIDE + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool same = __all(other == my_xcc);
+    if (!seen || !same) {
+      if (lane == 0) atomicAdd(fault + (seen ? 1 : 0), 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[r] = __builtin_nanf("");
+    }
+    asm volatile("" ::: "memory");
+  }
+  // lower layer of a pair: per-lane source of the style term of its two 16-byte pieces of the row-major store
+  const float* spp[2] = {nullptr, nullptr};
+  if (pr.sp_out && active) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = lane + 64 * i, row = v >> 2, cq = (v & 3) * 8;
+      int64_t bb = (tile * 32 + row) / pr.n_seq;
+      if (bb > pr.n_b - 1) bb = pr.n_b - 1;               // padding rows of the last tile: any valid row
+      spp[i] = pr.sp_out + bb * steps * pr.sp_D + s * 32 + cq;
+    }
+  }
   unsigned char* xs = (unsigned char*)hto + w * 4096;      // this wave's 4 KiB tile: x rounds, then the h tile
   T* ht = (T*)xs;
   // x rows are fetched as full 128-byte lines, 8 lanes per row (fragments read straight from the rows would be
@@ -753,6 +806,14 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
       continue;
     }
     const int64_t rb = tile * steps + t;
+    float4 spv[2][2];                                  // style term of this step's rows: in flight for the whole step
+    if (pr.sp_out) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        spv[i][0] = *(const float4*)(spp[i] + (int64_t)t * pr.sp_D);
+        spv[i][1] = *(const float4*)(spp[i] + (int64_t)t * pr.sp_D + 4);
+      }
+    }
     f32x16 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -786,9 +847,19 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[r] = __builtin_nanf("");
       }
+      // upper layer of a pair: x_{t+1} (requested below) exists once the producer has closed step t + 2; the counter
+      // is polled only when the last value seen does not cover it (the producer is faster and runs away)
+      if (gate && t + 1 < steps && seen < ARRIVALS * (t + 4)) {
+        seen = cl_wait_val(gate, ARRIVALS * (t + 4), lane);
+        if (!seen) {
+          if (lane == 0) atomicAdd(fault, 1);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c[r] = __builtin_nanf("");
+        }
+      }
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
-      const uint4* hx = hxb + ((tile * 2 + ((t + 1) & 1)) * 16) * 64 + lane;
+      const uint4* hx = hxb + ((hx_tile * 2 + ((t + 1) & 1)) * 16) * 64 + lane;
       uint4 ah[R::NKC];
 #pragma unroll
       for (int kc = 0; kc < R::NKC; ++kc) ah[kc] = ld_sc1(hx + kc * 64);
@@ -824,7 +895,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
     // the exchange copy goes out FIRST: only it has to be acknowledged before the counter moves; chunks 2s, 2s+1 of
     // this tile in fragment image, 1 KiB each
     {
-      uint4* hxo = hxb + ((tile * 2 + (t & 1)) * 16 + 2 * s) * 64 + lane;
+      uint4* hxo = hxb + ((hx_tile * 2 + (t & 1)) * 16 + 2 * s) * 64 + lane;
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) hxo[jj * 64] = *(const uint4*)(ht + l31 * 32 + 16 * jj + 8 * h);
     }
@@ -833,7 +904,17 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int v = lane + 64 * i, row = v >> 2, cq = (v & 3) * 8;
-      *(uint4*)(Hout + (rb * 32 + row) * H + s * 32 + cq) = *(const uint4*)(ht + row * 32 + cq);
+      uint4 hv = *(const uint4*)(ht + row * 32 + cq);
+      if (pr.sp_out) {                                 // the next layer's input: bf16(h + style), as glue_fwd writes it
+        const float sp8[8] = {spv[i][0].x, spv[i][0].y, spv[i][0].z, spv[i][0].w,
+                              spv[i][1].x, spv[i][1].y, spv[i][1].z, spv[i][1].w};
+        T he[8], xo[8];
+        __builtin_memcpy(he, &hv, 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xo[e] = dj_from_f32<T>(dj_to_f32(he[e]) + sp8[e]);
+        __builtin_memcpy(&hv, xo, 16);
+      }
+      *(uint4*)(Hout + (rb * 32 + row) * H + s * 32 + cq) = hv;
     }
     if (Cout) store_frag(Cout + ((rb * R::NCBH + s) * 64 + lane) * 16, cv);
     if (Zst) {
@@ -854,6 +935,42 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
       asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (pr.sp_out) {          // the rows of the last step are out: one more round for the consuming layer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+template <bool SIGM, int NKX>
+__global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __restrict__ X, int DP,
+                                                               const bf16_t* __restrict__ Wpack,
+                                                               const float* __restrict__ bias,
+                                                               StashElem<bf16_t>* __restrict__ Zst,
+                                                               const bf16_t* __restrict__ Upack,
+                                                               bf16_t* __restrict__ Hout, bf16_t* __restrict__ Cout,
+                                                               int steps, int* __restrict__ cl, int ntiles) {
+  ClPair pr;
+  pr.sp_out = nullptr; pr.sp_D = 0; pr.n_seq = 1; pr.n_b = 1; pr.gate = nullptr; pr.role = 0;
+  lstm_fwd_cluster_body<SIGM, NKX>(X, DP, Wpack, bias, Zst, Upack, Hout, Cout, steps, cl, ntiles, pr, (int)gridDim.x);
+}
+// two stacked inference layers as a wavefront (ClPair): blocks [0, n) = the lower layer (input width 96 -> 8 k-chunks),
+// blocks [n, 2n) = the upper one (256 -> 16); X1 is both the lower layer's output and the upper layer's input
+struct ClPairArgs {
+  const bf16_t* X0; int DP0; const bf16_t* W0; const float* b0; const bf16_t* U0;
+  bf16_t* X1; const bf16_t* W1; const float* b1; const bf16_t* U1; bf16_t* H1;
+  const float* sp1; int sp_D, n_seq, n_b;
+};
+template <bool SIGM>
+__global__ __launch_bounds__(512) void lstm_fwd_cluster_pair_kernel(ClPairArgs a, int steps, int* __restrict__ cl, int ntiles) {
+  const int nblocks = (int)gridDim.x >> 1;
+  ClPair pr;
+  if ((int)blockIdx.x < nblocks) {
+    pr.sp_out = a.sp1; pr.sp_D = a.sp_D; pr.n_seq = a.n_seq; pr.n_b = a.n_b; pr.gate = nullptr; pr.role = 0;
+    lstm_fwd_cluster_body<SIGM, 8>(a.X0, a.DP0, a.W0, a.b0, nullptr, a.U0, a.X1, nullptr, steps, cl, ntiles, pr, nblocks);
+  } else {
+    pr.sp_out = nullptr; pr.sp_D = 0; pr.n_seq = 1; pr.n_b = 1; pr.gate = cl; pr.role = 1;
+    lstm_fwd_cluster_body<SIGM, 16>(a.X1, 256, a.W1, a.b1, nullptr, a.U1, a.H1, nullptr, steps, cl, ntiles, pr, nblocks);
   }
 }
 
@@ -1379,7 +1496,47 @@ int launch_fwd_cluster(int ntiles, int steps, const void* X, int DP, int NKX, co
               : launch_fwd_cluster_s<false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st);
 }
 
+int launch_fwd_cluster_pair(int ntiles, int steps, const ClPairArgs& a, int sigm, void* scratch, hipStream_t st) {
+  using R = RecCfg<bf16_t, 256>;
+  if (ntiles < 1 || ntiles > 64 || a.DP0 > 128 || a.DP0 % 8 || !scratch || ((uintptr_t)scratch & 127) || a.sp_D < 256)
+    return 1016;
+  if (cluster_cus() < 128) return 1017;                 // both halves of the grid must be co-resident
+  const size_t smem = (size_t)(4 * 16 * 64 + 4 * R::NKC * 64) * 16 + (size_t)8 * 4096;
+  static bool attr_done_dev[DJ_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[dj_current_device()];
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_cluster_pair_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)lstm_fwd_cluster_pair_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipError_t e = hipMemsetAsync(scratch, 0, CL_OFF_FAULT, st);
+  if (e != hipSuccess) return (int)e;
+  if (sigm)
+    hipLaunchKernelGGL((lstm_fwd_cluster_pair_kernel<true>), dim3(128), dim3(512), smem, st, a, steps, (int*)scratch, ntiles);
+  else
+    hipLaunchKernelGGL((lstm_fwd_cluster_pair_kernel<false>), dim3(128), dim3(512), smem, st, a, steps, (int*)scratch, ntiles);
+  return (int)hipGetLastError();
+}
+
 }  // namespace
+
+// Two stacked bf16 H = 256 inference layers (input widths <= 128 and 256) as ONE wavefront launch: the lower layer
+// writes the upper layer's input X1 = bf16(h + sp1[b * steps + t]) itself (rows (b, n) of n_seq sequences per b).
+// Returns 1017 when the device cannot hold both halves of the grid (the caller then runs the layers one by one).
+int dj_launch_lstm_fwd_cluster_pair(int ntiles, int steps, const void* X0, int DP0, const void* W0pack, const float* b0,
+                                    const void* U0pack, void* X1, const void* W1pack, const float* b1, const void* U1pack,
+                                    void* H1, const float* sp1, int sp_D, int n_seq, int n_b, int sigm, void* scratch,
+                                    hipStream_t st) {
+  ClPairArgs a;
+  a.X0 = (const bf16_t*)X0; a.DP0 = DP0; a.W0 = (const bf16_t*)W0pack; a.b0 = b0; a.U0 = (const bf16_t*)U0pack;
+  a.X1 = (bf16_t*)X1; a.W1 = (const bf16_t*)W1pack; a.b1 = b1; a.U1 = (const bf16_t*)U1pack; a.H1 = (bf16_t*)H1;
+  a.sp1 = sp1; a.sp_D = sp_D; a.n_seq = n_seq; a.n_b = n_b;
+  return launch_fwd_cluster_pair(ntiles, steps, a, sigm, scratch, st);
+}
 
 #define DJ_DISPATCH_TH(FN, ...)                                     \
   if (dtype == DJ_F32 && H == 256) return FN<float, 256>(__VA_ARGS__);  \

@@ -171,6 +171,32 @@ def test_predict_models_fp32(gpu_device):
     np.testing.assert_allclose(nout, nref, rtol=1e-3, atol=1e-5)
 
 
+@pytest.mark.parametrize("G,T,N", [(3, 128, 48), (5, 16, 40), (1, 7, 128)], ids=["gen_window", "ragged_tiles", "one_piece"])
+def test_time_axis_pair_launch_matches_layer_by_layer(gpu_device, monkeypatch, G, T, N):
+    """Inference of the bf16 time axis runs both 256-unit layers as one wavefront launch (dj_lstm.hip ClPair): its
+    output must be bit-identical to the layer-by-layer launches (same arithmetic, the glue folded into the lower
+    layer's store), close to the fp32 oracle, and leave no cluster fault."""
+    from music_generator_amd.engine import Engine
+    ocfg, dcfg = _cfgs(time_steps=T, num_notes=N, dtype="bf16")
+    params = O.init_params(ocfg, seed=11)
+    flat = torch.from_numpy(O.flatten_params(ocfg, params)).to(gpu_device)
+    notes, chosen, beat, style, target = O.synthetic_batch(ocfg, G, seed=4, T=T)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(gpu_device)
+    eng = Engine(dcfg, G, T, device=gpu_device)
+    monkeypatch.delenv("DEEPJ_CLUSTER_PAIR", raising=False)
+    pair = eng.time_model_predict(flat, d(notes), d(beat), d(style)).float().cpu().numpy()
+    pair2 = eng.time_model_predict(flat, d(notes), d(beat), d(style)).float().cpu().numpy()
+    monkeypatch.setenv("DEEPJ_CLUSTER_PAIR", "0")
+    seq = eng.time_model_predict(flat, d(notes), d(beat), d(style)).float().cpu().numpy()
+    monkeypatch.delenv("DEEPJ_CLUSTER_PAIR", raising=False)
+    assert eng.cluster_faults() == 0
+    assert np.isfinite(pair).all()
+    np.testing.assert_array_equal(pair, pair2)
+    np.testing.assert_array_equal(pair, seq)
+    tref = O.time_model_predict(ocfg, params, notes, beat, style)
+    assert np.abs(pair - tref).max() < 3e-2
+
+
 def test_seed_reproducible_and_mask_sensitive(gpu_device):
     T, B = 4, 2
     ocfg, dcfg = _cfgs(time_steps=T)
