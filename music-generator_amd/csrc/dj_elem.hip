@@ -442,49 +442,64 @@ __global__ __launch_bounds__(256) void feature_bwd_kernel(FeatArgs a, const T* _
 // ------------------------------------------------------------------ inter-layer glue
 
 // x_next = concat[drop(h), shift(drop(chosen))] + drop(tanh-style)   (model.py:85,77-82 / 101-117)
-// One workgroup per (b,t); thread = (8-column chunk, note group), notes strided by the group count:
-// no per-element index division, 16-byte accesses, the style row is read once per thread.
+// One workgroup per (b,t), two passes: (1) the 8-column chunks that lie wholly inside h -- thread = (chunk, note group),
+// notes strided by the group count: no per-element index division, 16-byte accesses, the style row read once per
+// thread; (2) the remaining chunk(s) (note layer 0: the three `chosen` columns + padding), thread = (note, chunk).
+// With both kinds in one loop the few tail lanes of every wave dragged the wave through their per-element path (three
+// dependent loads and hashes) in every iteration: the 264-column launch ran at 2 TB/s, the others at 4.6-5.6.
 template <typename T>
 __global__ __launch_bounds__(256) void glue_fwd_kernel(GlueArgs a, const T* __restrict__ Hin, T* __restrict__ X) {
   const int bt = blockIdx.x, t = bt % a.T, b = bt / a.T;
-  const int chunks = a.DP / 8, groups = 256 / chunks;
-  const int ch = threadIdx.x % chunks, grp = threadIdx.x / chunks;
-  if (grp >= groups) return;
-  const int d0 = ch * 8;
-  const bool whole_h = d0 + 8 <= a.Hd;
-  float spv[8];
+  const int chunks = a.DP / 8, nwh = a.Hd / 8;            // all chunks / chunks wholly inside h
+  if (nwh > 0) {
+    const int groups = 256 / nwh;
+    const int ch = threadIdx.x % nwh, grp = threadIdx.x / nwh;
+    if (grp < groups) {
+      const int d0 = ch * 8;
+      float spv[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) spv[e] = (a.sp && d0 + e < a.D) ? a.sp[(int64_t)bt * a.D + d0 + e] : 0.f;
-  for (int n = grp; n < a.N; n += groups) {
+      for (int e = 0; e < 8; ++e) spv[e] = (a.sp && d0 + e < a.D) ? a.sp[(int64_t)bt * a.D + d0 + e] : 0.f;
+      for (int n = grp; n < a.N; n += groups) {
+        const uint32_t r = (uint32_t)bt * a.N + n;
+        const int64_t rin = a.in_na ? dj_row_na(b, t, n, a.T, a.N) : dj_row_ta(b, t, n, a.T, a.N);
+        const int64_t rout = a.out_na ? dj_row_na(b, t, n, a.T, a.N) : dj_row_ta(b, t, n, a.T, a.N);
+        const uint32_t ko = dj_rowkey(a.d_out, r), ks = dj_rowkey(a.d_style, r);
+        float v[8];
+        load8(Hin + rin * a.Hd + d0, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= dj_keep(a.d_out, ko, d0 + e);
+        if (a.sp) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (d0 + e < a.D) v[e] += spv[e] * dj_keep(a.d_style, ks, d0 + e);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (d0 + e >= a.D) v[e] = 0.f;
+        store8(X + rout * a.DP + d0, v);
+      }
+    }
+  }
+  const int ntail = chunks - nwh;                          // chunks that straddle or follow the end of h
+  for (int i = threadIdx.x; i < a.N * ntail; i += 256) {
+    const int n = i / ntail, d0 = (nwh + i % ntail) * 8;
     const uint32_t r = (uint32_t)bt * a.N + n;
     const int64_t rin = a.in_na ? dj_row_na(b, t, n, a.T, a.N) : dj_row_ta(b, t, n, a.T, a.N);
     const int64_t rout = a.out_na ? dj_row_na(b, t, n, a.T, a.N) : dj_row_ta(b, t, n, a.T, a.N);
     const uint32_t ko = dj_rowkey(a.d_out, r), ks = dj_rowkey(a.d_style, r);
+    const uint32_t kc = (a.chosen && n > 0) ? dj_rowkey(a.d_chosen, r - 1) : 0u;
     float v[8];
-    if (whole_h) {                             // whole chunk comes from the producing layer's h
-      load8(Hin + rin * a.Hd + d0, v);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= dj_keep(a.d_out, ko, d0 + e);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int d = d0 + e;
-        v[e] = 0.f;
-        if (d < a.Hd)
-          v[e] = dj_to_f32(Hin[rin * a.Hd + d]) * dj_keep(a.d_out, ko, d);
-        else if (a.chosen && d < a.Hd + 3 && n > 0)
-          v[e] = a.chosen[(int64_t)(r - 1) * 3 + (d - a.Hd)] *
-                 dj_keep(a.d_chosen, dj_rowkey(a.d_chosen, r - 1), d - a.Hd);
-      }
+    for (int e = 0; e < 8; ++e) {
+      const int d = d0 + e;
+      v[e] = 0.f;
+      if (d < a.Hd)
+        v[e] = dj_to_f32(Hin[rin * a.Hd + d]) * dj_keep(a.d_out, ko, d);
+      else if (a.chosen && d < a.Hd + 3 && n > 0)
+        v[e] = a.chosen[(int64_t)(r - 1) * 3 + (d - a.Hd)] * dj_keep(a.d_chosen, kc, d - a.Hd);
+      if (a.sp && d < a.D) v[e] += a.sp[(int64_t)bt * a.D + d] * dj_keep(a.d_style, ks, d);
+      if (d >= a.D) v[e] = 0.f;
     }
-    if (a.sp) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        if (d0 + e < a.D) v[e] += spv[e] * dj_keep(a.d_style, ks, d0 + e);
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (d0 + e >= a.D) v[e] = 0.f;
     store8(X + rout * a.DP + d0, v);
   }
 }
