@@ -168,6 +168,16 @@ __device__ __forceinline__ void dj_store4(bf16_t* p, float a, float b, float c, 
 __device__ __forceinline__ void dj_store4(float* p, float a, float b, float c, float d) {
   *(float4*)p = make_float4(a, b, c, d);
 }
+// Sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: four v_add_f32 with a DPP operand
+// (row_mirror, row_half_mirror, quad_perm [1,0,3,2], quad_perm [2,3,0,1]) instead of four ds_bpermute round trips
+// through the LDS crossbar, which is what __shfl_xor compiles to.
+__device__ __forceinline__ float dj_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+  return v;
+}
 // write 16 fp32 values as a fragment (round to T)
 __device__ __forceinline__ void store_frag(float* p, const float (&x)[16]) {
 #pragma unroll

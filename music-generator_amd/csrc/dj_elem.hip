@@ -636,9 +636,9 @@ __global__ __launch_bounds__(256) void head_loss_wide_kernel(HeadArgs a, const T
     l2 += b2;
     const float p0 = dj_sigmoid(l0), p1 = dj_sigmoid(l1);
     if (a.out && lane == 0) {
-      a.out[rr * 3] = p0;
-      a.out[rr * 3 + 1] = p1;
-      a.out[rr * 3 + 2] = l2;
+      a.out[(int64_t)rr * 3] = p0;
+      a.out[(int64_t)rr * 3 + 1] = p1;
+      a.out[(int64_t)rr * 3 + 2] = l2;
     }
     if (!a.target) continue;
     float dl0, dl1, dl2, Lv;
@@ -701,12 +701,17 @@ __global__ __launch_bounds__(256) void head_loss_kernel(HeadArgs a, const T* __r
   }
   const float b0 = a.bn[0], b1 = a.bn[1], b2 = a.bv[0];
   float gb0 = 0.f, gb1 = 0.f, gb2 = 0.f, lsum = 0.f;
-  const int64_t rows = (int64_t)a.B * a.T * a.N;
-  for (int64_t base = wave * RPW; base < rows; base += nwaves * RPW) {
-    const int64_t r = base + slot;
+  // 32-bit row arithmetic (the launcher refuses more than 2^31 rows): the three 64-bit divisions per row that stood
+  // here cost more instructions than the head itself and 50 registers (152 VGPRs = 3 waves per SIMD)
+  const uint32_t rows = (uint32_t)a.B * (uint32_t)a.T * (uint32_t)a.N;
+  const uint32_t stride = (uint32_t)(nwaves * RPW), uN = (uint32_t)a.N, uT = (uint32_t)a.T;
+#pragma unroll 1
+  for (uint32_t base = (uint32_t)wave * RPW; base < rows; base += stride) {
+    const uint32_t r = base + slot;
     const bool live = r < rows;
-    const int64_t rr = live ? r : rows - 1;
-    const int n = rr % a.N, bt = rr / a.N, t = bt % a.T, b = bt / a.T;
+    const uint32_t rr = live ? r : rows - 1;
+    const uint32_t ubt = rr / uN;
+    const int n = (int)(rr - ubt * uN), bt = (int)ubt, b = (int)(ubt / uT), t = (int)(ubt - (uint32_t)b * uT);
     const int64_t row = dj_row_na(b, t, n, a.T, a.N);
     const uint32_t rk = dj_rowkey(a.d_out, (uint32_t)rr);
     float x[8], kp[8];
@@ -720,23 +725,29 @@ __global__ __launch_bounds__(256) void head_loss_kernel(HeadArgs a, const T* __r
       l1 += x[e] * w1[e];
       l2 += x[e] * w2[e];
     }
+    if constexpr (LPR == 16) {          // a row is one DPP row
+      l0 = dj_row16_sum(l0);
+      l1 = dj_row16_sum(l1);
+      l2 = dj_row16_sum(l2);
+    } else {
 #pragma unroll
-    for (int sft = LPR / 2; sft > 0; sft >>= 1) {
-      l0 += __shfl_xor(l0, sft);
-      l1 += __shfl_xor(l1, sft);
-      l2 += __shfl_xor(l2, sft);
+      for (int sft = LPR / 2; sft > 0; sft >>= 1) {
+        l0 += __shfl_xor(l0, sft);
+        l1 += __shfl_xor(l1, sft);
+        l2 += __shfl_xor(l2, sft);
+      }
     }
     l0 += b0;
     l1 += b1;
     l2 += b2;
     const float p0 = dj_sigmoid(l0), p1 = dj_sigmoid(l1);
     if (a.out && live && sub == 0) {
-      a.out[rr * 3] = p0;
-      a.out[rr * 3 + 1] = p1;
-      a.out[rr * 3 + 2] = l2;
+      a.out[(int64_t)rr * 3] = p0;
+      a.out[(int64_t)rr * 3 + 1] = p1;
+      a.out[(int64_t)rr * 3 + 2] = l2;
     }
     if (!a.target || !live) continue;
-    const float t0 = a.target[rr * 3], t1 = a.target[rr * 3 + 1], t2 = a.target[rr * 3 + 2];
+    const float t0 = a.target[(int64_t)rr * 3], t1 = a.target[(int64_t)rr * 3 + 1], t2 = a.target[(int64_t)rr * 3 + 2];
     const float played = t0;
     float pc;
     bool inr;
@@ -1008,6 +1019,7 @@ int dj_launch_glue_bwd(int dtype, const void* ga, const void* dX, void* dH, floa
 int dj_launch_head(int dtype, const void* ha, const void* Hn, void* dH, hipStream_t st) {
   const HeadArgs& a = *(const HeadArgs*)ha;
   int64_t rows = (int64_t)a.B * a.T * a.N;
+  if (rows >= ((int64_t)1 << 31) - (1 << 20)) return 1026;      // 32-bit row arithmetic in the kernels
   int grid = (int)((rows + 15) / 16 < 2048 ? (rows + 15) / 16 : 2048);
   if (a.Hd == 128) {
     DJ_T_DISPATCH(hipLaunchKernelGGL((head_loss_kernel<float, 128>), dim3(grid), dim3(256), 0, st, a, (const float*)Hn,
