@@ -143,7 +143,11 @@ def test_gemm_nt(gpu_device, dtype, M, N, K):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("M,Ka,kv,N,shift,steps", [(1024, 96, 94, 512, 0, 0), (2048, 264, 259, 512, 0, 0),
-                                                   (1536, 128, 128, 512, 32, 6), (4096, 256, 256, 1024, 32, 8)])
+                                                   (1536, 128, 128, 512, 32, 6), (4096, 256, 256, 1024, 32, 8),
+                                                   # small outputs (bf16: one accumulator tile per wave): the conv
+                                                   # kernel gradient's shape, row counts that leave waves idle, narrower operands
+                                                   (98304, 80, 72, 64, 0, 0), (960, 80, 72, 64, 0, 0),
+                                                   (64, 96, 96, 64, 0, 0), (4992, 40, 33, 16, 0, 0)])
 def test_gemm_tn(gpu_device, dtype, M, Ka, kv, N, shift, steps):
     L, lib = _lib()
     g = torch.Generator().manual_seed(M + Ka)
