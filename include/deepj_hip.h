@@ -135,6 +135,18 @@ int32_t dj_generate_step_resident(const dj_config* cfg, const float* params, voi
                                   const double* uniform_pool, const float* notes_src, float* notes_dst,
                                   const float* beat_src, float* beat_dst, const float* style_win, void* workspace,
                                   int64_t workspace_bytes, void* stream);
+/* The part of a generated step that depends on the parameters and the style window only -- weight packing, style
+ * embedding and projections (model.py:141-142,77,110-113), the transposed conv kernel, the sampler's style terms -- can
+ * be done ONCE per run: dj_generate_prepare leaves it in the workspace, dj_generate_step_prepared is
+ * dj_generate_step_resident without that part (same arguments, same results bit for bit).  Contract: the same cfg,
+ * params, style_win and workspace as the dj_generate_prepare call, and nothing else has used the workspace in
+ * between (call dj_generate_prepare again after any other use; it costs ~70 us). */
+int32_t dj_generate_prepare(const dj_config* cfg, const float* params, const float* style_win, void* workspace,
+                            int64_t workspace_bytes, void* stream);
+int32_t dj_generate_step_prepared(const dj_config* cfg, const float* params, void* state, float* results,
+                                  const double* uniform_pool, const float* notes_src, float* notes_dst,
+                                  const float* beat_src, float* beat_dst, const float* style_win, void* workspace,
+                                  int64_t workspace_bytes, void* stream);
 
 /* ---- single-kernel entry points (unit-tested against the oracle one by one) ---- */
 

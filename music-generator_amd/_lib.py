@@ -72,6 +72,8 @@ _SIGS = {
     "dj_gen_state_size": (C.c_int32, []),
     "dj_generate_step_resident": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "dj_generate_step": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "dj_generate_prepare": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, C.c_int64, _P]),
+    "dj_generate_step_prepared": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
 }
 OPTIONAL = set()
 

@@ -192,6 +192,9 @@ struct Ctx {
   hipStream_t st;
   bool train;
   uint64_t seed;
+  // generation with dj_generate_prepare done: packed weights, style embedding / projections and the transposed conv
+  // kernel in the workspace are current (they depend on the parameters and the style vector only)
+  bool static_ready = false;
   template <typename X = void> X* at(int64_t off) const { return (X*)(ws + off); }
 };
 
@@ -318,7 +321,7 @@ int time_axis_forward(const Ctx& c, const float* notes, const float* beat) {
   const float pin = p.c.input_dropout, pdr = p.c.dropout;
   DjDrop d_notes = mkdrop(c.seed, DJ_SITE_NOTES, pin, c.train);
   RUN(dj_launch_bins(notes, c.at<float>(p.w_bins), p.B, p.T, p.N, p.c.octave, d_notes, c.st));
-  RUN(style_proj_all(c, p.tl, p.w_sp_t, p.Lt));
+  if (!c.static_ready) RUN(style_proj_all(c, p.tl, p.w_sp_t, p.Lt));
   FeatArgs fa;
   fa.notes = notes; fa.beat = beat; fa.bins = c.at<float>(p.w_bins); fa.sp0 = c.at<float>(p.w_sp_t[0]);
   fa.Wc = c.P + p.p_conv_W; fa.bc = c.P + p.p_conv_b;
@@ -329,7 +332,7 @@ int time_axis_forward(const Ctx& c, const float* notes, const float* beat) {
   {
     ProfScope ps(PC_FEATURE_FWD, c.st);
     // conv as im2col GEMM on the MFMA units: Xcol -> Y = Xcol Wc + bc -> tanh / dropout / assembly
-    RUN(dj_launch_cvt_transpose(dt, c.P + p.p_conv_W, 72, 64, c.at(p.w_WcT), 80, c.st));
+    if (!c.static_ready) RUN(dj_launch_cvt_transpose(dt, c.P + p.p_conv_W, 72, 64, c.at(p.w_WcT), 80, c.st));
     RUN(dj_launch_feature_xcol(dt, &fa, c.at(p.w_Xcol), c.st));
     RUN(dj_launch_gemm_nt(dt, (int)p.Mt, 64, 80, c.at(p.w_Xcol), 80, c.at(p.w_WcT), 80, c.at(p.w_Ycol), 64, 0,
                           c.P + p.p_conv_b, c.st));
@@ -721,15 +724,31 @@ int32_t dj_generate_step(const dj_config* cfg, const float* params, const float*
   return dj_launch_generate_notes(p.c.dtype, p.B, p.T, p.N, p.Ht, p.Hn, p.Ln, p.S, p.SU, params, offs,
                                   c.at(p.w_H_t[p.Lt - 1]), style_win + (int64_t)(p.T - 1) * p.S, (int64_t)p.T * p.S,
                                   c.at<float>(p.w_dX_n), uniforms, temperature, next_notes, draws_used, nullptr,
-                                  nullptr, p.c.recurrent_sigmoid, c.st);
+                                  nullptr, p.c.recurrent_sigmoid, 0, c.st);
 }
 
 int32_t dj_gen_state_size(void) { return dj_gen_state_bytes(); }
 
-int32_t dj_generate_step_resident(const dj_config* cfg, const float* params, void* state, float* results,
-                                  const double* uniform_pool, const float* notes_src, float* notes_dst,
-                                  const float* beat_src, float* beat_dst, const float* style_win, void* ws,
-                                  int64_t ws_bytes, void* stream) {
+namespace {
+// the part of a generated step that depends on the parameters and the style vector only: weight packing, style
+// embedding and projections, transposed conv kernel, the sampler's style terms
+int generate_static(const Ctx& c, const float* style_win, const int64_t* offs) {
+  const Plan& p = c.p;
+  for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], p.w_Wp_t[l], false));
+  RUN(style_forward(c, style_win));
+  return 0;
+}
+void generate_offs(const Plan& p, int64_t* offs) {
+  offs[0] = p.p_style_W; offs[1] = p.p_style_b; offs[2] = p.p_nd_W; offs[3] = p.p_nd_b; offs[4] = p.p_vd_W;
+  offs[5] = p.p_vd_b;
+  for (int l = 0; l < p.Ln; ++l) {
+    offs[6 + 5 * l] = p.nl[l].dW; offs[7 + 5 * l] = p.nl[l].db; offs[8 + 5 * l] = p.nl[l].W; offs[9 + 5 * l] = p.nl[l].U;
+    offs[10 + 5 * l] = p.nl[l].b;
+  }
+}
+int generate_resident(const dj_config* cfg, const float* params, void* state, float* results, const double* uniform_pool,
+                      const float* notes_src, float* notes_dst, const float* beat_src, float* beat_dst,
+                      const float* style_win, void* ws, int64_t ws_bytes, void* stream, bool static_ready) {
   Plan p;
   RUN(make_plan(cfg, p));
   RUN(check_ws(p, ws, ws_bytes));
@@ -739,21 +758,52 @@ int32_t dj_generate_step_resident(const dj_config* cfg, const float* params, voi
   const int64_t need = (int64_t)(8 * 64 + 4 * 8 * 512 + (int64_t)p.B * p.N * 4 * p.Hn) * 4;
   if (need > p.Mn * (int64_t)p.nl[0].DP * p.esz) return 1302;
   Ctx c{p, params, (char*)ws, (hipStream_t)stream, false, 0};
-  for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], p.w_Wp_t[l], false));
-  RUN(style_forward(c, style_win));
-  RUN(time_axis_forward(c, notes_src, beat_src));
+  c.static_ready = static_ready;
   int64_t offs[6 + 5 * MAXL];
-  offs[0] = p.p_style_W; offs[1] = p.p_style_b; offs[2] = p.p_nd_W; offs[3] = p.p_nd_b; offs[4] = p.p_vd_W;
-  offs[5] = p.p_vd_b;
-  for (int l = 0; l < p.Ln; ++l) {
-    offs[6 + 5 * l] = p.nl[l].dW; offs[7 + 5 * l] = p.nl[l].db; offs[8 + 5 * l] = p.nl[l].W; offs[9 + 5 * l] = p.nl[l].U;
-    offs[10 + 5 * l] = p.nl[l].b;
-  }
+  generate_offs(p, offs);
+  if (!static_ready) RUN(generate_static(c, style_win, offs));
+  RUN(time_axis_forward(c, notes_src, beat_src));
   RUN(dj_launch_generate_notes(p.c.dtype, p.B, p.T, p.N, p.Ht, p.Hn, p.Ln, p.S, p.SU, params, offs,
                                c.at(p.w_H_t[p.Lt - 1]), style_win + (int64_t)(p.T - 1) * p.S, (int64_t)p.T * p.S,
                                c.at<float>(p.w_dX_n), uniform_pool, nullptr, nullptr, nullptr, state, results,
-                               p.c.recurrent_sigmoid, c.st));
+                               p.c.recurrent_sigmoid, static_ready ? 1 : 0, c.st));
   return dj_launch_gen_advance(state, results, notes_src, notes_dst, beat_src, beat_dst, p.B, p.T, p.N, p.NB, c.st);
+}
+}  // namespace
+
+int32_t dj_generate_step_resident(const dj_config* cfg, const float* params, void* state, float* results,
+                                  const double* uniform_pool, const float* notes_src, float* notes_dst,
+                                  const float* beat_src, float* beat_dst, const float* style_win, void* ws,
+                                  int64_t ws_bytes, void* stream) {
+  return generate_resident(cfg, params, state, results, uniform_pool, notes_src, notes_dst, beat_src, beat_dst, style_win,
+                           ws, ws_bytes, stream, false);
+}
+// the same step for a workspace on which dj_generate_prepare has run with these parameters and this style window
+// (and nothing else since): the per-run constants are not recomputed
+int32_t dj_generate_step_prepared(const dj_config* cfg, const float* params, void* state, float* results,
+                                  const double* uniform_pool, const float* notes_src, float* notes_dst,
+                                  const float* beat_src, float* beat_dst, const float* style_win, void* ws,
+                                  int64_t ws_bytes, void* stream) {
+  return generate_resident(cfg, params, state, results, uniform_pool, notes_src, notes_dst, beat_src, beat_dst, style_win,
+                           ws, ws_bytes, stream, true);
+}
+int32_t dj_generate_prepare(const dj_config* cfg, const float* params, const float* style_win, void* ws, int64_t ws_bytes,
+                            void* stream) {
+  Plan p;
+  RUN(make_plan(cfg, p));
+  RUN(check_ws(p, ws, ws_bytes));
+  if (!params || !style_win) return 1210;
+  if (p.B > 8) return 1301;
+  const int64_t need = (int64_t)(8 * 64 + 4 * 8 * 512 + (int64_t)p.B * p.N * 4 * p.Hn) * 4;
+  if (need > p.Mn * (int64_t)p.nl[0].DP * p.esz) return 1302;
+  Ctx c{p, params, (char*)ws, (hipStream_t)stream, false, 0};
+  int64_t offs[6 + 5 * MAXL];
+  generate_offs(p, offs);
+  RUN(generate_static(c, style_win, offs));
+  RUN(style_proj_all(c, p.tl, p.w_sp_t, p.Lt));
+  RUN(dj_launch_cvt_transpose(p.c.dtype, c.P + p.p_conv_W, 72, 64, c.at(p.w_WcT), 80, c.st));
+  return dj_launch_generate_prep(p.B, p.T, p.N, p.Ht, p.Hn, p.Ln, p.S, p.SU, params, offs,
+                                 style_win + (int64_t)(p.T - 1) * p.S, (int64_t)p.T * p.S, c.at<float>(p.w_dX_n), c.st);
 }
 
 int32_t dj_lstm_pack_w(int32_t dtype, int32_t H, const float* W, int32_t D, void* wpack, void* stream) {

@@ -12,6 +12,7 @@
 // draw, generate.py:52-58); the number consumed is returned so the host can advance NumPy's
 // MT19937 stream by exactly that many draws.
 #include <cstdint>
+#include <cstring>
 #include <cstdlib>
 #include "dj_kernels.h"
 
@@ -549,13 +550,33 @@ int dj_launch_gen_advance(void* state, const float* results, const float* nsrc, 
 }
 int dj_gen_state_bytes() { return (int)sizeof(DjGenState); }
 
+// the sampler's style terms alone (gen_prep_kernel into the scratch): dj_generate_prepare
+int dj_launch_generate_prep(int G, int T, int N, int Ht, int Hn, int Ln, int S, int SU, const float* P, const int64_t* offs,
+                            const float* style_last, int64_t style_stride, float* scratch, hipStream_t st) {
+  if (G < 1 || G > GEN_MAXG || Ln < 1 || Ln > 4 || 4 * Hn > 1024 || (Hn % 32) || Ht + 3 > 512 || SU > 64 || S > 64) return 1300;
+  GenArgs a;
+  memset(&a, 0, sizeof(a));
+  a.G = G; a.N = N; a.Hn = Hn; a.Ht = Ht; a.Ln = Ln; a.S = S; a.SU = SU; a.T = T; a.P = P;
+  a.p_style_W = offs[0]; a.p_style_b = offs[1];
+  for (int l = 0; l < Ln; ++l) {
+    a.dW[l] = offs[6 + 5 * l]; a.db[l] = offs[7 + 5 * l];
+  }
+  a.D0 = Ht + 3;
+  a.style_last = style_last;
+  a.style_stride = style_stride;
+  a.svec = scratch;
+  hipLaunchKernelGGL(gen_prep_kernel, dim3(Ln), dim3(512), 0, st, a);
+  return (int)hipGetLastError();
+}
+
 // Htime: TA-ordered top time-axis h buffer of the window (operand dtype).  scratch: float workspace
 // of at least GEN_MAXG*64 + 4*GEN_MAXG*512 + G*N*4Hn floats.
 int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int Ln, int S, int SU, const float* P,
                              const int64_t* offs /* [6 + 5*Ln] */, const void* Htime, const float* style_last,
                              int64_t style_stride,
                              float* scratch, const double* uniforms, const float* temperature, float* next_notes,
-                             int* draws_used, void* state, float* results, int sigm, hipStream_t st) {
+                             int* draws_used, void* state, float* results, int sigm, int static_ready,
+                             hipStream_t st) {
   if (G < 1 || G > GEN_MAXG || Ln < 1 || Ln > 4 || 4 * Hn > 1024 || (Hn % 32) || Ht + 3 > 512 || SU > 64 || S > 64) return 1300;
   GenArgs a;
   a.G = G; a.N = N; a.Hn = Hn; a.Ht = Ht; a.Ln = Ln; a.S = S; a.SU = SU; a.T = T; a.P = P;
@@ -572,7 +593,8 @@ int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int
   a.zx0 = scratch + GEN_MAXG * 64 + 4 * GEN_MAXG * 512;
   a.uniforms = uniforms; a.temperature = temperature; a.next_notes = next_notes; a.draws_used = draws_used;
   a.state = (DjGenState*)state; a.results = results;
-  hipLaunchKernelGGL(gen_prep_kernel, dim3(Ln), dim3(512), 0, st, a);
+  // static_ready: the style terms in the scratch are current (they depend on the style vector and the weights only)
+  if (!static_ready) hipLaunchKernelGGL(gen_prep_kernel, dim3(Ln), dim3(512), 0, st, a);
   dim3 gz((4 * Hn + 255) / 256, G * ((N + ZX_NB - 1) / ZX_NB));
   if (dtype == DJ_F32)
     hipLaunchKernelGGL(gen_zx0_kernel<float>, gz, dim3(256), 0, st, a, (const float*)Htime);

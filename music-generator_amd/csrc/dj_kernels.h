@@ -137,11 +137,13 @@ int dj_launch_nadam(float* p, const float* g, float* m, float* v, int64_t n, con
 int dj_launch_ta_to_canonical(int dtype, const void* Hin, float* out, int B, int T, int N, int Hd, hipStream_t st);
 int dj_launch_canonical_to_na(int dtype, const float* in, void* out, int B, int T, int N, int Hd, hipStream_t st);
 // dj_gen.hip
+int dj_launch_generate_prep(int G, int T, int N, int Ht, int Hn, int Ln, int S, int SU, const float* P, const int64_t* offs,
+                            const float* style_last, int64_t style_stride, float* scratch, hipStream_t st);
 int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int Ln, int S, int SU, const float* P,
                              const int64_t* offs /* [6 + 5*Ln] */, const void* Htime, const float* style_last,
                              int64_t style_stride, float* scratch, const double* uniforms, const float* temperature,
                              float* next_notes, int* draws_used, void* state, float* results, int sigm,
-                             hipStream_t st);
+                             int static_ready, hipStream_t st);
 int dj_launch_gen_advance(void* state, const float* results, const float* nsrc, float* ndst, const float* bsrc,
                           float* bdst, int G, int T, int N, int NB, hipStream_t st);
 int dj_gen_state_bytes();

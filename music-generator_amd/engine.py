@@ -258,8 +258,9 @@ class ResidentGeneration:
     RNG-draw offset and emitted notes live in HBM; two ping-pong steps are captured into one
     hipGraph (through torch.cuda.CUDAGraph) and replayed.  `run(k, uniforms)` advances k steps."""
 
-    def __init__(self, engine: Engine, params, styles, default_temp=1.0, steps_cap=4096, use_graph=True):
+    def __init__(self, engine: Engine, params, styles, default_temp=1.0, steps_cap=4096, use_graph=True, prepared=True):
         self.e, self.params = engine, params
+        self.prepared = prepared          # False: dj_generate_step_resident, which redoes the per-run constants every step
         G, T, N = engine.batch, engine.time_steps, engine.cfg.num_notes
         dev = engine.device
         assert engine.lib.dj_gen_state_size() == GEN_STATE_DTYPE.itemsize
@@ -281,14 +282,26 @@ class ResidentGeneration:
         self.graph = None
         self._want_graph = use_graph
 
+    def _prepare(self):
+        """Per-run constants (packed weights, style terms, ...) into the workspace: dj_generate_prepare.  Every run()
+        starts with it, so other uses of the engine between two run() calls are fine."""
+        e = self.e
+        if not self.prepared:
+            return
+        with torch.cuda.device(e.device):
+            rc = e.lib.dj_generate_prepare(C.byref(e.c), _lib.ptr(self.params), _lib.ptr(self.style), e.ws_ptr, e.ws_bytes,
+                                           _stream_ptr())
+        _lib.check(rc, "dj_generate_prepare")
+
     def _step(self, src):
         e = self.e
+        fn = e.lib.dj_generate_step_prepared if self.prepared else e.lib.dj_generate_step_resident
         with torch.cuda.device(e.device):
-            rc = e.lib.dj_generate_step_resident(
+            rc = fn(
                 C.byref(e.c), _lib.ptr(self.params), _lib.ptr(self.state), _lib.ptr(self.results), _lib.ptr(self.pool),
                 _lib.ptr(self.notes[src]), _lib.ptr(self.notes[1 - src]), _lib.ptr(self.beat[src]),
                 _lib.ptr(self.beat[1 - src]), _lib.ptr(self.style), e.ws_ptr, e.ws_bytes, _stream_ptr())
-        _lib.check(rc, "dj_generate_step_resident")
+        _lib.check(rc, "dj_generate_step_prepared")
 
     def read_state(self):
         return self.state.cpu().numpy().view(GEN_STATE_DTYPE)[0]
@@ -307,6 +320,7 @@ class ResidentGeneration:
         assert st0 + k <= self.cap
         self.pool[:len(uniforms)].copy_(torch.as_tensor(np.asarray(uniforms, np.float64)))
         self._set_draw_off(0)
+        self._prepare()
         done = 0
         if self._want_graph and self.graph is None and self.cur == 0 and k >= 2:
             try:                                                  # capture two ping-pong steps once

@@ -347,6 +347,37 @@ def test_resident_graph_generation_matches_stepwise(gpu_device, monkeypatch):
     assert 0 < res[..., 0].sum() < res[..., 0].size              # some notes, some silence
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_prepared_generation_step_equals_resident_step(gpu_device, dtype):
+    """dj_generate_prepare + dj_generate_step_prepared (per-run constants done once) against dj_generate_step_resident
+    (redone every step): bit-equal notes, state and draw offset; another use of the engine between two run() calls
+    (which overwrites the workspace) must not matter, because every run() prepares again."""
+    from music_generator_amd.engine import Engine, ResidentGeneration, init_params_numpy
+    from music_generator_amd.dataset import compute_genre
+    ocfg, dcfg = _cfgs(dtype=dtype)
+    G, T, N = 3, dcfg.time_steps, dcfg.num_notes
+    eng = Engine(dcfg, G, T, device=gpu_device)
+    flat = init_params_numpy(dcfg, seed=21)
+    params = torch.from_numpy(flat).to(gpu_device)
+    styles = [compute_genre(i) for i in range(G)]
+    rng = np.random.RandomState(5)
+    u1, u2 = rng.random_sample(2 * N * G * 6), rng.random_sample(2 * N * G * 5)
+    outs = []
+    for prepared in (True, False):
+        run = ResidentGeneration(eng, params, styles, steps_cap=64, prepared=prepared)
+        a, da = run.run(6, u1)
+        # someone else uses the engine (and its workspace) between the two chunks
+        z = torch.zeros(G, T, N, 3, device=gpu_device)
+        eng.time_model_predict(params, z, torch.zeros(G, T, dcfg.notes_per_bar, device=gpu_device),
+                               torch.zeros(G, T, dcfg.num_styles, device=gpu_device))
+        b, db = run.run(5, u2)
+        st = run.read_state()
+        outs.append((a, da, b, db, int(st["step"]), int(st["near_ties"])))
+    for x, y in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(x, y)
+    assert outs[0][0][..., 0].sum() > 0
+
+
 def test_resident_graph_generation_1024_steps(gpu_device, monkeypatch):
     """BASELINE configs[3] at its stated length: 3 style vectors, 1024-step pieces, hipGraph-replayed
     device-resident step vs the step-wise API on the same weights: bit-equal rolls, same NumPy RNG
