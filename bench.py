@@ -241,7 +241,7 @@ def generation_bench(dtype, steps):
             "dtype": dtype, "hbm_gbs": round(gen_bytes / (dt / n) / 1e9, 1), "hbm_bytes_per_step": gen_bytes,
             "bound": "latency (M = 144 rows, 128 + 48 dependent steps per generated step)",
             "near_tie_draws": Gn.last_run_stats["near_ties"], "draws": Gn.last_run_stats["draws"],
-            "path": "dj_generate_step_resident (hipGraph replay), NumPy MT19937 draws in reference order"}
+            "path": "dj_generate_prepare + dj_generate_step_prepared (hipGraph replay), NumPy MT19937 draws in reference order"}
 
 
 def scaled_bench(args, dev, rank, world, dist):

@@ -254,7 +254,7 @@ GEN_STATE_DTYPE = np.dtype([("step", "<i4"), ("draw_off", "<i4"), ("near_ties", 
 
 
 class ResidentGeneration:
-    """Device-resident sampling run (dj_generate_step_resident): windows, temperature schedule,
+    """Device-resident sampling run (dj_generate_prepare + dj_generate_step_prepared): windows, temperature schedule,
     RNG-draw offset and emitted notes live in HBM; two ping-pong steps are captured into one
     hipGraph (through torch.cuda.CUDAGraph) and replayed.  `run(k, uniforms)` advances k steps."""
 
