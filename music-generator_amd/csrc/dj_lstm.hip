@@ -960,6 +960,227 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
     if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
+// Cooperative form of the body above for sweeps with at most ONE tile per cluster (generation: 5 tiles) in inference:
+// there a member's whole step -- 128 MFMAs and the cell update of 16 elements per lane -- sat on one wave while seven
+// idled, all of it on the latency chain of the exchange.  Here waves 0-3 take one GATE each (x W and h U of that gate:
+// a quarter of the products), park the pre-activations in LDS, and each then updates a quarter of the cells (accumulator
+// registers 4w .. 4w+3 of all four gates, lane-local as before); wave 0 sends the h slice.  Same sums in the same
+// order as the one-wave form: bit-identical results.  Two workgroup barriers per step; waves 4-7 only keep them company.
+template <bool SIGM, int NKX>
+__device__ __forceinline__ void lstm_fwd_cluster_coop_body(const bf16_t* __restrict__ X, int DP,
+                                                           const bf16_t* __restrict__ Wpack,
+                                                           const float* __restrict__ bias,
+                                                           const bf16_t* __restrict__ Upack, bf16_t* __restrict__ Hout,
+                                                           int steps, int* __restrict__ cl, int ntiles, const ClPair pr,
+                                                           int nblocks) {
+  using T = bf16_t;
+  constexpr int H = 256;
+  using R = RecCfg<T, H>;
+  using Frag = typename DjFrag<T>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Frag* Bw = (Frag*)smem_raw;                              // [4][NKX][64]  W slice of this member
+  Frag* Bu = Bw + 4 * NKX * 64;                            // [4][NKC][64]  U slice
+  unsigned char* hto = (unsigned char*)(Bu + 4 * R::NKC * 64);   // 8 x 4 KiB: x rounds of waves 0-3, h tile, gate buffer
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  const int bidx = (int)blockIdx.x - pr.role * nblocks;
+  const int xcd = bidx & 7, j = bidx >> 3, s = j & (CL_M - 1);
+  const int lcid = xcd + 8 * (j >> 3);
+  const int cid = lcid + pr.role * (nblocks >> 6) * 8;
+  const int64_t tile = lcid;                               // one tile per cluster
+  const bool live = tile < ntiles;                         // uniform for the workgroup
+  const bool gwave = w < 4;                                // gate waves; gate index = w
+  const int64_t hx_tile = tile + (int64_t)pr.role * 128;
+  int* cnt = cl + 2 * cid * CL_CNT_STRIDE;
+  int* xccs = cnt + CL_CNT_STRIDE;
+  int* fault = cl + CL_CNT_INTS;
+  uint4* hxb = (uint4*)((unsigned char*)cl + CL_OFF_HX);
+  constexpr int ARRIVALS = CL_M;
+  {
+    const uint4* gw = (const uint4*)((const Frag*)Wpack + (int64_t)s * 4 * NKX * 64);
+    const uint4* gu = (const uint4*)((const Frag*)Upack + (int64_t)s * 4 * R::NKC * 64);
+    for (int i = tid; i < 4 * NKX * 64; i += 512) ((uint4*)Bw)[i] = gw[i];
+    for (int i = tid; i < 4 * R::NKC * 64; i += 512) ((uint4*)Bu)[i] = gu[i];
+  }
+  float c4[4] = {0.f, 0.f, 0.f, 0.f};                      // cell state of accumulator registers 4w .. 4w+3
+  const float bvg = bias[(w & 3) * H + s * 32 + l31];      // bias of this wave's gate
+  const int my_xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15) + 1;
+  if (live && w == 0) {                                    // round 0 of the exchange: h_{-1} = 0
+    uint4* hxo = hxb + ((hx_tile * 2 + 1) * 16 + 2 * s) * 64 + lane;
+    hxo[0] = make_uint4(0, 0, 0, 0);
+    hxo[64] = make_uint4(0, 0, 0, 0);
+  }
+  if (tid == 0) __hip_atomic_store(xccs + s, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  {
+    bool ok = cl_wait(cnt, ARRIVALS, lane);
+    int other = my_xcc;
+    if (ok && lane < CL_M) other = __hip_atomic_load(xccs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool same = __all(other == my_xcc);
+    if (!ok || !same) {
+      if (lane == 0 && w == 0) atomicAdd(fault + (ok ? 1 : 0), 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c4[e] = __builtin_nanf("");
+    }
+  }
+  int* gate = pr.gate ? cl + 2 * lcid * CL_CNT_STRIDE : nullptr;
+  int seen = 0;
+  if (gate && live && gwave) {
+    seen = cl_wait_val(gate, ARRIVALS * 3, lane);
+    int other = my_xcc;
+    if (seen && lane < CL_M) other = __hip_atomic_load(gate + CL_CNT_STRIDE + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool same = __all(other == my_xcc);
+    if (!seen || !same) {
+      if (lane == 0 && w == 0) atomicAdd(fault + (seen ? 1 : 0), 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c4[e] = __builtin_nanf("");
+    }
+    asm volatile("" ::: "memory");
+  }
+  const float* spp[2] = {nullptr, nullptr};
+  if (pr.sp_out && live && w == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = lane + 64 * i, row = v >> 2, cq = (v & 3) * 8;
+      int64_t bb = (tile * 32 + row) / pr.n_seq;
+      if (bb > pr.n_b - 1) bb = pr.n_b - 1;
+      spp[i] = pr.sp_out + bb * steps * pr.sp_D + s * 32 + cq;
+    }
+  }
+  unsigned char* xs = hto + (w & 3) * 4096;                // this wave's x rounds
+  T* ht = (T*)hto;                                         // the h tile of the step (wave 0's slab, see the barriers)
+  float* zgate = (float*)(hto + 4 * 4096);                 // [4 gates][64 lanes][16] pre-activations
+  const int xr8 = lane >> 3, xc = lane & 7;
+  constexpr int NR = (NKX + 3) / 4, NRA = (NR + 1) / 2;
+  ClXRegs<NR> xq;
+  if (live && gwave) cl_load_x<NR, 0, NR>(xq, X + (tile * steps * 32 + xr8) * DP + xc * 8, DP, xc);
+  for (int t = 0; t < steps; ++t) {
+    if (!live || !gwave) {         // exactly the two workgroup barriers of a gate wave's step
+      __syncthreads();
+      __syncthreads();
+      continue;
+    }
+    const int64_t rb = tile * steps + t;
+    float4 spv[2][2];
+    if (pr.sp_out && w == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        spv[i][0] = *(const float4*)(spp[i] + (int64_t)t * pr.sp_D);
+        spv[i][1] = *(const float4*)(spp[i] + (int64_t)t * pr.sp_D + 4);
+      }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // ---- x_t W of gate w (before the wait)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *(uint4*)(xs + (xr8 + 8 * i) * 128 + ((xc ^ xr8) << 4)) = xq.v[r][i];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int kc = 4 * r + q;
+        if (kc < NKX) {
+          const Frag a = *(const Frag*)(xs + l31 * 128 + (((2 * q + h) ^ (l31 & 7)) << 4));
+          dj_mfma(acc, a, Bw[(w * NKX + kc) * 64 + lane]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    const T* xnext = X + ((tile * steps + (t + 1 < steps ? t + 1 : t)) * 32 + xr8) * DP + xc * 8;
+    // ---- h_{t-1} U of gate w
+    {
+      if (!cl_wait(cnt, ARRIVALS * (t + 1), lane)) {
+        if (lane == 0 && w == 0) atomicAdd(fault, 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c4[e] = __builtin_nanf("");
+      }
+      if (gate && t + 1 < steps && seen < ARRIVALS * (t + 4)) {
+        seen = cl_wait_val(gate, ARRIVALS * (t + 4), lane);
+        if (!seen) {
+          if (lane == 0 && w == 0) atomicAdd(fault, 1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) c4[e] = __builtin_nanf("");
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+      const uint4* hx = hxb + ((hx_tile * 2 + ((t + 1) & 1)) * 16) * 64 + lane;
+      uint4 ah[R::NKC];
+#pragma unroll
+      for (int kc = 0; kc < R::NKC; ++kc) ah[kc] = ld_sc1(hx + kc * 64);
+      asm volatile("" ::: "memory");
+      cl_load_x<NR, 0, NRA>(xq, xnext, DP, xc);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NRA) : "memory");
+#pragma unroll
+      for (int kc = 0; kc < R::NKC; ++kc) {
+        Frag a;
+        __builtin_memcpy(&a, &ah[kc], 16);
+        dj_mfma(acc, a, Bu[(w * R::NKC + kc) * 64 + lane]);
+      }
+    }
+    cl_load_x<NR, NRA, NR>(xq, xnext, DP, xc);
+    // ---- gate w of all 16 registers -> LDS; then registers 4w .. 4w+3 of all four gates back
+    {
+      float* zq = zgate + (w * 64 + lane) * 16;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+        *(float4*)(zq + 4 * r4) = make_float4(acc[4 * r4] + bvg, acc[4 * r4 + 1] + bvg, acc[4 * r4 + 2] + bvg, acc[4 * r4 + 3] + bvg);
+    }
+    __syncthreads();                                   // A: every gate is in LDS
+    {
+      const float4 zi4 = *(const float4*)(zgate + (0 * 64 + lane) * 16 + 4 * w);
+      const float4 zf4 = *(const float4*)(zgate + (1 * 64 + lane) * 16 + 4 * w);
+      const float4 zg4 = *(const float4*)(zgate + (2 * 64 + lane) * 16 + 4 * w);
+      const float4 zo4 = *(const float4*)(zgate + (3 * 64 + lane) * 16 + 4 * w);
+      const float zi[4] = {zi4.x, zi4.y, zi4.z, zi4.w}, zf[4] = {zf4.x, zf4.y, zf4.z, zf4.w};
+      const float zg[4] = {zg4.x, zg4.y, zg4.z, zg4.w}, zo[4] = {zo4.x, zo4.y, zo4.z, zo4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * w + e;
+        const float ig = dj_ract<SIGM>(zi[e]), fg = dj_ract<SIGM>(zf[e]), gg = dj_tanh(zg[e]), og = dj_ract<SIGM>(zo[e]);
+        const float cn = fg * c4[e] + ig * gg;
+        c4[e] = cn;
+        ht[dj_crow(r, lane) * 32 + l31] = dj_from_f32<T>(og * dj_tanh(cn));
+      }
+    }
+    __syncthreads();                                   // B: the h tile is complete (and the gate buffer is free again)
+    if (w == 0) {
+      // the exchange copy first (only it has to be acknowledged before the counter moves), then the row-major slice
+      {
+        uint4* hxo = hxb + ((hx_tile * 2 + (t & 1)) * 16 + 2 * s) * 64 + lane;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) hxo[jj * 64] = *(const uint4*)(ht + l31 * 32 + 16 * jj + 8 * h);
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int v = lane + 64 * i, row = v >> 2, cq = (v & 3) * 8;
+        uint4 hv = *(const uint4*)(ht + row * 32 + cq);
+        if (pr.sp_out) {
+          const float sp8[8] = {spv[i][0].x, spv[i][0].y, spv[i][0].z, spv[i][0].w,
+                                spv[i][1].x, spv[i][1].y, spv[i][1].z, spv[i][1].w};
+          T he[8], xo[8];
+          __builtin_memcpy(he, &hv, 16);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xo[e] = dj_from_f32<T>(dj_to_f32(he[e]) + sp8[e]);
+          __builtin_memcpy(&hv, xo, 16);
+        }
+        *(uint4*)(Hout + (rb * 32 + row) * H + s * 32 + cq) = hv;
+      }
+      asm volatile("" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (pr.sp_out) {          // the rows of the last step are out: one more round for the consuming layer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && live) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 template <bool SIGM, int NKX>
 __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __restrict__ X, int DP,
                                                                const bf16_t* __restrict__ Wpack,
@@ -979,16 +1200,22 @@ struct ClPairArgs {
   bf16_t* X1; const bf16_t* W1; const float* b1; const bf16_t* U1; bf16_t* H1;
   const float* sp1; int sp_D, n_seq, n_b;
 };
-template <bool SIGM>
+template <bool SIGM, bool COOP>
 __global__ __launch_bounds__(512) void lstm_fwd_cluster_pair_kernel(ClPairArgs a, int steps, int* __restrict__ cl, int ntiles) {
   const int nblocks = (int)gridDim.x >> 1;
   ClPair pr;
   if ((int)blockIdx.x < nblocks) {
     pr.sp_out = a.sp1; pr.sp_D = a.sp_D; pr.n_seq = a.n_seq; pr.n_b = a.n_b; pr.gate = nullptr; pr.role = 0;
-    lstm_fwd_cluster_body<SIGM, 8>(a.X0, a.DP0, a.W0, a.b0, nullptr, a.U0, a.X1, nullptr, steps, cl, ntiles, pr, nblocks);
+    if (COOP)
+      lstm_fwd_cluster_coop_body<SIGM, 8>(a.X0, a.DP0, a.W0, a.b0, a.U0, a.X1, steps, cl, ntiles, pr, nblocks);
+    else
+      lstm_fwd_cluster_body<SIGM, 8>(a.X0, a.DP0, a.W0, a.b0, nullptr, a.U0, a.X1, nullptr, steps, cl, ntiles, pr, nblocks);
   } else {
     pr.sp_out = nullptr; pr.sp_D = 0; pr.n_seq = 1; pr.n_b = 1; pr.gate = cl; pr.role = 1;
-    lstm_fwd_cluster_body<SIGM, 16>(a.X1, 256, a.W1, a.b1, nullptr, a.U1, a.H1, nullptr, steps, cl, ntiles, pr, nblocks);
+    if (COOP)
+      lstm_fwd_cluster_coop_body<SIGM, 16>(a.X1, 256, a.W1, a.b1, a.U1, a.H1, steps, cl, ntiles, pr, nblocks);
+    else
+      lstm_fwd_cluster_body<SIGM, 16>(a.X1, 256, a.W1, a.b1, nullptr, a.U1, a.H1, nullptr, steps, cl, ntiles, pr, nblocks);
   }
 }
 
@@ -1523,20 +1750,27 @@ int launch_fwd_cluster_pair(int ntiles, int steps, const ClPairArgs& a, int sigm
   static bool attr_done_dev[DJ_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[dj_current_device()];
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_cluster_pair_kernel<false>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)lstm_fwd_cluster_pair_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    if (e != hipSuccess) return (int)e;
+    const void* fns[4] = {(const void*)lstm_fwd_cluster_pair_kernel<false, false>, (const void*)lstm_fwd_cluster_pair_kernel<true, false>,
+                          (const void*)lstm_fwd_cluster_pair_kernel<false, true>, (const void*)lstm_fwd_cluster_pair_kernel<true, true>};
+    for (const void* fn : fns) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+    }
     attr_done = true;
   }
   hipError_t e = hipMemsetAsync(scratch, 0, CL_OFF_FAULT, st);
   if (e != hipSuccess) return (int)e;
-  if (sigm)
-    hipLaunchKernelGGL((lstm_fwd_cluster_pair_kernel<true>), dim3(128), dim3(512), smem, st, a, steps, (int*)scratch, ntiles);
-  else
-    hipLaunchKernelGGL((lstm_fwd_cluster_pair_kernel<false>), dim3(128), dim3(512), smem, st, a, steps, (int*)scratch, ntiles);
+  // at most one tile per cluster (8 clusters per layer): the cooperative body, four waves per tile
+  static const bool coop_off = getenv("DEEPJ_CLUSTER_COOP") && getenv("DEEPJ_CLUSTER_COOP")[0] == '0';
+  const bool coop = ntiles <= 8 && !coop_off;
+#define DJ_PAIR_LAUNCH(S, C_) \
+  hipLaunchKernelGGL((lstm_fwd_cluster_pair_kernel<S, C_>), dim3(128), dim3(512), smem, st, a, steps, (int*)scratch, ntiles)
+  if (sigm) {
+    if (coop) DJ_PAIR_LAUNCH(true, true); else DJ_PAIR_LAUNCH(true, false);
+  } else {
+    if (coop) DJ_PAIR_LAUNCH(false, true); else DJ_PAIR_LAUNCH(false, false);
+  }
+#undef DJ_PAIR_LAUNCH
   return (int)hipGetLastError();
 }
 
