@@ -49,10 +49,13 @@ template <typename T, bool SIGM>
 __global__ __launch_bounds__(256) void step_fwd_kernel(T* __restrict__ Z, const float* __restrict__ R,
                                                        float* __restrict__ cst, T* __restrict__ Hs,
                                                        T* __restrict__ Cs, int H, int nrows, int steps, int t) {
-  const int q = H >> 2;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)nrows * q) return;
-  const int v = (int)(idx / q), u = (int)(idx % q) * 4;
+  // 32-bit index arithmetic (the launchers refuse nrows * H / 4 >= 2^31): a 64-bit division and modulo per thread cost
+  // more instructions than the cell itself
+  const uint32_t q = (uint32_t)H >> 2;
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (uint32_t)nrows * q) return;
+  const uint32_t vq = idx / q;
+  const int v = (int)vq, u = (int)(idx - vq * q) * 4;
   const int64_t pr = step_row(v, steps, t);
   float z[4][4], c[4], hn[4];
 #pragma unroll
@@ -91,10 +94,13 @@ __global__ __launch_bounds__(256) void step_bwd_kernel(const T* __restrict__ Z, 
                                                        const T* __restrict__ dH, const float* __restrict__ Rb,
                                                        float* __restrict__ dcs, T* __restrict__ dZ, int H, int nrows,
                                                        int steps, int t) {
-  const int q = H >> 2;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)nrows * q) return;
-  const int v = (int)(idx / q), u = (int)(idx % q) * 4;
+  // 32-bit index arithmetic (the launchers refuse nrows * H / 4 >= 2^31): a 64-bit division and modulo per thread cost
+  // more instructions than the cell itself
+  const uint32_t q = (uint32_t)H >> 2;
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (uint32_t)nrows * q) return;
+  const uint32_t vq = idx / q;
+  const int v = (int)vq, u = (int)(idx - vq * q) * 4;
   const int64_t pr = step_row(v, steps, t);
   float z[4][4], ct[4], cp[4], dh[4], dcc[4], dz[4][4];
 #pragma unroll
@@ -209,6 +215,7 @@ int dj_launch_lstm_step_fwd(int dtype, int H, int ntiles, int steps, void* Z, co
                             float* scratch, int sigm, hipStream_t st) {
   if (ntiles <= 0 || steps <= 0) return 0;
   if (H < 32 || (H % 32)) return 1012;
+  if ((int64_t)ntiles * 32 * (H >> 2) >= ((int64_t)1 << 31)) return 1014;
   float* R = scratch;
   float* cst = scratch + (int64_t)ntiles * 32 * 4 * H;
   return dtype == DJ_F32 ? step_fwd_t<float>(H, ntiles, steps, Z, Ut, Hs, Cs, R, cst, sigm, st)
@@ -219,6 +226,7 @@ int dj_launch_lstm_step_bwd(int dtype, int H, int ntiles, int steps, const void*
                             const void* dH, void* dZ, float* dbias, float* scratch, int sigm, hipStream_t st) {
   if (ntiles <= 0 || steps <= 0) return 0;
   if (H < 32 || (H % 32)) return 1012;
+  if ((int64_t)ntiles * 32 * (H >> 2) >= ((int64_t)1 << 31)) return 1014;
   float* Rb = scratch;
   float* dcs = scratch + (int64_t)ntiles * 32 * 4 * H;
   return dtype == DJ_F32 ? step_bwd_t<float>(H, ntiles, steps, Z, Uc, Cs, dH, dZ, dbias, Rb, dcs, sigm, st)
