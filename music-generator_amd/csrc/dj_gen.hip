@@ -398,6 +398,14 @@ __global__ __launch_bounds__(512) void gen_sample_ks_kernel(GenArgs a) {
     }
   };
 
+  // barriers inside the note loop: LDS traffic only -- __syncthreads() also waits for vmcnt(0), i.e. for the next note's
+  // x W + b that the cell update has just requested (one exposed L2 round trip per note)
+  auto lds_barrier = [&]() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
   for (int n = 0; n < a.N; ++n) {
 #pragma unroll 1
     for (int l = 0; l < Ln; ++l) {
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(512) void gen_sample_ks_kernel(GenArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         if (g < G) *(float4*)(zp + ((int64_t)(ks * G + g)) * C4 + 4 * cg) = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
-      __syncthreads();
+      lds_barrier();
       // ---- cell update (Keras gate order i,f,c,o): unit (g, u) = (cu_g, cu_u)
       if (cell) {
         float z[4];
@@ -437,22 +445,23 @@ __global__ __launch_bounds__(512) void gen_sample_ks_kernel(GenArgs a) {
         hs[si] = hv;
         if (l + 1 < Ln) xs[cu_g * Hn + cu_u] = hv + spl[((l + 1) * G + cu_g) * Hn + cu_u];
       }
-      __syncthreads();
+      lds_barrier();
     }
-    // ---- heads: (play, replay) = sigmoid(h Wn + bn), volume = h Wv + bv   (model.py:94-95)
+    // ---- heads: (play, replay) = sigmoid(h Wn + bn), volume = h Wv + bv   (model.py:94-95); one 32-lane half wave
+    // per (piece, output): all G x 3 sums in one round, DPP row sums + one cross-row exchange
     {
-      const int wv = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
-      const float* ht = hs + (Ln - 1) * G * Hn;
-      for (int job = wv; job < G * 3; job += nw) {
-        const int g = job / 3, o = job % 3;
+      const int half = tid >> 5, l32 = tid & 31;
+      if (half < G * 3) {
+        const int g = half / 3, o = half - g * 3;
+        const float* ht = hs + ((Ln - 1) * G + g) * Hn;
         float s = 0.f;
-        for (int k = lane; k < Hn; k += 64) s += ht[g * Hn + k] * hw[o * Hn + k];
-#pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) s += __shfl_xor(s, sft);
-        if (lane == 0) logit[g * 4 + o] = s + hw[3 * Hn + o];
+        for (int k = l32; k < Hn; k += 32) s += ht[k] * hw[o * Hn + k];
+        s = dj_row16_sum(s);
+        s += __shfl_xor(s, 16);
+        if (l32 == 0) logit[g * 4 + o] = s + hw[3 * Hn + o];
       }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- sampling, reference draw order (generate.py:47-58,116-118)
     if (tid == 0) {
       int k = kdraw;
@@ -485,8 +494,9 @@ __global__ __launch_bounds__(512) void gen_sample_ks_kernel(GenArgs a) {
       }
       kdraw = k;
     }
-    __syncthreads();
+    lds_barrier();
   }
+  __syncthreads();
   float* out_notes = a.state ? a.results + (int64_t)a.state->step * G * a.N * 3 : a.next_notes;
   for (int i = tid; i < G * a.N * 3; i += blockDim.x) out_notes[i] = res[i];
   if (tid == 0) {
