@@ -227,6 +227,8 @@ def generation_bench(dtype, steps):
                 break
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        for _ in g:                               # let the generator finish: it reads the near-tie census at its end
+            pass
     # ALGORITHMIC HBM bytes of one generated time step: the stateless 128-step window through the time axis
     # (generate.py:106-109) plus one pass over the fp32 weights; the note loop runs out of L2.  Per row and layer:
     # bf16 (x W fused into the weight-stationary cluster sweep): x in, h out = (D + H) elements; fp32 (separate

@@ -277,7 +277,7 @@ class ResidentGeneration:
         host["silent"][0, :G] = engine.cfg.notes_per_bar          # generate.py:24
         host["first_near_step"] = -1
         self.state = torch.from_numpy(host.view(np.uint8).copy()).to(dev)
-        self.pool = torch.zeros(2 * N * G * 64, dtype=torch.float64, device=dev)
+        self.pool = torch.zeros(2 * N * G * 128, dtype=torch.float64, device=dev)
         self.cur = 0                                              # which window buffer is current
         self.graph = None
         self._want_graph = use_graph

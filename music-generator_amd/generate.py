@@ -91,7 +91,9 @@ def process_inputs(ins):
     return [np.array(col) for col in zip(*ins)]
 
 
-GEN_CHUNK = NOTES_PER_BAR          # time steps per device launch batch of the resident path
+# time steps per device launch batch of the resident path: the host work of a batch (two state read-backs, the pool
+# upload, the per-run constants, the result copy) is not overlapped with the device, so it is spread over four bars
+GEN_CHUNK = 4 * NOTES_PER_BAR
 
 # Filled by the fused paths of generate(): how many Bernoulli draws of the last run fell within 1e-5 of the
 # probability they were compared with, and the time step of the first one (-1 = none).  Zero near ties certifies
