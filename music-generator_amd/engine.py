@@ -344,6 +344,9 @@ class ResidentGeneration:
                 self.cur ^= 1
                 done += 1
         out = self.results[st0:st0 + k].cpu().numpy()
+        # a cluster fault (expired wait, members of a cluster on different XCDs) poisons the affected rows with NaN,
+        # which the sampler would turn into silence: never hand such notes out
+        self.e.raise_on_cluster_faults("generation")
         return out, int(self.read_state()["draw_off"])
 
 

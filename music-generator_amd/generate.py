@@ -135,6 +135,8 @@ def _fused_step(shared, engine, pieces):
     nxt, used = engine.generate_step(shared.params, be.tensor(notes), be.tensor(beat), be.tensor(style), u_dev, temps)
     nxt = be.numpy(nxt)
     used = used.cpu().numpy()
+    if hasattr(engine, "raise_on_cluster_faults"):        # NaN-poisoned rows would be sampled as silence
+        engine.raise_on_cluster_faults("generation")
     np.random.random_sample(int(used[0]))
     last_run_stats["draws"] += int(used[0])
     last_run_stats["near_ties"] += int(used[1])

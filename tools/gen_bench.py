@@ -24,4 +24,4 @@ def run(dtype, bars, slow=False):
     print(f"[{dtype}{' slow' if slow else ''}] {n} steps: {dt/n*1e3:.2f} ms/step, {3*48*n/dt:.0f} notes/s", flush=True)
 
 if __name__ == "__main__":
-    run("f32", 4); run("bf16", 4); run("bf16", 1, slow=True)
+    run("f32", 12); run("bf16", 12); run("bf16", 1, slow=True)

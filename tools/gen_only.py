@@ -16,6 +16,6 @@ if len(sys.argv) > 2:
         for _ in Gn.generate(models, bars, styles):
             pass
         torch.cuda.synchronize()
-    run(sys.argv[1], 3)
+    run(sys.argv[1], 12)
 else:
-    gb.run(sys.argv[1] if len(sys.argv) > 1 else "bf16", 3)
+    gb.run(sys.argv[1] if len(sys.argv) > 1 else "bf16", 12)
