@@ -757,7 +757,8 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
     bool ok = cl_wait(cnt, ARRIVALS, lane);
     int other = my_xcc;
     if (ok && lane < CL_M) other = __hip_atomic_load(xccs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool same = __all(other == my_xcc);
+    // fault[2]: test hook (DEEPJ_DEBUG_CLUSTER_FAULT): the launch behaves as if its clusters were spread over XCDs
+    const bool same = __all(other == my_xcc) && __hip_atomic_load(fault + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
     if (!ok || !same) {
       if (lane == 0 && w == 0) atomicAdd(fault + (ok ? 1 : 0), 1);
 #pragma unroll
@@ -1017,7 +1018,8 @@ __device__ __forceinline__ void lstm_fwd_cluster_coop_body(const bf16_t* __restr
     bool ok = cl_wait(cnt, ARRIVALS, lane);
     int other = my_xcc;
     if (ok && lane < CL_M) other = __hip_atomic_load(xccs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool same = __all(other == my_xcc);
+    // fault[2]: test hook (DEEPJ_DEBUG_CLUSTER_FAULT): the launch behaves as if its clusters were spread over XCDs
+    const bool same = __all(other == my_xcc) && __hip_atomic_load(fault + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
     if (!ok || !same) {
       if (lane == 0 && w == 0) atomicAdd(fault + (ok ? 1 : 0), 1);
 #pragma unroll
@@ -1728,6 +1730,27 @@ int cluster_cus() {
   }
   return cus[dev];
 }
+// Test hook: with DEEPJ_DEBUG_CLUSTER_FAULT set, the next launches fail their placement check (word 2 of the fault
+// line), so that the host-side handling (fallback in fit, errors in predict / generation) can be exercised on hardware.
+int cluster_fault_hook(void* scratch, hipStream_t st) {
+  static void* armed[16] = {};                        // scratches whose hook word is set (a handful of engines at most)
+  const char* e = getenv("DEEPJ_DEBUG_CLUSTER_FAULT");
+  const bool want = e && e[0] != '0';
+  int slot = -1, free_slot = -1;
+  for (int i = 0; i < 16; ++i) {
+    if (armed[i] == scratch) slot = i;
+    if (!armed[i] && free_slot < 0) free_slot = i;
+  }
+  if (want && slot < 0) {
+    if (free_slot < 0) return 1018;
+    if (hipMemsetAsync((char*)scratch + CL_OFF_FAULT + 8, 1, 4, st) != hipSuccess) return 1018;
+    armed[free_slot] = scratch;
+  } else if (!want && slot >= 0) {
+    if (hipMemsetAsync((char*)scratch + CL_OFF_FAULT + 8, 0, 4, st) != hipSuccess) return 1018;
+    armed[slot] = nullptr;
+  }
+  return 0;
+}
 int launch_fwd_cluster(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
                        void* Zst, const void* Upack, void* Hout, void* Cout, int sigm, void* scratch, hipStream_t st) {
   using R = RecCfg<bf16_t, 256>;
@@ -1737,6 +1760,7 @@ int launch_fwd_cluster(int ntiles, int steps, const void* X, int DP, int NKX, co
   // counters and XCC ids of every cluster start at zero in every launch (a memset node under graph capture)
   hipError_t e = hipMemsetAsync(scratch, 0, CL_OFF_FAULT, st);
   if (e != hipSuccess) return (int)e;
+  if (int rc = cluster_fault_hook(scratch, st)) return rc;
   return sigm ? launch_fwd_cluster_s<true>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st)
               : launch_fwd_cluster_s<false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st);
 }
@@ -1760,6 +1784,7 @@ int launch_fwd_cluster_pair(int ntiles, int steps, const ClPairArgs& a, int sigm
   }
   hipError_t e = hipMemsetAsync(scratch, 0, CL_OFF_FAULT, st);
   if (e != hipSuccess) return (int)e;
+  if (int rc = cluster_fault_hook(scratch, st)) return rc;
   // at most one tile per cluster (8 clusters per layer): the cooperative body, four waves per tile
   static const bool coop_off = getenv("DEEPJ_CLUSTER_COOP") && getenv("DEEPJ_CLUSTER_COOP")[0] == '0';
   const bool coop = ntiles <= 8 && !coop_off;

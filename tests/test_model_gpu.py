@@ -2,6 +2,7 @@
 the CPU oracle on the same seeded inputs.  north_star tolerance: 1e-3 relative on the
 outputs ("logits") in fp32 mode; gradients are checked at 2e-3 relative to the
 per-tensor max (fp32 atomics reorder sums).  bf16 mode is checked at bf16 tolerance."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -239,6 +240,50 @@ def test_keras_surface_on_hip(gpu_device, tmp_path):
     hm2 = build_models(time_steps=T, seed=9)
     hm2[0].load_weights(ck)
     np.testing.assert_array_equal(hm2[0].get_weights()[5], hm[0].get_weights()[5])
+
+
+def test_injected_cluster_fault_is_never_silent(gpu_device, monkeypatch, capsys):
+    """DEEPJ_DEBUG_CLUSTER_FAULT makes the bf16 cluster kernels fail their placement check on the device (rows
+    poisoned with NaN, the event counted in the workspace).  What the host side must make of it: train_on_batch
+    notices before the optimizer step, switches the process to the per-tile kernel and repeats the step -- the result
+    equals a fault-free step on the per-tile kernel; predict, evaluate and generation raise instead of returning NaN
+    (or silence sampled from NaN)."""
+    from music_generator_amd import generate as Gn
+    from music_generator_amd._lib import DeepJError
+    from music_generator_amd.data import synthetic_batch
+    from music_generator_amd.dataset import compute_genre
+    from music_generator_amd.model import build_models
+    T = 8
+    a = synthetic_batch(48, T, 3, seed=2)
+    x, y = [a[0], a[1], a[2], a[3]], [a[4]]
+    monkeypatch.delenv("DEEPJ_DEBUG_CLUSTER_FAULT", raising=False)
+    monkeypatch.setenv("DEEPJ_CLUSTER", "0")                 # reference: the per-tile kernels, no fault
+    ref = build_models(time_steps=T, dtype="bf16", input_dropout=0.0, dropout=0.0, seed=4)
+    l_ref = ref[0].train_on_batch(x, y)
+    w_ref = ref[0].get_weights()
+    monkeypatch.delenv("DEEPJ_CLUSTER")
+    hm = build_models(time_steps=T, dtype="bf16", input_dropout=0.0, dropout=0.0, seed=4)
+    monkeypatch.setenv("DEEPJ_DEBUG_CLUSTER_FAULT", "1")
+    with pytest.raises(DeepJError, match="cluster faults"):
+        hm[0].predict(x)
+    with pytest.raises(DeepJError, match="cluster faults"):
+        hm[1].predict([x[0], x[2], x[3]])                    # time model: the wavefront launch
+    np.random.seed(1)
+    gm = build_models(dtype="bf16", seed=4)
+    with pytest.raises(DeepJError, match="cluster faults"):
+        list(Gn.generate(gm, 1, [compute_genre(i) for i in range(3)]))
+    l_f = hm[0].train_on_batch(x, y)                         # falls back and repeats the step
+    assert "falling back to the per-tile kernel" in capsys.readouterr().out
+    assert os.environ.get("DEEPJ_CLUSTER") == "0"
+    monkeypatch.delenv("DEEPJ_DEBUG_CLUSTER_FAULT")
+    assert np.isfinite(l_f) and abs(l_f - l_ref) < 1e-5 * abs(l_ref)     # (fp32 atomics reorder the loss / gradient sums)
+    for wa, wb in zip(hm[0].get_weights(), w_ref):
+        np.testing.assert_allclose(wa, wb, rtol=0, atol=1e-4)             # one Nadam step of lr 2e-3 on equal gradients
+    monkeypatch.delenv("DEEPJ_CLUSTER", raising=False)       # the fallback set it for the process
+    os.environ.pop("DEEPJ_CLUSTER", None)
+    # and the hook is gone: a fresh model runs the cluster kernels without a fault
+    ok = build_models(time_steps=T, dtype="bf16", input_dropout=0.0, dropout=0.0, seed=4)
+    assert np.isfinite(ok[0].predict(x)).all()
 
 
 def test_generate_with_hip_models_matches_oracle_models(gpu_device):
