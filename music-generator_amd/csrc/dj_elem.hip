@@ -307,19 +307,30 @@ __global__ __launch_bounds__(256) void feature_asm_kernel(FeatArgs a, T* __restr
         const float spc = col < a.F ? a.sp0[(int64_t)bt * a.F + col] : 0.f;
         // pitch_bins quirk (model.py:43-49): flat index f = bt N + n, value bins[((f / BT) % octave) BT + f % BT]
         const int64_t bT = (int64_t)a.B * a.T, f0 = (int64_t)bt * a.N + n0;
-        int64_t fq = f0 / bT, fr = f0 % bT;            // uniform; advanced per note below
+        const int64_t fr = f0 % bT;                    // uniform
+        const int fqm = (int)((f0 / bT) % a.octave);   // uniform; both advanced per note below WITHOUT divisions:
+        // the lanes of a wave hold different columns, so every branch below is walked by the whole wave in every
+        // iteration -- a 64-bit modulo in the one-lane bins branch cost more than the rest of the loop
+        int nm = (n0 + (tid >> 5)) % a.octave;         // n % octave of this thread's notes (n advances by 8)
+        const int nstep = 8 % a.octave;
         for (int nl = tid >> 5; nl < nc; nl += 8) {
           const int n = n0 + nl;
           float v = add;
           if (col == 0) {
             v = (float)n / (float)a.N;                              // model.py:22-30
           } else if (col <= a.octave) {
-            v = ((n % a.octave) == col - 1) ? 1.f : 0.f;            // model.py:32-41
+            v = (nm == col - 1) ? 1.f : 0.f;                        // model.py:32-41
           } else if (col == a.octave + 1) {
-            int64_t q2 = fq, r2 = fr + nl;
-            while (r2 >= bT) { r2 -= bT; ++q2; }
-            v = a.bins[(q2 % a.octave) * bT + r2];
+            int qm = fqm;
+            int64_t r2 = fr + nl;
+            while (r2 >= bT) {
+              r2 -= bT;
+              if (++qm == a.octave) qm = 0;
+            }
+            v = a.bins[qm * bT + r2];
           }
+          nm += nstep;
+          if (nm >= a.octave) nm -= a.octave;
           if (col < a.F) v += spc * dj_keep(a.d_style, rks[n], col);
           xrow[nl * a.FP + col] = dj_from_f32<T>(v);
         }
