@@ -494,7 +494,8 @@ __global__ __launch_bounds__(512) void gen_sample_ks_kernel(GenArgs a) {
       }
       kdraw = k;
     }
-    lds_barrier();
+    // no barrier here: the next note's first phase (h U of layer 0) needs neither `chosen` nor the logits, so the
+    // other waves start it while thread 0 samples; `chosen` is read behind the next barrier (cell update of layer 0)
   }
   __syncthreads();
   float* out_notes = a.state ? a.results + (int64_t)a.state->step * G * a.N * 3 : a.next_notes;
