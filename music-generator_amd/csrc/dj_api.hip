@@ -165,7 +165,7 @@ int make_plan(const dj_config* cfg, Plan& p) {
   p.w_WcT = wtake(64 * 80 * p.esz);         // conv kernel as the k-contiguous Bt operand [64 outputs][80 taps]
   p.w_zero = wtake(256);                      // a zero line (h_{-1} rows of the fused weight-gradient GEMM)
   // exchange state of the weight-stationary cluster forward kernel (bf16, H = 256): per workspace, i.e. per engine
-  p.w_cluster = wtake((cfg->dtype == DJ_BF16 && (p.Ht == 256 || p.Hn == 256)) ? dj_lstm_cluster_scratch_bytes_impl() : 0);
+  p.w_cluster = wtake((p.Ht == 256 || p.Hn == 256) ? dj_lstm_cluster_scratch_bytes_impl() : 0);   // bf16 sweeps, fp32 inference
   {                                           // fp32 scratch of the per-step path (layers with H not 128/256)
     int64_t fl = 0;
     if (!rec_persistent(p.Ht)) fl = dj_lstm_step_scratch_floats(p.Ht, p.tilesT);
@@ -309,6 +309,14 @@ int lstm_layer_fwd(const Ctx& c, const LstmP& L, int64_t tiles, int steps, int64
                           c.st));
   }
   ProfScope ps(is_note ? PC_LSTM_FWD_NOTE : PC_LSTM_FWD_TIME, c.st);
+  // fp32 inference with a handful of tiles (generation in the parity mode): 8 workgroups per tile with their slice of
+  // U resident in LDS instead of one workgroup per tile streaming all of it every step (dj_lstm.hip)
+  if (!c.train && dt == DJ_F32 && L.H == 256 && tiles <= 8 && cluster_enabled() &&
+      !(getenv("DEEPJ_CLUSTER_F32") && getenv("DEEPJ_CLUSTER_F32")[0] == '0')) {
+    const int rc = dj_launch_lstm_fwd_cluster_f32((int)tiles, steps, c.at(wZx), c.at(wUf), c.at(wH),
+                                                  c.p.c.recurrent_sigmoid, c.at(c.p.w_cluster), c.st);
+    if (rc != 1017) return rc;
+  }
   RUN(dj_launch_lstm_fwd(dt, L.H, (int)tiles, steps, c.at(wZx), c.train ? c.at(wZ) : nullptr, c.at(wUf), c.at(wH),
                          c.train ? c.at(wC) : nullptr, c.p.c.recurrent_sigmoid, c.st));
   return 0;
@@ -895,7 +903,7 @@ int32_t dj_lstm_cluster_faults(void* cluster_scratch) { return dj_lstm_cluster_f
 int32_t dj_workspace_cluster_faults(const dj_config* cfg, void* ws, int64_t ws_bytes) {
   Plan p;
   if (make_plan(cfg, p) || check_ws(p, ws, ws_bytes)) return -1;
-  if (!(p.c.dtype == DJ_BF16 && (p.Ht == 256 || p.Hn == 256))) return 0;
+  if (!(p.Ht == 256 || p.Hn == 256)) return 0;
   return dj_lstm_cluster_faults_impl((char*)ws + p.w_cluster);
 }
 int32_t dj_lstm_pack_wt(int32_t dtype, int32_t H, const float* W, int32_t D, void* out, void* stream) {

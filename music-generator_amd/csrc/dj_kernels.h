@@ -96,6 +96,8 @@ int dj_lstm_fused_nkx(int dtype, int H, int D);
 int dj_launch_lstm_pack_w(int dtype, int H, const float* W, int D, int NKX, void* out, hipStream_t st);
 // cluster_scratch: dj_lstm_cluster_scratch_bytes_impl() bytes, 128-byte aligned, owned by the caller's workspace
 // (null = per-tile kernel only)
+int dj_launch_lstm_fwd_cluster_f32(int ntiles, int steps, const void* Zx, const void* Upack, void* Hout, int sigm,
+                                   void* scratch, hipStream_t st);
 int dj_launch_lstm_fwd_cluster_pair(int ntiles, int steps, const void* X0, int DP0, const void* W0pack, const float* b0,
                                     const void* U0pack, void* X1, const void* W1pack, const float* b1, const void* U1pack,
                                     void* H1, const float* sp1, int sp_D, int n_seq, int n_b, int sigm, void* scratch,

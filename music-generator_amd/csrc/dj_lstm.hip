@@ -1183,6 +1183,153 @@ __device__ __forceinline__ void lstm_fwd_cluster_coop_body(const bf16_t* __restr
     if (tid == 0 && live) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
+// fp32 (parity mode) sibling of the cooperative body for sweeps of at most 8 tiles in inference (generation: the
+// certified sampling path runs in fp32).  The per-tile kernel streams 1 MB of fp32 U per step through ONE compute unit
+// per tile (36 us per step with 5 tiles); here 8 workgroups share a tile, each with its 128 KB slice of U resident in
+// LDS; x W + b comes precomputed and fragment-tiled (Zx, dj_gemm_nt c_mode 2) like for the per-tile kernel.  Waves 0-3
+// take one gate each (32 k-chunks of the 32x32x2 fp32 MFMA), park the pre-activations in LDS and update a quarter of
+// the cells each; wave 0 sends the h slice (fp32, A-fragment image: 4 chunks of 1 KiB per member and step).  Same sums
+// in the same order as lstm_fwd_kernel<float, 256>: bit-identical results.  Exchange protocol, placement check and
+// fault handling as in lstm_fwd_cluster_body.
+template <bool SIGM>
+__global__ __launch_bounds__(512) void lstm_fwd_cluster_f32_kernel(const float* __restrict__ Zx,
+                                                                   const float* __restrict__ Upack,
+                                                                   float* __restrict__ Hout, int steps,
+                                                                   int* __restrict__ cl, int ntiles) {
+  using T = float;
+  constexpr int H = 256;
+  using R = RecCfg<T, H>;
+  using Frag = typename DjFrag<T>::type;                   // f32x4: 4 k per lane half, 8 k per chunk
+  static_assert(R::NKC == 32 && R::NCB == 32, "fp32 H = 256 geometry");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Frag* Bu = (Frag*)smem_raw;                              // [4][32][64]  U slice of this member: 128 KiB
+  float* ht = (float*)(Bu + 4 * R::NKC * 64);              // [32 rows][32 units] h slice of the step
+  float* zgate = ht + 32 * 32;                             // [4 gates][64 lanes][16] pre-activations
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, s = j & (CL_M - 1);
+  const int cid = xcd + 8 * (j >> 3);
+  const int64_t tile = cid;                                // one tile per cluster
+  const bool live = tile < ntiles;
+  const bool gwave = w < 4;
+  int* cnt = cl + 2 * cid * CL_CNT_STRIDE;
+  int* xccs = cnt + CL_CNT_STRIDE;
+  int* fault = cl + CL_CNT_INTS;
+  uint4* hxb = (uint4*)((unsigned char*)cl + CL_OFF_HX);   // [tile][parity][32 chunks][64 lanes] x 16 bytes
+  constexpr int ARRIVALS = CL_M;
+  {
+    const uint4* gu = (const uint4*)((const Frag*)Upack + (int64_t)s * 4 * R::NKC * 64);
+    for (int i = tid; i < 4 * R::NKC * 64; i += 512) ((uint4*)Bu)[i] = gu[i];
+  }
+  float c4[4] = {0.f, 0.f, 0.f, 0.f};
+  const int my_xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15) + 1;
+  if (live && w == 0) {                                    // round 0: h_{-1} = 0 into the parity-1 slots
+    uint4* hxo = hxb + ((tile * 2 + 1) * 32 + 4 * s) * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) hxo[c * 64] = make_uint4(0, 0, 0, 0);
+  }
+  if (tid == 0) __hip_atomic_store(xccs + s, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  {
+    bool ok = cl_wait(cnt, ARRIVALS, lane);
+    int other = my_xcc;
+    if (ok && lane < CL_M) other = __hip_atomic_load(xccs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool same = __all(other == my_xcc) && __hip_atomic_load(fault + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+    if (!ok || !same) {
+      if (lane == 0 && w == 0) atomicAdd(fault + (ok ? 1 : 0), 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c4[e] = __builtin_nanf("");
+    }
+  }
+  // this gate wave's block of x W + b: fragment (gate w, units 32 s ..) of row block rb
+  auto zxaddr = [&](int64_t rb) { return Zx + ((rb * R::NCB + ((w & 3) * H + s * 32) / 32) * 64 + lane) * 16; };
+  float4 zx[4];
+  if (live && gwave) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) zx[i] = ((const float4*)zxaddr(tile * steps))[i];
+  }
+  for (int t = 0; t < steps; ++t) {
+    if (!live || !gwave) {         // exactly the two workgroup barriers of a gate wave's step
+      __syncthreads();
+      __syncthreads();
+      continue;
+    }
+    const int64_t rb = tile * steps + t;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[4 * i] = zx[i].x; acc[4 * i + 1] = zx[i].y; acc[4 * i + 2] = zx[i].z; acc[4 * i + 3] = zx[i].w;
+    }
+    if (!cl_wait(cnt, ARRIVALS * (t + 1), lane)) {
+      if (lane == 0 && w == 0) atomicAdd(fault, 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) c4[e] = __builtin_nanf("");
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    {
+      const uint4* hx = hxb + ((tile * 2 + ((t + 1) & 1)) * 32) * 64 + lane;
+      uint4 ah[R::NKC];
+#pragma unroll
+      for (int kc = 0; kc < R::NKC; ++kc) ah[kc] = ld_sc1(hx + kc * 64);
+      asm volatile("" ::: "memory");
+      // next step's x W + b behind the h fragments (loads return in order): 4 requests, so the wait is a constant
+      const float4* zn = (const float4*)zxaddr(t + 1 < steps ? rb + 1 : rb);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) zx[i] = zn[i];
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#pragma unroll
+      for (int kc = 0; kc < R::NKC; ++kc) {
+        Frag a;
+        __builtin_memcpy(&a, &ah[kc], 16);
+        dj_mfma(acc, a, Bu[((w & 3) * R::NKC + kc) * 64 + lane]);
+      }
+    }
+    {
+      float* zq = zgate + (w * 64 + lane) * 16;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+        *(float4*)(zq + 4 * r4) = make_float4(acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]);
+    }
+    __syncthreads();                                   // A: every gate is in LDS
+    {
+      const float4 zi4 = *(const float4*)(zgate + (0 * 64 + lane) * 16 + 4 * w);
+      const float4 zf4 = *(const float4*)(zgate + (1 * 64 + lane) * 16 + 4 * w);
+      const float4 zg4 = *(const float4*)(zgate + (2 * 64 + lane) * 16 + 4 * w);
+      const float4 zo4 = *(const float4*)(zgate + (3 * 64 + lane) * 16 + 4 * w);
+      const float zi[4] = {zi4.x, zi4.y, zi4.z, zi4.w}, zf[4] = {zf4.x, zf4.y, zf4.z, zf4.w};
+      const float zg[4] = {zg4.x, zg4.y, zg4.z, zg4.w}, zo[4] = {zo4.x, zo4.y, zo4.z, zo4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * w + e;
+        const float ig = dj_ract<SIGM>(zi[e]), fg = dj_ract<SIGM>(zf[e]), gg = dj_tanh(zg[e]), og = dj_ract<SIGM>(zo[e]);
+        const float cn = fg * c4[e] + ig * gg;
+        c4[e] = cn;
+        ht[dj_crow(r, lane) * 32 + l31] = og * dj_tanh(cn);
+      }
+    }
+    __syncthreads();                                   // B: the h tile is complete
+    if (w == 0) {
+      // exchange copy (A-fragment image: chunk 4 s + c holds units 8 c .. 8 c + 7: lane (l31, h) -> 4 k at 8 c + 4 h)
+      {
+        uint4* hxo = hxb + ((tile * 2 + (t & 1)) * 32 + 4 * s) * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) hxo[c * 64] = *(const uint4*)(ht + l31 * 32 + 8 * c + 4 * h);
+      }
+      asm volatile("" ::: "memory");
+      // row-major slice: 32 rows x 128 bytes -> 4 x 16-byte vectors per lane
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int v = lane + 64 * i, row = v >> 3, cq = (v & 7) * 4;
+        *(uint4*)(Hout + (rb * 32 + row) * H + s * 32 + cq) = *(const uint4*)(ht + row * 32 + cq);
+      }
+      asm volatile("" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // the exchange copy is acknowledged (stores in order)
+      if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
 template <bool SIGM, int NKX>
 __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __restrict__ X, int DP,
                                                                const bf16_t* __restrict__ Wpack,
@@ -1800,6 +1947,37 @@ int launch_fwd_cluster_pair(int ntiles, int steps, const ClPairArgs& a, int sigm
 }
 
 }  // namespace
+
+// fp32 H = 256 inference sweep of at most 8 tiles on clusters of 8 workgroups (lstm_fwd_cluster_f32_kernel).  Returns
+// 1017 when the device cannot hold the grid (the caller then uses the per-tile kernel).
+int dj_launch_lstm_fwd_cluster_f32(int ntiles, int steps, const void* Zx, const void* Upack, void* Hout, int sigm,
+                                   void* scratch, hipStream_t st) {
+  using R = RecCfg<float, 256>;
+  if (ntiles < 1 || ntiles > 8 || !scratch || ((uintptr_t)scratch & 127)) return 1016;
+  if (cluster_cus() < 64) return 1017;
+  const size_t smem = (size_t)4 * R::NKC * 64 * 16 + (size_t)(32 * 32 + 4 * 64 * 16) * sizeof(float);
+  static bool attr_done_dev[DJ_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[dj_current_device()];
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_cluster_f32_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)lstm_fwd_cluster_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipError_t e = hipMemsetAsync(scratch, 0, CL_OFF_FAULT, st);
+  if (e != hipSuccess) return (int)e;
+  if (int rc = cluster_fault_hook(scratch, st)) return rc;
+  if (sigm)
+    hipLaunchKernelGGL((lstm_fwd_cluster_f32_kernel<true>), dim3(64), dim3(512), smem, st, (const float*)Zx,
+                       (const float*)Upack, (float*)Hout, steps, (int*)scratch, ntiles);
+  else
+    hipLaunchKernelGGL((lstm_fwd_cluster_f32_kernel<false>), dim3(64), dim3(512), smem, st, (const float*)Zx,
+                       (const float*)Upack, (float*)Hout, steps, (int*)scratch, ntiles);
+  return (int)hipGetLastError();
+}
 
 // Two stacked bf16 H = 256 inference layers (input widths <= 128 and 256) as ONE wavefront launch: the lower layer
 // writes the upper layer's input X1 = bf16(h + sp1[b * steps + t]) itself (rows (b, n) of n_seq sequences per b).

@@ -198,6 +198,29 @@ def test_time_axis_pair_launch_matches_layer_by_layer(gpu_device, monkeypatch, G
     assert np.abs(pair - tref).max() < 3e-2
 
 
+@pytest.mark.parametrize("G,T,N", [(3, 128, 48), (5, 16, 40), (1, 7, 128)], ids=["gen_window", "ragged_tiles", "one_piece"])
+def test_time_axis_fp32_cluster_matches_per_tile_kernel(gpu_device, monkeypatch, G, T, N):
+    """fp32 inference of the time axis with at most 8 sequence tiles runs on clusters of 8 workgroups with U resident in
+    LDS (lstm_fwd_cluster_f32_kernel): bit-identical to the per-tile kernel (same sums in the same order), within the
+    north_star's 1e-3 of the oracle, no cluster fault."""
+    from music_generator_amd.engine import Engine
+    ocfg, dcfg = _cfgs(time_steps=T, num_notes=N)
+    params = O.init_params(ocfg, seed=12)
+    flat = torch.from_numpy(O.flatten_params(ocfg, params)).to(gpu_device)
+    notes, chosen, beat, style, target = O.synthetic_batch(ocfg, G, seed=6, T=T)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(gpu_device)
+    eng = Engine(dcfg, G, T, device=gpu_device)
+    monkeypatch.delenv("DEEPJ_CLUSTER_F32", raising=False)
+    cl = eng.time_model_predict(flat, d(notes), d(beat), d(style)).cpu().numpy()
+    monkeypatch.setenv("DEEPJ_CLUSTER_F32", "0")
+    pt = eng.time_model_predict(flat, d(notes), d(beat), d(style)).cpu().numpy()
+    monkeypatch.delenv("DEEPJ_CLUSTER_F32", raising=False)
+    assert eng.cluster_faults() == 0
+    np.testing.assert_array_equal(cl, pt)
+    tref = O.time_model_predict(ocfg, params, notes, beat, style)
+    np.testing.assert_allclose(cl, tref, rtol=1e-3, atol=2e-5)
+
+
 def test_seed_reproducible_and_mask_sensitive(gpu_device):
     T, B = 4, 2
     ocfg, dcfg = _cfgs(time_steps=T)
