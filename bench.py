@@ -481,6 +481,11 @@ def main():
             out["fp32_parity_mode"] = fp32_parity_mode(dict(num_notes=N, time_steps=T), B, T, N, pin, pdr, dev, rank)
         if world == 1 and args.gen_steps > 0:
             out["generation"] = generation_bench(args.dtype, args.gen_steps)
+            if args.dtype != "f32" and not args.no_fp32:
+                # the mode in which the sampled notes are certified against the fp32 oracle (DESIGN.md "Sampling parity")
+                g32 = generation_bench("f32", min(args.gen_steps, 256))
+                out["generation"]["fp32_parity_mode"] = {k: g32[k] for k in
+                                                         ("value", "unit", "ms_per_time_step", "steps", "near_tie_draws", "draws")}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, T, N, min(args.cpu_sample, B), pin, pdr, B, steps=args.cpu_steps)
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
