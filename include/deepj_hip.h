@@ -224,7 +224,9 @@ int32_t dj_lstm_pack_wt(int32_t dtype, int32_t H, const float* W, int32_t D, voi
 int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack_bwd,
                        const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias,
                        int32_t recurrent_sigmoid, const void* wtpack, int32_t D, void* dX, int32_t DP, void* stream);
-/* The bf16 H = 256 forward sweep of 64..256 tiles runs as weight-stationary clusters of 8 workgroups that meet
+/* The bf16 H = 256 forward sweep (any tile count; in inference with <= 64 tiles both time-axis layers in one wavefront
+ * launch, with <= 8 tiles four waves per tile) and the fp32 H = 256 inference sweep of <= 8 tiles (dj_predict /
+ * dj_time_model_predict / dj_generate_* in the parity mode) run as weight-stationary clusters of 8 workgroups that meet
  * once per step through a counter in L2 (dj_lstm.hip).  Their exchange state (counters, the members' XCC ids, the h
  * slices) lives in a caller-owned scratch -- part of the workspace for the dj_train / dj_predict calls, one per
  * workspace and therefore per engine / stream; concurrent sweeps must not share one.  Two things are checked at run
@@ -234,7 +236,8 @@ int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, 
  * XCD's L2 relies on) is detected in round 0.  In both cases the affected tiles carry NaN from there on (so does the
  * loss) and the event is counted.  dj_lstm_cluster_faults / dj_workspace_cluster_faults return the number of events
  * recorded in that scratch / workspace since the previous call (synchronise the device; 0 in a healthy run, -1 on a
- * HIP error).  DEEPJ_CLUSTER=0 selects the per-tile kernel instead. */
+ * HIP error).  DEEPJ_CLUSTER=0 selects the per-tile kernels instead (DEEPJ_CLUSTER_PAIR / _COOP / _F32 = 0 the
+ * individual forms); DEEPJ_DEBUG_CLUSTER_FAULT=1 injects a placement fault (tests). */
 int64_t dj_lstm_cluster_scratch_bytes(void);
 int32_t dj_lstm_cluster_faults(void* cluster_scratch);
 int32_t dj_workspace_cluster_faults(const dj_config* cfg, void* workspace, int64_t workspace_bytes);
