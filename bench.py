@@ -160,15 +160,16 @@ def cpu_baseline(cfg, T, N, sample_b, pin, pdr, batch, warmup=1, steps=3):
             "s_per_step": [round(t, 2) for t in times], "loss": loss}
 
 
-def make_step(eng, opt, P, G, batch, world, rank, dist):
+def make_step(eng, opt, P, G, batch, world, rank, dist, force_collective=False):
     """THE timed step: forward + BPTT, one all-reduce(sum) of the flat fp32 gradient over RCCL/xGMI when
     world > 1, Nadam with the 1/world scale folded in.  Factored out so that the 2-rank gloo test
-    (tests/test_bench_cpu.py) runs exactly this function."""
+    (tests/test_bench_cpu.py) and the world-size-1 RCCL test on the GPU (tests/test_dist_gpu.py, force_collective)
+    run exactly this function."""
     notes, chosen, beat, style, target = batch
 
     def step(i):
         loss = eng.train_fwd_bwd(P, G, notes, chosen, beat, style, target, seed=i * world + rank)
-        if world > 1:
+        if world > 1 or force_collective:
             dist.all_reduce(G)                           # one flat fp32 buffer
         opt.step(P, G, grad_scale=1.0 / world)
         return loss
@@ -246,16 +247,17 @@ def generation_bench(dtype, steps):
             "path": "dj_generate_prepare + dj_generate_step_prepared (hipGraph replay), NumPy MT19937 draws in reference order"}
 
 
-def scaled_bench(args, dev, rank, world, dist):
+def scaled_record(dtype, micro, steps, warmup, dropout, dev, rank, world, dist):
     """BASELINE configs[4]: 3 x 1024 units per axis, batch 128 x 256 steps x 128 notes per GPU.  The batch runs as
-    `--micro` equal micro-batches through one workspace with gradient accumulation (dj_train_fwd_bwd_acc) and ONE
-    optimizer step; as with data-parallel ranks, pitch_bins couples samples within a micro-batch only."""
+    `micro` equal micro-batches through one workspace with gradient accumulation (dj_train_fwd_bwd_acc) and ONE
+    optimizer step; as with data-parallel ranks, pitch_bins couples samples within a micro-batch only.  Returns the
+    JSON record (rank 0) or None."""
     from music_generator_amd import _lib
     from music_generator_amd.data import synthetic_batch
     from music_generator_amd.engine import DeepJConfig, Engine, Nadam, init_params_numpy
-    B, T, N, micro = 128, 256, 128, args.micro
-    pin, pdr = args.dropout or (0.2, 0.5)
-    cfg = DeepJConfig(num_notes=N, time_steps=T, dtype=args.dtype, time_axis_units=1024, note_axis_units=1024,
+    B, T, N = 128, 256, 128
+    pin, pdr = dropout or (0.2, 0.5)
+    cfg = DeepJConfig(num_notes=N, time_steps=T, dtype=dtype, time_axis_units=1024, note_axis_units=1024,
                       time_axis_layers=3, note_axis_layers=3)
     eng = Engine(cfg, B // micro, T, device=dev, input_dropout=pin, dropout=pdr)
     P = torch.from_numpy(init_params_numpy(cfg, seed=1234)).to(dev)
@@ -274,7 +276,7 @@ def scaled_bench(args, dev, rank, world, dist):
         opt.step(P, G, grad_scale=1.0 / (micro * world))
         return loss
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
     if world > 1:
@@ -282,8 +284,8 @@ def scaled_bench(args, dev, rank, world, dist):
     torch.cuda.synchronize()
     lib.dj_profile_enable(1)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
+    for i in range(steps):
+        loss = step(warmup + i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -300,32 +302,101 @@ def scaled_bench(args, dev, rank, world, dist):
     for c in range(lib.dj_profile_category_count()):
         ms, n = C.c_double(), C.c_int64()
         _lib.check(lib.dj_profile_read(c, C.byref(ms), C.byref(n)), "dj_profile_read")
-        kernels[lib.dj_profile_category_name(c).decode()] = round(ms.value / args.steps, 3)
+        kernels[lib.dj_profile_category_name(c).decode()] = round(ms.value / steps, 3)
     lib.dj_profile_enable(0)
+    ws_gib = round(eng.ws_bytes / 2 ** 30, 1)
+    del eng, P, G, opt, data, parts
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    fl = category_flops(cfg, B, T, N)
+    flops_step = 3 * (fl["gemm_xw"] + fl["lstm_fwd_time"] + fl["lstm_fwd_note"])
+    tf = flops_step * world * steps / elapsed / 1e12
+    dom = max(fl, key=lambda c_: kernels.get(c_, 0.0))
+    dom_tf = fl[dom] / (kernels[dom] * 1e-3) / 1e12 if kernels.get(dom) else 0.0
+    rates = {k_: round(fl[k_] / (kernels[k_] * 1e-3) / 1e12, 1) for k_ in fl if kernels.get(k_)}
+    return {
+        "metric": "note-steps/sec (train)", "value": round(world * B * T * N * steps / elapsed, 1),
+        "unit": "note-steps/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": f"scaled biaxial-LSTM train step (BASELINE configs[4]): 3x1024 time-axis + 3x1024 "
+                               f"note-axis LSTM, batch {B}/GPU as {micro} micro-batches x {T} steps x {N} notes, "
+                               f"dropout {pin}/{pdr}, Nadam; random-init weights",
+                   "global_batch": B * world, "seq_len": T, "num_notes": N, "parallelism": f"dp{world}",
+                   "micro_batches": micro, "workspace_gib": ws_gib},
+        "model_tflops_per_s": round(tf, 1), "final_loss": round(final_loss, 5),
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(dom_tf, 1), "peak": PEAK_TFLOPS[dtype],
+                     "unit": "TFLOP/s", "frac": round(dom_tf / PEAK_TFLOPS[dtype], 4), "traffic": None,
+                     "whole_step_mfma_frac": round(tf / world / PEAK_TFLOPS[dtype], 4),
+                     "flops_per_step": flops_step},
+        "kernel_ms_per_step": kernels, "kernel_tflops": rates, "cpu_baseline": None}
+
+
+def scaled_bench(args, dev, rank, world, dist):
+    rec = scaled_record(args.dtype, args.micro, args.steps, args.warmup, args.dropout, dev, rank, world, dist)
     if rank == 0:
-        fl = category_flops(cfg, B, T, N)
-        flops_step = 3 * (fl["gemm_xw"] + fl["lstm_fwd_time"] + fl["lstm_fwd_note"])
-        tf = flops_step * world * args.steps / elapsed / 1e12
-        dom = max(fl, key=lambda c_: kernels.get(c_, 0.0))
-        dom_tf = fl[dom] / (kernels[dom] * 1e-3) / 1e12 if kernels.get(dom) else 0.0
-        print(json.dumps({
-            "metric": "note-steps/sec (train)", "value": round(world * B * T * N * args.steps / elapsed, 1),
-            "unit": "note-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"scaled biaxial-LSTM train step (BASELINE configs[4]): 3x1024 time-axis + 3x1024 "
-                                   f"note-axis LSTM, batch {B}/GPU as {micro} micro-batches x {T} steps x {N} notes, "
-                                   f"dropout {pin}/{pdr}, Nadam; random-init weights",
-                       "global_batch": B * world, "seq_len": T, "num_notes": N, "parallelism": f"dp{world}",
-                       "micro_batches": micro, "workspace_gib": round(eng.ws_bytes / 2 ** 30, 1)},
-            "model_tflops_per_s": round(tf, 1), "final_loss": round(final_loss, 5),
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(dom_tf, 1), "peak": PEAK_TFLOPS[args.dtype],
-                         "unit": "TFLOP/s", "frac": round(dom_tf / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
-                         "whole_step_mfma_frac": round(tf / world / PEAK_TFLOPS[args.dtype], 4)},
-            "kernel_ms_per_step": kernels, "cpu_baseline": None}), flush=True)
+        print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic_from_dir(pmc_dir, category_of):
+    """HBM bytes per launch of every kernel category from rocprofv3 PMC passes found under `pmc_dir` (counter_collection
+    CSVs of `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs of THIS build, separate passes): read = 2 x FETCH_SIZE KB
+    (gfx950 tallies 128-byte requests at 64 bytes), write = WRITE_SIZE KB -- MI355X_MICROARCH.md, HBM section."""
+    import csv
+    import glob
+    from collections import defaultdict
+    acc = {"FETCH_SIZE": defaultdict(list), "WRITE_SIZE": defaultdict(list)}
+    for f in glob.glob(os.path.join(pmc_dir, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] in acc:
+                acc[r["Counter_Name"]][r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    out = defaultdict(lambda: [0.0, 0])
+    for k, v in acc["FETCH_SIZE"].items():
+        c = category_of(k)
+        if c is None:
+            continue
+        w = acc["WRITE_SIZE"].get(k)
+        per = 2.0 * 1024 * sum(v) / len(v) + (1024 * sum(w) / len(w) if w else 0.0)
+        out[c][0] += per * len(v)
+        out[c][1] += len(v)
+    return {c: tot / n for c, (tot, n) in out.items() if n}
+
+
+def pmc_category(name):
+    """Kernel name -> bench category for the PMC summary (as tools/pmc_summary.py)."""
+    if "lstm_bwd_kernel" in name:
+        return "lstm_bwd_time" if "Li256" in name else "lstm_bwd_note"
+    if "lstm_fwd_cluster" in name:
+        return "lstm_fwd_time"
+    if "lstm_fwd" in name:
+        return "lstm_fwd_time" if "Li256" in name else "lstm_fwd_note"
+    if "lstm_wgrad" in name:
+        return "gemm_dw"
+    return None
+
+
+def self_launch(argv, gpus):
+    """`python bench.py --gpus N` without a launcher: start the ranks ourselves.  The parent has not touched the GPU
+    (nothing above calls into HIP), so the ranks are fresh CHILD processes of `python -m torch.distributed.run`
+    (subprocess, never exec); their stdout/stderr pass through, the child's exit code is ours."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    launcher = os.environ.get("DEEPJ_BENCH_LAUNCHER")          # tests: a stub in place of torch.distributed.run
+    if launcher:
+        cmd = [sys.executable, launcher] + cmd[1:]
+    print("[bench] starting %d ranks: %s" % (gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -348,6 +419,12 @@ def main():
     ap.add_argument("--dropout", type=float, nargs=2, default=None, metavar=("INPUT", "HIDDEN"),
                     help="override the reference's dropout rates 0.2 0.5 (experiments only; the metric uses the defaults)")
     ap.add_argument("--gen-steps", type=int, default=1024, help="generated time steps for the secondary metric (0 = skip)")
+    ap.add_argument("--scaled-steps", type=int, default=2,
+                    help="timed steps of the `scaled` sub-record (BASELINE configs[4], after 1 warm-up; 0 = skip)")
+    ap.add_argument("--pmc-dir", default=None,
+                    help="directory with rocprofv3 `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of THIS build "
+                         "(counter_collection CSVs): roofline.traffic is computed from them instead of the committed "
+                         "profiles/pmc_traffic.json")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -355,8 +432,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one rank per GPU)")
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        # the driver's plain form `python bench.py --gpus N ...`: no launcher above us -> be the launcher
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the DeepJ engine has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -432,13 +510,20 @@ def main():
         sec = ms * 1e-3
         tflops = fl[dom] / sec / 1e12 if ms > 0 else 0.0
         gbs = by[dom] / sec / 1e9 if ms > 0 else 0.0
-        traffic, tsrc = None, None
+        traffic, tsrc, committed = None, None, None
         try:                                            # HBM bytes per launch of that kernel from the committed PMC passes
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if args.dtype == "bf16" and (B, T, N) == (64, 128, 128) and dom in pm:
-                traffic, tsrc = pm[dom], "profiles/pmc_traffic.json: " + pm["source"]
+                committed = traffic = pm[dom]
+                tsrc = "profiles/pmc_traffic.json (committed passes of an earlier run): " + pm["source"]
         except Exception:
             pass
+        if args.pmc_dir:                                # passes of THIS build, made in the same gpurun call
+            live = pmc_traffic_from_dir(args.pmc_dir, pmc_category)
+            if dom in live:
+                traffic = live[dom]
+                tsrc = ("measured: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes under %s (this build; FETCH_SIZE x 2 "
+                        "per MI355X_MICROARCH.md), bytes per launch" % args.pmc_dir)
         # the roof that binds is the one with the larger lower-bound time for this kernel
         t_mfma, t_hbm = fl[dom] / (PEAK_TFLOPS[args.dtype] * 1e12), by[dom] / (PEAK_HBM_GBS * 1e9)
         if t_hbm >= t_mfma:
@@ -447,7 +532,7 @@ def main():
         else:
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(tflops, 2), "peak": PEAK_TFLOPS[args.dtype],
                     "unit": "TFLOP/s", "frac": round(tflops / PEAK_TFLOPS[args.dtype], 4)}
-        roof.update({"traffic": traffic, "traffic_committed_pmc": traffic, "traffic_source": tsrc,
+        roof.update({"traffic": traffic, "traffic_committed_pmc": committed, "traffic_source": tsrc,
                      "launches_per_step": lps[dom],
                      "avg_launch_ms": round(ms / lps[dom], 4), "bytes_per_launch": by[dom] / lps[dom],
                      "flops_per_launch": fl[dom] / lps[dom],
@@ -486,6 +571,16 @@ def main():
                 g32 = generation_bench("f32", min(args.gen_steps, 256))
                 out["generation"]["fp32_parity_mode"] = {k: g32[k] for k in
                                                          ("value", "unit", "ms_per_time_step", "steps", "near_tie_draws", "draws")}
+        if world == 1 and args.scaled_steps > 0 and args.dtype == "bf16" and (B, T, N) == (64, 128, 128):
+            # BASELINE configs[4] next to the headline, so that its number is driver-visible: 1 warm-up + 2 timed steps
+            free, _ = torch.cuda.mem_get_info(dev)
+            if free > 230 * 2 ** 30:
+                rec = scaled_record(args.dtype, args.micro, args.scaled_steps, 1, args.dropout, dev, rank, 1, None)
+                out["scaled"] = {k: rec[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config",
+                                                     "model_tflops_per_s", "final_loss", "roofline", "kernel_ms_per_step",
+                                                     "kernel_tflops")}
+            else:
+                out["scaled"] = {"skipped": "needs a 218 GiB workspace; %.0f GiB free" % (free / 2 ** 30)}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(cfg, T, N, min(args.cpu_sample, B), pin, pdr, B, steps=args.cpu_steps)
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

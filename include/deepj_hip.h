@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DJ_ABI_VERSION 1
+#define DJ_ABI_VERSION 2
 #define DJ_DTYPE_F32 0  /* fp32 operands, v_mfma_f32_32x32x2_f32 (parity mode)            */
 #define DJ_DTYPE_BF16 1 /* bf16 operands/stash, fp32 accumulate + cell state (throughput) */
 
@@ -36,15 +36,36 @@ typedef struct dj_config {
   int32_t octave_units;     /* constants.py:70 (must be 64)                              */
   int32_t style_units;      /* constants.py:71 (<= 64)                                   */
   int32_t note_units;       /* constants.py:72 (must be 3)                               */
-  int32_t time_axis_units;  /* constants.py:73 (128 or 256)                              */
-  int32_t note_axis_units;  /* constants.py:74 (128 or 256)                              */
+  int32_t time_axis_units;  /* constants.py:73; multiple of 32 in 32..2048: 128 / 256 run */
+  int32_t note_axis_units;  /* constants.py:74   the persistent kernels, other widths the */
+                            /*   per-step GEMM + gate path (scaled model: 1024)          */
   int32_t time_axis_layers; /* constants.py:76 (1..4)                                    */
   int32_t note_axis_layers; /* constants.py:77 (1..4)                                    */
   int32_t dtype;            /* DJ_DTYPE_*                                                */
   int32_t recurrent_sigmoid;/* 0: Keras-2 hard_sigmoid gates (default), 1: sigmoid       */
   float input_dropout;      /* model.py:128 build_models(input_dropout=0.2)              */
   float dropout;            /* model.py:128 build_models(dropout=0.5)                    */
+  int32_t kernel_flags;     /* OR of DJ_KF_* below; 0 = the library's own selection      */
+  int32_t fuse_xw_min_tiles;/* > 0: fuse x*W into the recurrent sweep from this many     */
+                            /*   sequence tiles on (0 = default rule; tests)             */
 } dj_config;
+
+/* Kernel-selection flags (dj_config.kernel_flags: per engine; none changes results beyond summation order).  The
+ * DEEPJ_* environment variables of the same meaning (DEEPJ_CLUSTER=0, DEEPJ_CLUSTER_PAIR=0, DEEPJ_CLUSTER_F32=0,
+ * DEEPJ_CLUSTER_COOP=0, DEEPJ_FUSE_DX=0, DEEPJ_GEN_KSPLIT=0, DEEPJ_DEBUG_CLUSTER_FAULT=1, DEEPJ_FUSE_XW_MIN_TILES=n)
+ * are read ONCE, at the first call into the library, as process-wide defaults that are OR-ed with these bits; there
+ * is no getenv on the launch path.  dj_env_reload() reads them again (tests that switch kernels inside one process).
+ * A hipGraph captured from these calls keeps the selection in force at capture time.  dj_generate_prepare and
+ * dj_generate_step_prepared must see the same flags (the packed-weight layout depends on them): same cfg, and no
+ * dj_env_reload() in between. */
+#define DJ_KF_NO_CLUSTER 1          /* H = 256 sweeps on the per-tile kernels (set by the host after a cluster fault) */
+#define DJ_KF_NO_CLUSTER_PAIR 2     /* inference: time-axis layers one launch each instead of the wavefront pair       */
+#define DJ_KF_NO_CLUSTER_F32 4      /* fp32 inference with <= 8 tiles on the per-tile kernel                           */
+#define DJ_KF_NO_CLUSTER_COOP 8     /* wavefront pair without the cooperative (4 waves per tile) body                  */
+#define DJ_KF_NO_FUSE_DX 16         /* dX = dz W^T always as a GEMM                                                    */
+#define DJ_KF_NO_GEN_KSPLIT 32      /* note sampler: one thread per gate column                                       */
+#define DJ_KF_DEBUG_CLUSTER_FAULT 64 /* cluster launches fail their placement check (fault-handling tests)            */
+int32_t dj_env_reload(void);
 
 int32_t dj_abi_version(void);
 
@@ -83,6 +104,11 @@ int32_t dj_train_fwd_bwd_acc(const dj_config* cfg, const float* params, float* g
 int32_t dj_nadam_step(float* params, const float* grads, float* m, float* v, int64_t count, int64_t step_t,
                       double* m_schedule_host, float lr, float beta1, float beta2, float epsilon, float schedule_decay,
                       float grad_scale, void* stream);
+
+/* The `style` Dense layer alone (model.py:141-142) on style_in [rows, num_styles] -> out [rows, style_units]:
+ * model.get_layer('style') applied to the identity in visualize.py:13-23 (style-embedding export). */
+int32_t dj_style_embedding(const dj_config* cfg, const float* params, const float* style_in, int32_t rows, float* out,
+                           void* stream);
 
 /* Model.predict of the three Keras models built by build_models (model.py:151,155,167),
  * inference mode (no dropout):
@@ -236,11 +262,20 @@ int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, 
  * XCD's L2 relies on) is detected in round 0.  In both cases the affected tiles carry NaN from there on (so does the
  * loss) and the event is counted.  dj_lstm_cluster_faults / dj_workspace_cluster_faults return the number of events
  * recorded in that scratch / workspace since the previous call (synchronise the device; 0 in a healthy run, -1 on a
- * HIP error).  DEEPJ_CLUSTER=0 selects the per-tile kernels instead (DEEPJ_CLUSTER_PAIR / _COOP / _F32 = 0 the
- * individual forms); DEEPJ_DEBUG_CLUSTER_FAULT=1 injects a placement fault (tests). */
+ * HIP error).  DJ_KF_NO_CLUSTER (DEEPJ_CLUSTER=0) selects the per-tile kernels instead (DJ_KF_NO_CLUSTER_PAIR / _COOP /
+ * _F32 the individual forms); DJ_KF_DEBUG_CLUSTER_FAULT injects a placement fault (tests). */
 int64_t dj_lstm_cluster_scratch_bytes(void);
 int32_t dj_lstm_cluster_faults(void* cluster_scratch);
 int32_t dj_workspace_cluster_faults(const dj_config* cfg, void* workspace, int64_t workspace_bytes);
+/* Diagnostics: the two counts separately, without resetting them -- words_host[0] = expired waits (a member never
+ * arrived), words_host[1] = clusters whose members reported different XCC ids.  Synchronises. */
+int32_t dj_workspace_cluster_fault_words(const dj_config* cfg, void* workspace, int64_t workspace_bytes,
+                                         int32_t* words_host);
+/* The same census without a host round trip: a one-thread kernel on `stream` ADDS the count (as a float) to
+ * out_dev[0] and resets the words -- put out_dev next to the loss and one device-to-host copy per training step
+ * carries both (Model.fit reads [loss, faults] together before the optimizer step; the caller zeroes out_dev). */
+int32_t dj_workspace_faults_async(const dj_config* cfg, void* workspace, int64_t workspace_bytes, float* out_dev,
+                                  void* stream);
 /* mask[rows, cols] (fp32 0 or 1/(1-p)) of dropout site `site` -- exposes the counter
  * hash so tests can pin it against the oracle. */
 int32_t dj_dropout_mask(uint64_t seed, int32_t site, float p, int64_t rows, int32_t cols, float* mask, void* stream);

@@ -16,7 +16,13 @@ class DjConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "batch", "time_steps", "num_notes", "num_styles", "notes_per_bar", "octave", "octave_units",
         "style_units", "note_units", "time_axis_units", "note_axis_units", "time_axis_layers",
-        "note_axis_layers", "dtype", "recurrent_sigmoid")] + [("input_dropout", C.c_float), ("dropout", C.c_float)]
+        "note_axis_layers", "dtype", "recurrent_sigmoid")] + [("input_dropout", C.c_float), ("dropout", C.c_float),
+                                                              ("kernel_flags", C.c_int32), ("fuse_xw_min_tiles", C.c_int32)]
+
+
+# dj_config.kernel_flags (include/deepj_hip.h DJ_KF_*)
+KF_NO_CLUSTER, KF_NO_CLUSTER_PAIR, KF_NO_CLUSTER_F32, KF_NO_CLUSTER_COOP = 1, 2, 4, 8
+KF_NO_FUSE_DX, KF_NO_GEN_KSPLIT, KF_DEBUG_CLUSTER_FAULT = 16, 32, 64
 
 
 class DeepJError(RuntimeError):
@@ -28,6 +34,10 @@ _lib = None
 _P = C.c_void_p
 _SIGS = {
     "dj_abi_version": (C.c_int32, []),
+    "dj_env_reload": (C.c_int32, []),
+    "dj_style_embedding": (C.c_int32, [C.POINTER(DjConfig), _P, _P, C.c_int32, _P, _P]),
+    "dj_workspace_cluster_fault_words": (C.c_int32, [C.POINTER(DjConfig), _P, C.c_int64, C.POINTER(C.c_int32)]),
+    "dj_workspace_faults_async": (C.c_int32, [C.POINTER(DjConfig), _P, C.c_int64, _P, _P]),
     "dj_param_count": (C.c_int64, [C.POINTER(DjConfig)]),
     "dj_param_info": (C.c_int32, [C.POINTER(DjConfig), C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64),
                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -101,7 +111,7 @@ def load():
             raise DeepJError(f"{LIB_PATH} does not export {name}")
         fn.restype = res
         fn.argtypes = args
-    if lib.dj_abi_version() != 1:
+    if lib.dj_abi_version() != 2:
         raise DeepJError("libdeepj_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -204,37 +204,58 @@ struct Ctx {
     if (rc_) return rc_;       \
   } while (0)
 
+// ---- kernel-selection switches.  The DEEPJ_* environment variables are read ONCE (first use of the library, or
+// dj_env_reload()) into process defaults; per-engine choices travel in dj_config.kernel_flags / fuse_xw_min_tiles.
+// No getenv on the launch path, and nothing the host side does to one engine (the cluster-fault fallback) leaks into
+// another engine or into a captured graph's view of the world.
+struct EnvDefaults { uint32_t flags; int64_t fuse_xw_min_tiles; };
+EnvDefaults read_env() {
+  EnvDefaults d{0u, -1};
+  auto off = [](const char* name) { const char* e = getenv(name); return e && e[0] == '0'; };
+  auto on = [](const char* name) { const char* e = getenv(name); return e && e[0] != '0' && e[0] != 0; };
+  if (off("DEEPJ_CLUSTER")) d.flags |= DJ_KF_NO_CLUSTER;
+  if (off("DEEPJ_CLUSTER_PAIR")) d.flags |= DJ_KF_NO_CLUSTER_PAIR;
+  if (off("DEEPJ_CLUSTER_F32")) d.flags |= DJ_KF_NO_CLUSTER_F32;
+  if (off("DEEPJ_CLUSTER_COOP")) d.flags |= DJ_KF_NO_CLUSTER_COOP;
+  if (off("DEEPJ_FUSE_DX")) d.flags |= DJ_KF_NO_FUSE_DX;
+  if (off("DEEPJ_GEN_KSPLIT")) d.flags |= DJ_KF_NO_GEN_KSPLIT;
+  if (on("DEEPJ_DEBUG_CLUSTER_FAULT")) d.flags |= DJ_KF_DEBUG_CLUSTER_FAULT;
+  if (const char* e = getenv("DEEPJ_FUSE_XW_MIN_TILES")) d.fuse_xw_min_tiles = atoll(e);
+  return d;
+}
+EnvDefaults& env_defaults() {
+  static EnvDefaults d = read_env();
+  return d;
+}
+inline uint32_t kflags(const dj_config& c) { return (uint32_t)c.kernel_flags | env_defaults().flags; }
+
+// the weight-stationary cluster kernels may be used by this plan (host side: cleared per engine after a cluster fault)
+inline bool cluster_enabled(const dj_config& c) { return !(kflags(c) & DJ_KF_NO_CLUSTER); }
+
 // Fuse x*W into the recurrent kernel when its extra L2 weight stream (D x 4H) is no larger than
 // twice the recurrent one (H x 4H); wider inputs (note layer 0: D = 259 vs H = 128) are cheaper as
 // a separate GEMM (measured: fused +1.25 ms on the note axis vs 1.24 ms of GEMMs saved).  With few
 // sequence tiles (generation: 5) the chip is idle anyway and the recurrence is a pure latency chain:
 // there the projection stays a separate (parallel) GEMM and the chain carries h*U only.
-// DEEPJ_FUSE_XW_MIN_TILES overrides the tile threshold (tests run the fused kernel on small shapes with it).
-inline bool cluster_enabled();
-inline bool fuse_xw(const LstmP& L) {
-  const char* e = getenv("DEEPJ_FUSE_XW_MIN_TILES");
-  const int64_t min_tiles = e ? atoll(e) : 128;
+// dj_config.fuse_xw_min_tiles / DEEPJ_FUSE_XW_MIN_TILES override the tile threshold (tests run the fused kernel on
+// small shapes with it).
+inline bool fuse_xw(const dj_config& c, const LstmP& L) {
+  const bool forced = c.fuse_xw_min_tiles > 0 || env_defaults().fuse_xw_min_tiles >= 0;
+  const int64_t min_tiles = c.fuse_xw_min_tiles > 0 ? c.fuse_xw_min_tiles
+                                                    : (env_defaults().fuse_xw_min_tiles >= 0 ? env_defaults().fuse_xw_min_tiles : 128);
   // H = 128 in bf16 keeps U (and W up to H columns) in registers: also the 259-wide note layer 0 is cheaper fused
   const int dmax = (L.H == 128 && L.dtype == DJ_BF16) ? 288 : 2 * L.H;
   if (!rec_persistent(L.H) || L.D > dmax) return false;
   // bf16 H = 256 with the weight-stationary cluster kernel: W and U never leave LDS, so the fused sweep also wins
   // the latency chain of a few tiles (generation: 5 tiles x 128 steps streamed 1 MB of weights per step before)
-  if (!e && L.H == 256 && L.dtype == DJ_BF16 && L.DP <= 256 && cluster_enabled()) return true;
+  if (!forced && L.H == 256 && L.dtype == DJ_BF16 && L.DP <= 256 && cluster_enabled(c)) return true;
   return L.tiles >= min_tiles;
 }
 
-// DEEPJ_CLUSTER=0 keeps the bf16 H = 256 forward sweep on the per-tile kernel (the host side sets it after a
-// cluster fault: model.py)
-inline bool cluster_enabled() {
-  const char* e = getenv("DEEPJ_CLUSTER");
-  return !(e && e[0] == '0');
-}
-
 // Where the BPTT kernel offers it (bf16, H = 128, D <= H: U^T and W^T both stationary in registers) it also
-// produces dX = dz W^T, which replaces one GEMM pass over dZ for that layer.  DEEPJ_FUSE_DX=0 keeps the GEMM.
-inline int fuse_dx(const LstmP& L) {            // 0: GEMM, 1: whole dX in the kernel, 2: last column block only
-  const char* e = getenv("DEEPJ_FUSE_DX");
-  if (!rec_persistent(L.H) || (e && e[0] == '0')) return 0;
+// produces dX = dz W^T, which replaces one GEMM pass over dZ for that layer.  DJ_KF_NO_FUSE_DX keeps the GEMM.
+inline int fuse_dx(const dj_config& c, const LstmP& L) {            // 0: GEMM, 1: whole dX in the kernel, 2: last column block only
+  if (!rec_persistent(L.H) || (kflags(c) & DJ_KF_NO_FUSE_DX)) return 0;
   return dj_lstm_bwd_has_dx(L.dtype, L.H, L.D);
 }
 
@@ -243,7 +264,7 @@ int prep_layer(const Ctx& c, const LstmP& L, int64_t wWt, int64_t wWc, int64_t w
                bool need_bwd) {
   const int dt = c.p.c.dtype;
   ProfScope ps(PC_PREP, c.st);
-  if (fuse_xw(L))   // input kernel W as MFMA B fragments for the fused x*W inside the recurrent kernel
+  if (fuse_xw(c.p.c, L))   // input kernel W as MFMA B fragments for the fused x*W inside the recurrent kernel
     RUN(dj_launch_lstm_pack_w(dt, L.H, c.P + L.W, L.D, dj_lstm_fused_nkx(dt, L.H, L.D), c.at(wWt), c.st));
   else              // k-contiguous Bt operand of the separate x*W GEMM
     RUN(dj_launch_cvt_transpose(dt, c.P + L.W, L.D, 4 * L.H, c.at(wWt), L.DP, c.st));
@@ -253,8 +274,8 @@ int prep_layer(const Ctx& c, const LstmP& L, int64_t wWt, int64_t wWc, int64_t w
     RUN(dj_launch_cvt_transpose(dt, c.P + L.U, L.H, 4 * L.H, c.at(wUf), L.H, c.st));
     if (need_bwd && dt != DJ_F32) RUN(dj_launch_cvt_copy(dt, c.P + L.U, (int64_t)L.H * 4 * L.H, c.at(wUb), c.st));
   }
-  if (need_bwd && fuse_dx(L)) RUN(dj_launch_lstm_pack_wt(dt, L.H, c.P + L.W, L.D, c.at(wWp), c.st));
-  if (need_bwd && fuse_dx(L) != 1 && dt != DJ_F32)
+  if (need_bwd && fuse_dx(c.p.c, L)) RUN(dj_launch_lstm_pack_wt(dt, L.H, c.P + L.W, L.D, c.at(wWp), c.st));
+  if (need_bwd && fuse_dx(c.p.c, L) != 1 && dt != DJ_F32)
     RUN(dj_launch_cvt_copy(dt, c.P + L.W, (int64_t)L.D * 4 * L.H, c.at(wWc), c.st));
   return 0;
 }
@@ -281,13 +302,13 @@ int style_proj_all(const Ctx& c, const LstmP* Ls, const int64_t* w_sp, int n) {
 int lstm_layer_fwd(const Ctx& c, const LstmP& L, int64_t tiles, int steps, int64_t M, int64_t wX, int64_t wWt,
                    int64_t wUf, int64_t wZ, int64_t wZx, int64_t wH, int64_t wC, bool is_note) {
   const int dt = c.p.c.dtype;
-  if (fuse_xw(L)) {
+  if (fuse_xw(c.p.c, L)) {
     // z = x W + h U + b in one persistent kernel (Z receives the gate stash when training)
     ProfScope ps(is_note ? PC_LSTM_FWD_NOTE : PC_LSTM_FWD_TIME, c.st);
     RUN(dj_launch_lstm_fwd_fused(dt, L.H, (int)tiles, steps, c.at(wX), L.DP, dj_lstm_fused_nkx(dt, L.H, L.D), c.at(wWt),
                                  c.P + L.b, c.train ? c.at(wZ) : nullptr, c.at(wUf), c.at(wH),
                                  c.train ? c.at(wC) : nullptr, c.p.c.recurrent_sigmoid,
-                                 cluster_enabled() ? c.at(c.p.w_cluster) : nullptr, c.st));
+                                 cluster_enabled(c.p.c) ? c.at(c.p.w_cluster) : nullptr, c.st));
     return 0;
   }
   if (!rec_persistent(L.H)) {        // per-step path: z row-major in the operand dtype, in place in the stash buffer
@@ -311,8 +332,8 @@ int lstm_layer_fwd(const Ctx& c, const LstmP& L, int64_t tiles, int steps, int64
   ProfScope ps(is_note ? PC_LSTM_FWD_NOTE : PC_LSTM_FWD_TIME, c.st);
   // fp32 inference with a handful of tiles (generation in the parity mode): 8 workgroups per tile with their slice of
   // U resident in LDS instead of one workgroup per tile streaming all of it every step (dj_lstm.hip)
-  if (!c.train && dt == DJ_F32 && L.H == 256 && tiles <= 8 && cluster_enabled() &&
-      !(getenv("DEEPJ_CLUSTER_F32") && getenv("DEEPJ_CLUSTER_F32")[0] == '0')) {
+  if (!c.train && dt == DJ_F32 && L.H == 256 && tiles <= 8 && cluster_enabled(c.p.c) &&
+      !(kflags(c.p.c) & DJ_KF_NO_CLUSTER_F32)) {
     const int rc = dj_launch_lstm_fwd_cluster_f32((int)tiles, steps, c.at(wZx), c.at(wUf), c.at(wH),
                                                   c.p.c.recurrent_sigmoid, c.at(c.p.w_cluster), c.st);
     if (rc != 1017) return rc;
@@ -350,8 +371,8 @@ int time_axis_forward(const Ctx& c, const float* notes, const float* beat) {
   // upper one a few steps behind the lower one, which writes the upper layer's input itself (dj_lstm.hip, ClPair) --
   // the two latency chains of T steps overlap instead of following each other
   if (!c.train && p.Lt == 2 && dt == DJ_BF16 && p.tl[0].H == 256 && p.tl[1].H == 256 && p.tl[0].DP <= 128 &&
-      p.tl[1].D == 256 && p.tl[1].DP == 256 && p.tilesT <= 64 && fuse_xw(p.tl[0]) && fuse_xw(p.tl[1]) && cluster_enabled() &&
-      dj_lstm_fused_nkx(dt, 256, p.tl[0].D) == 8 && !(getenv("DEEPJ_CLUSTER_PAIR") && getenv("DEEPJ_CLUSTER_PAIR")[0] == '0')) {
+      p.tl[1].D == 256 && p.tl[1].DP == 256 && p.tilesT <= 64 && fuse_xw(p.c, p.tl[0]) && fuse_xw(p.c, p.tl[1]) && cluster_enabled(p.c) &&
+      dj_lstm_fused_nkx(dt, 256, p.tl[0].D) == 8 && !(kflags(p.c) & DJ_KF_NO_CLUSTER_PAIR)) {
     ProfScope ps(PC_LSTM_FWD_TIME, c.st);
     const int rc = dj_launch_lstm_fwd_cluster_pair(
         (int)p.tilesT, p.T, c.at(p.w_X_t[0]), p.tl[0].DP, c.at(p.w_Wt_t[0]), c.P + p.tl[0].b, c.at(p.w_Uf_t[0]),
@@ -433,7 +454,7 @@ int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int st
                    int64_t wWc, int64_t wWp, int64_t wUb, int64_t wZ, int64_t wH, int64_t wC, int64_t wdH, int64_t wdX,
                    int64_t wdZ, bool is_note) {
   const int dt = c.p.c.dtype;
-  const int fdx = fuse_dx(L);
+  const int fdx = fuse_dx(c.p.c, L);
   const int64_t cts = dz_tile_stride(c, L, M);
   {
     ProfScope ps(is_note ? PC_LSTM_BWD_NOTE : PC_LSTM_BWD_TIME, c.st);
@@ -484,10 +505,46 @@ int check_ws(const Plan& p, void* ws, int64_t bytes) {
   return 0;
 }
 
+// one kernel: fault words of the cluster scratch added to out[0] as a float, words reset (dj_workspace_faults_async)
+__global__ void faults_to_float_kernel(int* fault_words, float* out) {
+  if (threadIdx.x == 0) {
+    const int n = fault_words[0] + fault_words[1];
+    if (n) { out[0] += (float)n; fault_words[0] = 0; fault_words[1] = 0; }
+  }
+}
+
 }  // namespace
+
+// process-level switch defaults for the kernel translation units (dj_lstm.hip, dj_gen.hip)
+uint32_t dj_env_flags() { return env_defaults().flags; }
 
 // =============================================================================== C ABI
 extern "C" {
+
+int32_t dj_env_reload(void) {
+  env_defaults() = read_env();
+  return 0;
+}
+
+int32_t dj_style_embedding(const dj_config* cfg, const float* params, const float* style_in, int32_t rows, float* out,
+                           void* stream) {
+  Plan p;
+  RUN(make_plan(cfg, p));
+  if (!params || !style_in || !out || rows < 1) return 1210;
+  return dj_launch_dense_small(style_in, rows, p.S, params + p.p_style_W, params + p.p_style_b, out, p.SU, 0,
+                               (hipStream_t)stream);                                     // model.py:141-142
+}
+
+int32_t dj_workspace_faults_async(const dj_config* cfg, void* ws, int64_t ws_bytes, float* out, void* stream) {
+  Plan p;
+  RUN(make_plan(cfg, p));
+  RUN(check_ws(p, ws, ws_bytes));
+  if (!out) return 1210;
+  if (!(p.Ht == 256 || p.Hn == 256)) return 0;             // no cluster kernels in this plan: nothing to add
+  hipLaunchKernelGGL(faults_to_float_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                     (int*)dj_lstm_cluster_fault_words((char*)ws + p.w_cluster), out);
+  return (int)hipGetLastError();
+}
 
 int32_t dj_abi_version(void) { return DJ_ABI_VERSION; }
 
@@ -762,7 +819,7 @@ int generate_resident(const dj_config* cfg, const float* params, void* state, fl
   RUN(check_ws(p, ws, ws_bytes));
   if (!params || !state || !results || !uniform_pool || !notes_src || !notes_dst || !beat_src || !beat_dst || !style_win)
     return 1210;
-  if (p.B > 8 || p.NB != 16) return 1301;
+  if (p.B > 8) return 1301;
   const int64_t need = (int64_t)(8 * 64 + 4 * 8 * 512 + (int64_t)p.B * p.N * 4 * p.Hn) * 4;
   if (need > p.Mn * (int64_t)p.nl[0].DP * p.esz) return 1302;
   Ctx c{p, params, (char*)ws, (hipStream_t)stream, false, 0};
@@ -822,7 +879,7 @@ int32_t dj_lstm_fwd_fused(int32_t dtype, int32_t H, int32_t ntiles, int32_t step
                           void* Hout, void* Cout, int32_t sigm, void* cluster_scratch, void* stream) {
   if (D > DP) return 1232;
   return dj_launch_lstm_fwd_fused(dtype, H, ntiles, steps, X, DP, dj_lstm_fused_nkx(dtype, H, D), wpack, bias, stash,
-                                  upack_fwd, Hout, Cout, sigm, cluster_enabled() ? cluster_scratch : nullptr,
+                                  upack_fwd, Hout, Cout, sigm, (env_defaults().flags & DJ_KF_NO_CLUSTER) ? nullptr : cluster_scratch,
                                   (hipStream_t)stream);
 }
 int64_t dj_lstm_cluster_scratch_bytes(void) { return dj_lstm_cluster_scratch_bytes_impl(); }
@@ -905,6 +962,14 @@ int32_t dj_workspace_cluster_faults(const dj_config* cfg, void* ws, int64_t ws_b
   if (make_plan(cfg, p) || check_ws(p, ws, ws_bytes)) return -1;
   if (!(p.Ht == 256 || p.Hn == 256)) return 0;
   return dj_lstm_cluster_faults_impl((char*)ws + p.w_cluster);
+}
+int32_t dj_workspace_cluster_fault_words(const dj_config* cfg, void* ws, int64_t ws_bytes, int32_t* words_host) {
+  Plan p;
+  if (!words_host || make_plan(cfg, p) || check_ws(p, ws, ws_bytes)) return 1210;
+  words_host[0] = words_host[1] = 0;
+  if (!(p.Ht == 256 || p.Hn == 256)) return 0;
+  return (int)hipMemcpy(words_host, dj_lstm_cluster_fault_words((char*)ws + p.w_cluster), 2 * sizeof(int32_t),
+                        hipMemcpyDeviceToHost);
 }
 int32_t dj_lstm_pack_wt(int32_t dtype, int32_t H, const float* W, int32_t D, void* out, void* stream) {
   return dj_launch_lstm_pack_wt(dtype, H, W, D, out, (hipStream_t)stream);

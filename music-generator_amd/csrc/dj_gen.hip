@@ -532,7 +532,7 @@ __global__ void gen_advance_kernel(DjGenState* st, const float* __restrict__ res
   }
 }
 // runs after gen_advance_kernel of the same step (separate launch: every block above reads st->step)
-__global__ void gen_state_kernel(DjGenState* st, const float* __restrict__ results, int G, int N) {
+__global__ void gen_state_kernel(DjGenState* st, const float* __restrict__ results, int G, int N, int notes_per_bar) {
   const int g = threadIdx.x;
   if (g < G) {
     const float* nn = results + ((int64_t)st->step * G + g) * N * 3;
@@ -540,7 +540,7 @@ __global__ void gen_state_kernel(DjGenState* st, const float* __restrict__ resul
     for (int i = 0; i < N * 3; ++i) any = any || (nn[i] != 0.f);
     if (!any) {
       st->silent[g] += 1;
-      if (st->silent[g] >= 16) st->temperature[g] += 0.1;
+      if (st->silent[g] >= notes_per_bar) st->temperature[g] += 0.1;   // NOTES_PER_BAR (generate.py:65-67)
     } else {
       st->silent[g] = 0;
       st->temperature[g] = st->default_temp[g];
@@ -556,7 +556,7 @@ int dj_launch_gen_advance(void* state, const float* results, const float* nsrc, 
                           float* bdst, int G, int T, int N, int NB, hipStream_t st) {
   hipLaunchKernelGGL(gen_advance_kernel, dim3(64), dim3(256), 0, st, (DjGenState*)state, results, nsrc, ndst, bsrc,
                      bdst, G, T, N, NB, 0);
-  hipLaunchKernelGGL(gen_state_kernel, dim3(1), dim3(64), 0, st, (DjGenState*)state, results, G, N);
+  hipLaunchKernelGGL(gen_state_kernel, dim3(1), dim3(64), 0, st, (DjGenState*)state, results, G, N, NB);
   return (int)hipGetLastError();
 }
 int dj_gen_state_bytes() { return (int)sizeof(DjGenState); }
@@ -614,7 +614,7 @@ int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int
   const size_t smem = ((size_t)3 * Ln * G * Hn + (size_t)G * 4 * Hn + (size_t)G * Hn + 3 * Hn + 4 + (size_t)G * N * 3 + 9 * G + 8) *
                           sizeof(float) + (size_t)2 * N * G * sizeof(double) + 16;
   if (smem > 64 * 1024) return 1301;
-  static const bool ks_off = getenv("DEEPJ_GEN_KSPLIT") && atoi(getenv("DEEPJ_GEN_KSPLIT")) == 0;
+  const bool ks_off = (dj_env_flags() & DJ_KF_NO_GEN_KSPLIT) != 0;
   if (!ks_off && G <= 4 && 4 * Hn <= 512 && smem + (size_t)3 * G * 4 * Hn * sizeof(float) <= 64 * 1024) {
     const size_t smem_ks = smem + (size_t)3 * G * 4 * Hn * sizeof(float);      // zp is 4 x the size of zb
     if (sigm)

@@ -1,6 +1,10 @@
 // Internal C++ interface between the kernel translation units and dj_api.hip.
 #pragma once
 #include "dj_common.h"
+#include "../../include/deepj_hip.h"      // DJ_KF_* kernel-selection flags
+
+// DEEPJ_* environment switches as read once at load / dj_env_reload() (dj_api.hip): OR of DJ_KF_* bits
+uint32_t dj_env_flags();
 
 struct FeatArgs {
   const float* notes;   // [B,T,N,3]
@@ -109,6 +113,8 @@ int64_t dj_lstm_cluster_scratch_bytes_impl();
 // expired waits + misplaced clusters recorded in that scratch since the last call (0 in a healthy run; the affected
 // tiles carry NaN), -1 on a HIP error; synchronises
 int dj_lstm_cluster_faults_impl(void* cluster_scratch);
+// device address of the two fault words inside a cluster scratch
+void* dj_lstm_cluster_fault_words(void* cluster_scratch);
 // dj_step.hip -- generic-H path (one GEMM + gate launch per recurrence step)
 int64_t dj_lstm_step_scratch_floats(int H, int64_t ntiles);
 int dj_launch_lstm_step_fwd(int dtype, int H, int ntiles, int steps, void* Z, const void* Ut, void* Hs, void* Cs,

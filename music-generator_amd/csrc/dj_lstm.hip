@@ -1879,10 +1879,19 @@ int cluster_cus() {
 }
 // Test hook: with DEEPJ_DEBUG_CLUSTER_FAULT set, the next launches fail their placement check (word 2 of the fault
 // line), so that the host-side handling (fallback in fit, errors in predict / generation) can be exercised on hardware.
+// Counters and XCC ids of every cluster start at zero in every launch.  A KERNEL, not hipMemsetAsync: under hipGraph
+// replay a memset node followed by the cluster kernel was observed to take effect AFTER the kernel's round-0 arrivals
+// in some replay histories (ROCm 7.2; every wait of that launch then expires, tools/scratch history in DESIGN.md
+// section 8) -- kernel -> kernel edges do not have that problem.
+__global__ void cl_reset_kernel(uint4* p) { p[blockIdx.x * 256 + threadIdx.x] = make_uint4(0, 0, 0, 0); }
+int cluster_reset(void* scratch, hipStream_t st) {
+  static_assert(CL_OFF_FAULT % (256 * 16) == 0, "reset grid");
+  hipLaunchKernelGGL(cl_reset_kernel, dim3(CL_OFF_FAULT / (256 * 16)), dim3(256), 0, st, (uint4*)scratch);
+  return (int)hipGetLastError();
+}
 int cluster_fault_hook(void* scratch, hipStream_t st) {
   static void* armed[16] = {};                        // scratches whose hook word is set (a handful of engines at most)
-  const char* e = getenv("DEEPJ_DEBUG_CLUSTER_FAULT");
-  const bool want = e && e[0] != '0';
+  const bool want = (dj_env_flags() & DJ_KF_DEBUG_CLUSTER_FAULT) != 0;
   int slot = -1, free_slot = -1;
   for (int i = 0; i < 16; ++i) {
     if (armed[i] == scratch) slot = i;
@@ -1905,8 +1914,7 @@ int launch_fwd_cluster(int ntiles, int steps, const void* X, int DP, int NKX, co
     return 1016;
   const size_t smem = (size_t)(4 * NKX * 64 + 4 * R::NKC * 64) * 16 + (size_t)8 * 4096;
   // counters and XCC ids of every cluster start at zero in every launch (a memset node under graph capture)
-  hipError_t e = hipMemsetAsync(scratch, 0, CL_OFF_FAULT, st);
-  if (e != hipSuccess) return (int)e;
+  if (int rc = cluster_reset(scratch, st)) return rc;
   if (int rc = cluster_fault_hook(scratch, st)) return rc;
   return sigm ? launch_fwd_cluster_s<true>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st)
               : launch_fwd_cluster_s<false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st);
@@ -1929,11 +1937,10 @@ int launch_fwd_cluster_pair(int ntiles, int steps, const ClPairArgs& a, int sigm
     }
     attr_done = true;
   }
-  hipError_t e = hipMemsetAsync(scratch, 0, CL_OFF_FAULT, st);
-  if (e != hipSuccess) return (int)e;
+  if (int rc = cluster_reset(scratch, st)) return rc;
   if (int rc = cluster_fault_hook(scratch, st)) return rc;
   // at most one tile per cluster (8 clusters per layer): the cooperative body, four waves per tile
-  static const bool coop_off = getenv("DEEPJ_CLUSTER_COOP") && getenv("DEEPJ_CLUSTER_COOP")[0] == '0';
+  const bool coop_off = (dj_env_flags() & DJ_KF_NO_CLUSTER_COOP) != 0;
   const bool coop = ntiles <= 8 && !coop_off;
 #define DJ_PAIR_LAUNCH(S, C_) \
   hipLaunchKernelGGL((lstm_fwd_cluster_pair_kernel<S, C_>), dim3(128), dim3(512), smem, st, a, steps, (int*)scratch, ntiles)
@@ -1967,8 +1974,7 @@ int dj_launch_lstm_fwd_cluster_f32(int ntiles, int steps, const void* Zx, const 
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipError_t e = hipMemsetAsync(scratch, 0, CL_OFF_FAULT, st);
-  if (e != hipSuccess) return (int)e;
+  if (int rc = cluster_reset(scratch, st)) return rc;
   if (int rc = cluster_fault_hook(scratch, st)) return rc;
   if (sigm)
     hipLaunchKernelGGL((lstm_fwd_cluster_f32_kernel<true>), dim3(64), dim3(512), smem, st, (const float*)Zx,
@@ -2045,6 +2051,7 @@ int dj_lstm_fused_nkx(int dtype, int H, int D) {
 int dj_launch_lstm_pack_w(int dtype, int H, const float* W, int D, int NKX, void* out, hipStream_t st) {
   DJ_DISPATCH_TH(launch_pack_w, W, D, NKX, out, st)
 }
+void* dj_lstm_cluster_fault_words(void* scratch) { return (char*)scratch + CL_OFF_FAULT; }
 int dj_lstm_cluster_faults_impl(void* scratch) {
   if (!scratch) return 0;
   int n[2] = {0, 0};

@@ -34,8 +34,10 @@ class DeepJConfig:
     recurrent_activation: str = "hard_sigmoid"     # Keras 2.x LSTM default
     dtype: str = "f32"                             # "f32" (parity) | "bf16" (throughput)
 
-    def cstruct(self, batch, time_steps=None, input_dropout=0.0, dropout=0.0):
+    def cstruct(self, batch, time_steps=None, input_dropout=0.0, dropout=0.0, kernel_flags=0, fuse_xw_min_tiles=0):
         c = _lib.DjConfig()
+        c.kernel_flags = int(kernel_flags)               # include/deepj_hip.h DJ_KF_* (per engine)
+        c.fuse_xw_min_tiles = int(fuse_xw_min_tiles)
         c.batch = int(batch)
         c.time_steps = int(self.time_steps if time_steps is None else time_steps)
         c.num_notes = self.num_notes
@@ -124,7 +126,7 @@ class Engine:
     """One (config, batch, time_steps) instance = one workspace in HBM."""
 
     def __init__(self, cfg: DeepJConfig, batch: int, time_steps: int | None = None, device="cuda:0",
-                 input_dropout: float = 0.0, dropout: float = 0.0):
+                 input_dropout: float = 0.0, dropout: float = 0.0, kernel_flags: int = 0, fuse_xw_min_tiles: int = 0):
         if not torch.cuda.is_available():
             raise _lib.DeepJError("no HIP device visible: the DeepJ engine has no CPU path")
         self.lib = _lib.load()
@@ -132,7 +134,8 @@ class Engine:
         self.device = torch.device(device)
         self.batch = int(batch)
         self.time_steps = int(cfg.time_steps if time_steps is None else time_steps)
-        self.c = cfg.cstruct(batch, self.time_steps, input_dropout, dropout)
+        self.c = cfg.cstruct(batch, self.time_steps, input_dropout, dropout, kernel_flags, fuse_xw_min_tiles)
+        self.flags_epoch = 0                             # bumped when kernel_flags change (captured graphs are stale then)
         self.nparams = int(self.lib.dj_param_count(C.byref(self.c)))
         nbytes = int(self.lib.dj_workspace_bytes(C.byref(self.c)))
         if self.nparams < 0 or nbytes < 0:
@@ -144,7 +147,15 @@ class Engine:
             self.ws_ptr = C.c_void_p(self.ws.data_ptr() + pad)
             _lib.check(self.lib.dj_workspace_init(C.byref(self.c), self.ws_ptr, nbytes, _stream_ptr()),
                        "dj_workspace_init")
-        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        # [mean loss, cluster faults of the call]: one device-to-host copy serves both (dj_workspace_faults_async)
+        self.loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+
+    def set_kernel_flags(self, flags: int):
+        """Per-engine kernel selection (DJ_KF_*); e.g. KF_NO_CLUSTER after a cluster fault.  Affects later calls of
+        THIS engine only -- no environment variable, no other engine."""
+        if int(flags) != int(self.c.kernel_flags):
+            self.c.kernel_flags = int(flags)
+            self.flags_epoch += 1
 
     def cluster_faults(self) -> int:
         """Events recorded by the weight-stationary cluster forward kernel in THIS engine's workspace since the last
@@ -154,7 +165,15 @@ class Engine:
             n = int(self.lib.dj_workspace_cluster_faults(C.byref(self.c), self.ws_ptr, self.ws_bytes))
         if n < 0:
             raise _lib.DeepJError("dj_workspace_cluster_faults failed")
-        return n
+        return n + self.take_async_faults()
+
+    def take_async_faults(self, value=None) -> int:
+        """Faults that train_fwd_bwd calls have added to loss[1] (dj_workspace_faults_async) since the last take;
+        `value`: the number if the caller has already read loss[1] with the loss."""
+        m = int(self.loss[1].item()) if value is None else int(value)
+        if m:
+            self.loss[1:].zero_()
+        return m
 
     def raise_on_cluster_faults(self, what):
         n = self.cluster_faults()
@@ -188,8 +207,22 @@ class Engine:
                                                _lib.ptr(out), _lib.ptr(self.loss), self.ws_ptr, self.ws_bytes,
                                                C.c_uint64(int(seed) & (2 ** 64 - 1)), 1 if accumulate else 0,
                                                _stream_ptr())
-        _lib.check(rc, "dj_train_fwd_bwd")
+            _lib.check(rc, "dj_train_fwd_bwd")
+            # fault census of this call next to the loss, without a host round trip
+            _lib.check(self.lib.dj_workspace_faults_async(C.byref(self.c), self.ws_ptr, self.ws_bytes,
+                                                          C.c_void_p(self.loss.data_ptr() + 4), _stream_ptr()),
+                       "dj_workspace_faults_async")
         return self.loss
+
+    def style_embedding(self, params, style_in):
+        """style Dense layer (model.py:141-142) on style_in [rows, num_styles] -> [rows, style_units] (device)."""
+        rows = int(style_in.shape[0])
+        self._check(style_in, (rows, self.cfg.num_styles), "style_in")
+        out = torch.empty((rows, self.cfg.style_units), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dj_style_embedding(C.byref(self.c), _lib.ptr(params), _lib.ptr(style_in), rows,
+                                                   _lib.ptr(out), _stream_ptr()), "dj_style_embedding")
+        return out
 
     def predict(self, params, notes, chosen, beat, style, target=None):
         s3, sb, ss = self._shapes()
@@ -202,7 +235,7 @@ class Engine:
                                      _lib.ptr(out), _lib.ptr(self.loss) if target is not None else None,
                                      self.ws_ptr, self.ws_bytes, _stream_ptr())
         _lib.check(rc, "dj_predict")
-        return (out, self.loss) if target is not None else out
+        return (out, self.loss[:1]) if target is not None else out
 
     def time_model_predict(self, params, notes, beat, style):
         s3, sb, ss = self._shapes()
@@ -280,6 +313,8 @@ class ResidentGeneration:
         self.pool = torch.zeros(2 * N * G * 128, dtype=torch.float64, device=dev)
         self.cur = 0                                              # which window buffer is current
         self.graph = None
+        self._graph_epoch = engine.flags_epoch
+        self.last_state = None
         self._want_graph = use_graph
 
     def _prepare(self):
@@ -320,6 +355,8 @@ class ResidentGeneration:
         assert st0 + k <= self.cap
         self.pool[:len(uniforms)].copy_(torch.as_tensor(np.asarray(uniforms, np.float64)))
         self._set_draw_off(0)
+        if self._graph_epoch != self.e.flags_epoch:               # kernel selection changed: the capture is stale
+            self.graph, self._graph_epoch = None, self.e.flags_epoch
         self._prepare()
         done = 0
         if self._want_graph and self.graph is None and self.cur == 0 and k >= 2:
@@ -347,7 +384,8 @@ class ResidentGeneration:
         # a cluster fault (expired wait, members of a cluster on different XCDs) poisons the affected rows with NaN,
         # which the sampler would turn into silence: never hand such notes out
         self.e.raise_on_cluster_faults("generation")
-        return out, int(self.read_state()["draw_off"])
+        self.last_state = self.read_state()                       # schedule after this chunk (checked by the host mirror)
+        return out, int(self.last_state["draw_off"])
 
 
 class Nadam:

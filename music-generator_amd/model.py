@@ -116,9 +116,16 @@ class HipBackend:
         idx = self.torch.as_tensor(np.ascontiguousarray(ids, dtype=np.int64)).to(self.device)
         return [x.index_select(0, idx) for x in tensors]
 
-    def engine(self, cfg, batch, time_steps, input_dropout, dropout):
+    def engine(self, cfg, batch, time_steps, input_dropout, dropout, kernel_flags=0):
         from .engine import Engine
-        return Engine(cfg, batch, time_steps, device=self.device, input_dropout=input_dropout, dropout=dropout)
+        return Engine(cfg, batch, time_steps, device=self.device, input_dropout=input_dropout, dropout=dropout,
+                      kernel_flags=kernel_flags)
+
+    def dense_layer(self, engine, params, name, x):
+        """get_layer(name)(x) on the device: only the `style` embedding (visualize.py:13-17) is a layer of its own."""
+        if name != "style":
+            raise NotImplementedError("only the 'style' layer is callable on its own")
+        return self.numpy(engine.style_embedding(params, self.tensor(x)))
 
     def optimizer(self, n, **kw):
         from .engine import Nadam
@@ -158,6 +165,7 @@ class _Shared:
         self.grads_ext = None
         self.optimizer = None
         self.engines = {}
+        self.kernel_flags = 0          # DJ_KF_* of every engine of these models (set after a cluster fault)
         self.step = 0
         self.seed = seed
 
@@ -168,8 +176,16 @@ class _Shared:
             # keep at most a handful of workspaces alive (each can be GBs)
             if len(self.engines) >= 6:
                 self.engines.pop(next(iter(self.engines)))
-            self.engines[key] = self.backend.engine(self.cfg, batch, time_steps, pin, pdr)
+            kw = {"kernel_flags": self.kernel_flags} if self.kernel_flags else {}
+            self.engines[key] = self.backend.engine(self.cfg, batch, time_steps, pin, pdr, **kw)
         return self.engines[key]
+
+    def add_kernel_flags(self, flags):
+        """OR `flags` (DJ_KF_*) into every present and future engine of these models -- and nowhere else."""
+        self.kernel_flags |= int(flags)
+        for e in self.engines.values():
+            if hasattr(e, "set_kernel_flags"):
+                e.set_kernel_flags(self.kernel_flags)
 
 
 class _Layer:
@@ -191,10 +207,10 @@ class _Layer:
         return out
 
     def __call__(self, x):
-        w = self.get_weights()
-        if len(w) != 2 or w[0].ndim != 2:
-            raise NotImplementedError("only Dense layers are callable on host arrays")
-        return np.asarray(x, np.float32) @ w[0] + w[1]
+        """The layer applied to a host array, computed by the backend (HIP: dj_style_embedding)."""
+        x = np.ascontiguousarray(x, np.float32)
+        s = self._s
+        return s.backend.dense_layer(s.engine(1, 1, train=False), s.params, self.name, x)
 
 
 class Model:
@@ -314,9 +330,12 @@ class TrainableModel(Model):
             raise NotImplementedError("only optimizer='nadam' is implemented")
 
     def _dist(self):
+        """torch.distributed when it is initialised with more than one rank (DEEPJ_DIST_WORLD1=1: also with ONE rank,
+        so that the collective branch of the step can be exercised on a single GPU -- tests/test_dist_gpu.py)."""
         try:
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if dist.is_available() and dist.is_initialized() and (
+                    dist.get_world_size() > 1 or os.environ.get("DEEPJ_DIST_WORLD1") == "1"):
                 return dist
         except Exception:
             pass
@@ -370,37 +389,50 @@ class TrainableModel(Model):
                 for i in range(parts):
                     mb = [x_[i * k:(i + 1) * k].contiguous() for x_ in t]
                     li = eng.train_fwd_bwd(s.params, s.grads, *mb, seed=(seed + 7919 * i) & 0xFFFFFFFF, accumulate=i > 0)
-                    loss = li.clone() if loss is None else loss + li
-                loss = loss / parts                              # equal parts: mean of the micro-batch means
+                    loss = li.clone() if loss is None else loss + li     # [sum of means, faults so far (cumulative)]
+                    if loss.numel() > 1:
+                        loss[1] = li[1]
+                loss[:1] /= parts                                # equal parts: mean of the micro-batch means
                 s.grads.mul_(1.0 / parts)
             return eng, loss
 
         eng, loss = fwd_bwd()
-        faults = eng.cluster_faults() if hasattr(eng, "cluster_faults") else 0
+        # loss = [mean loss, cluster faults of this step] on the device (dj_workspace_faults_async): ONE read-back
+        has_faults = loss.numel() > 1
         if dist:
             # shard-size weighting, then ONE sum over ranks of [gradient | weight, weight * loss, faults]
             tail = s.grads_ext[n:]
             s.grads.mul_(weight)
             tail[0] = weight
-            tail[1:2].copy_(loss.detach().reshape(1) * weight)
-            tail[2] = float(faults)
+            tail[1:2].copy_(loss.detach()[:1] * weight)
+            if has_faults:
+                tail[2:3].copy_(loss.detach()[1:2])
+            else:
+                tail[2] = 0.0
             dist.all_reduce(s.grads_ext)
             w_sum, wl_sum, faults = [float(v) for v in be.numpy(tail)[:3]]     # the step's one host read-back
             total = float(total_weight) if total_weight is not None else w_sum
             loss_value = wl_sum / total
             scale = 1.0 / total
+            local_faults = None
         else:
-            loss_value = float(be.numpy(loss)[0])
+            host = be.numpy(loss)                                              # the step's one host read-back
+            loss_value, faults = float(host[0]), (float(host[1]) if has_faults else 0.0)
             scale = 1.0
+            local_faults = faults
         if faults:
             # a cluster wait expired or a cluster was spread over several XCDs (include/deepj_hip.h): this step's
-            # numbers are NaN.  Nothing has been applied yet: switch every rank to the per-tile kernel and redo it.
-            if os.environ.get("DEEPJ_CLUSTER") == "0":
+            # numbers are NaN.  Nothing has been applied yet: every rank switches ITS engines of this model family to
+            # the per-tile kernel (a dj_config flag; no environment variable, no other model is touched) and the
+            # step is repeated.
+            from ._lib import KF_NO_CLUSTER
+            if s.kernel_flags & KF_NO_CLUSTER:
                 raise RuntimeError("cluster faults reported with the cluster kernel disabled")
-            if rank == 0:
-                print("[deepj] %d cluster faults in the recurrent forward kernel: falling back to the per-tile kernel "
-                      "(DEEPJ_CLUSTER=0) and repeating the step" % int(faults))
-            os.environ["DEEPJ_CLUSTER"] = "0"
+            print("[deepj] rank %d: %d cluster faults in the recurrent forward kernel: falling back to the per-tile "
+                  "kernel for this model (DJ_KF_NO_CLUSTER) and repeating the step" % (rank, int(faults)), flush=True)
+            if hasattr(eng, "take_async_faults"):
+                eng.take_async_faults(local_faults)                            # reset the device-side census
+            s.add_kernel_flags(KF_NO_CLUSTER)
             return self._train_step(x, target, on_device, weight, total_weight)
         if loss_value != loss_value:
             raise FloatingPointError("training loss is NaN at step %d" % s.step)

@@ -18,9 +18,17 @@ def _ocfg(cfg, T):
 
 
 class _Engine:
-    def __init__(self, cfg, batch, T, pin, pdr):
+    def __init__(self, cfg, batch, T, pin, pdr, kernel_flags=0):
         self.cfg, self.ocfg, self.B, self.T, self.pin, self.pdr = cfg, _ocfg(cfg, T), batch, T, pin, pdr
-        self.loss = torch.zeros(1)
+        self.loss = torch.zeros(2)            # [mean loss, cluster faults] like the HIP engine
+        self.kernel_flags = kernel_flags
+        self.inject_faults = []               # tests: fault counts reported by the next train_fwd_bwd calls
+
+    def set_kernel_flags(self, flags):
+        self.kernel_flags = int(flags)
+
+    def take_async_faults(self, value=None):
+        return int(value or 0)
 
     def _p(self, params):
         return O.unflatten_params(self.ocfg, params.numpy())
@@ -30,7 +38,8 @@ class _Engine:
         loss, o, g = O.loss_and_grads(self.ocfg, self._p(params),
                                       [t.numpy() for t in (notes, chosen, beat, style, target)], masks)
         grads.copy_(torch.from_numpy(O.flatten_params(self.ocfg, g)))
-        self.loss = torch.tensor([loss], dtype=torch.float32)
+        faults = float(self.inject_faults.pop(0)) if self.inject_faults else 0.0
+        self.loss = torch.tensor([float("nan") if faults else loss, faults], dtype=torch.float32)
         return self.loss
 
     def predict(self, params, notes, chosen, beat, style, target=None):
@@ -73,8 +82,12 @@ class OracleBackend:
     def numpy(self, t):
         return t.detach().numpy()
 
-    def engine(self, cfg, batch, T, pin, pdr):
-        return _Engine(cfg, batch, T, pin, pdr)
+    def engine(self, cfg, batch, T, pin, pdr, kernel_flags=0):
+        return _Engine(cfg, batch, T, pin, pdr, kernel_flags)
+
+    def dense_layer(self, engine, params, name, x):
+        p = O.unflatten_params(engine.ocfg, params.numpy())
+        return np.asarray(x, np.float32) @ p[name + "/kernel"] + p[name + "/bias"]
 
     def optimizer(self, n, **kw):
         return _Nadam(n, **kw)

@@ -83,3 +83,44 @@ def test_roofline_accounting_matches_survey():
     assert by["lstm_fwd_time"] == (94 + 2 * 256) * 2 + 1024 + (256 + 2 * 256) * 2 + 1024
     by32 = bench.category_bytes(DeepJConfig(num_notes=128, dtype="f32"), 1, 1, 1, 4)
     assert by32["lstm_bwd_time"] == 2 * 10 * 256 * 4
+
+
+def test_bench_gpus_n_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` with no launcher above it (the driver's plain command form) must start the N ranks
+    itself -- as a CHILD `python -m torch.distributed.run ... bench.py <same args>` (subprocess, not exec, before any GPU
+    call) -- pass their output through and exit with the child's code.  Checked with a stub in place of the launcher."""
+    stub = tmp_path / "stub_launcher.py"
+    stub.write_text("import json, sys\n"
+                    "print(json.dumps({'stub_argv': sys.argv[1:]}), flush=True)\n"
+                    "sys.exit(7)\n")
+    env = dict(os.environ, DEEPJ_BENCH_LAUNCHER=str(stub))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 7, r.stderr[-2000:]
+    import json
+    argv = json.loads(r.stdout.strip().splitlines()[-1])["stub_argv"]
+    assert argv[:2] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in argv and "--nproc-per-node=4" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and int(argv[argv.index("--master-port") + 1]) > 0
+    i = argv.index(os.path.join(ROOT, "bench.py"))
+    assert argv[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+
+
+def test_bench_self_launch_through_the_real_launcher_fails_loudly_without_gpus():
+    """The same path through the real torch.distributed.run on this GPU-less machine: two ranks start, each refuses to
+    run without a HIP device, and the parent reports the failure (non-zero exit, no JSON line) instead of hanging or
+    printing a number."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DEEPJ_BENCH_LAUNCHER"):
+        env.pop(k, None)
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "bench.py needs a HIP device" in (r.stderr + r.stdout)
+    assert '"metric"' not in r.stdout

@@ -1,0 +1,117 @@
+"""RCCL meets the training step on the device: torch.distributed backend "nccl" (= RCCL on ROCm) initialised at
+world size 1 on the one GPU of the test box, in a FRESH child process, driving (a) bench.py's own timed step
+(make_step with its all-reduce forced) and (b) the collective branch of Model._train_step (DEEPJ_DIST_WORLD1=1) for 3
+steps each on the production kernel selection (bf16, B16 x T16 x N128: 64 time-axis tiles -> the weight-stationary
+cluster kernel): parameters and losses equal the non-distributed path, exactly one collective per step, no cluster
+fault with RCCL's kernels on the same device.  This is the N = 1 end of the path the driver launches at N = 2, 4, 8
+(no multi-GPU node is available to the builder: the multi-rank arithmetic is covered by the 2-rank gloo tests)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import json, os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import bench
+from music_generator_amd.data import synthetic_batch
+from music_generator_amd.engine import DeepJConfig, Engine, Nadam, init_params_numpy
+from music_generator_amd.model import build_models
+
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=dev)
+calls = {{"n": 0}}
+_orig = dist.all_reduce
+def counted(*a, **k):
+    calls["n"] += 1
+    return _orig(*a, **k)
+dist.all_reduce = counted
+
+B, T, N, STEPS = 16, 16, 128, 3
+cfg = DeepJConfig(num_notes=N, time_steps=T, dtype="bf16")
+batch = [torch.from_numpy(a).to(dev) for a in synthetic_batch(N, T, B, seed=0)]
+out = {{}}
+
+def run_bench_step(force):
+    eng = Engine(cfg, B, T, device=dev, input_dropout=0.2, dropout=0.5, fuse_xw_min_tiles=1)
+    P = torch.from_numpy(init_params_numpy(cfg, seed=1234)).to(dev)
+    G = torch.zeros_like(P)
+    step = bench.make_step(eng, Nadam(P.numel(), dev), P, G, batch, 1, 0, dist, force_collective=force)
+    losses = [float(step(i).cpu()[0]) for i in range(STEPS)]
+    torch.cuda.synchronize()
+    return P.cpu().numpy(), losses, eng.cluster_faults()
+
+calls["n"] = 0
+p1, l1, f1 = run_bench_step(True)
+out["bench_collectives"] = calls["n"]
+p0, l0, f0 = run_bench_step(False)
+out["bench_faults"] = [f1, f0]
+out["bench_loss"] = [l1, l0]
+pinit = init_params_numpy(cfg, seed=1234)
+out["bench_param_maxdiff"] = float(np.abs(p1 - p0).max())
+out["bench_param_moved"] = float(np.abs(p1 - pinit).max())
+out["bench_update_rel_l2"] = float(np.linalg.norm(p1 - p0) / np.linalg.norm(p1 - pinit))
+
+def run_model(dist_branch):
+    if dist_branch:
+        os.environ["DEEPJ_DIST_WORLD1"] = "1"
+    else:
+        os.environ.pop("DEEPJ_DIST_WORLD1", None)
+    m = build_models(time_steps=T, config=cfg, seed=5)[0]
+    x = [b.cpu().numpy() for b in batch]
+    losses = [m.train_on_batch([x[0], x[1], x[2], x[3]], [x[4]]) for _ in range(STEPS)]
+    eng = m._s.engine(B, T, train=True)
+    return np.concatenate([w.ravel() for w in m.get_weights()]), losses, eng.cluster_faults(), m._s.kernel_flags
+
+winit = np.concatenate([w.ravel() for w in build_models(time_steps=T, config=cfg, seed=5)[0].get_weights()])
+
+calls["n"] = 0
+w1, ml1, mf1, k1 = run_model(True)
+out["model_collectives"] = calls["n"]
+w0, ml0, mf0, k0 = run_model(False)
+out["model_faults"] = [mf1, mf0, k1, k0]
+out["model_loss"] = [ml1, ml0]
+out["model_param_maxdiff"] = float(np.abs(w1 - w0).max())
+out["model_update_rel_l2"] = float(np.linalg.norm(w1 - w0) / np.linalg.norm(w1 - winit))
+dist.barrier()
+dist.destroy_process_group()
+print("RESULT " + json.dumps(out), flush=True)
+'''
+
+
+def test_rccl_world1_drives_bench_step_and_model_step(gpu_device, tmp_path):
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / "child.py"
+    script.write_text(CHILD.format(root=ROOT, port=port))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DEEPJ_DIST_WORLD1"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    o = json.loads(line[len("RESULT "):])
+    print("rccl world-1:", {k: v for k, v in o.items() if "loss" not in k})
+    steps = 3
+    # bench.py's step: one all-reduce per step, same parameters as without it (an all-reduce over one rank is the
+    # identity; fp32 atomics reorder the gradient sums between runs), the cluster kernel never faulted beside RCCL
+    assert o["bench_collectives"] == steps
+    assert o["bench_faults"] == [0, 0]
+    # (Nadam divides by sqrt(v): where a gradient is rounding noise the two runs may step in different directions, so
+    # single parameters differ by up to ~lr; the UPDATE as a whole agrees)
+    assert o["bench_param_moved"] > 1e-3 and o["bench_param_maxdiff"] < 3 * 2e-3 and o["bench_update_rel_l2"] < 5e-3, o
+    assert all(abs(a - b) < 1e-4 * abs(b) for a, b in zip(*o["bench_loss"])), o["bench_loss"]
+    # Model._train_step: [gradient | weight, weight * loss, faults] in ONE collective per step
+    assert o["model_collectives"] == steps
+    assert o["model_faults"] == [0, 0, 0, 0]
+    assert o["model_param_maxdiff"] < 3 * 2e-3 and o["model_update_rel_l2"] < 5e-3, o
+    assert all(abs(a - b) < 1e-4 * abs(b) for a, b in zip(*o["model_loss"])), o["model_loss"]

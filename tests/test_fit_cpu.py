@@ -86,6 +86,22 @@ def test_summary_and_layers(capsys):
     assert note_model.time_steps == 1
 
 
+def test_visualize_writes_the_reference_files(tmp_path, monkeypatch):
+    """visualize.main (reference visualize.py:11-43): OUT_DIR/style_embedding_vec.tsv [23, 64] and
+    style_embedding_labels.tsv with the (Genre, Artist) header + one row per style."""
+    from music_generator_amd import constants as K, visualize
+    monkeypatch.chdir(tmp_path)
+    models = _tiny_models()
+    emb = visualize.main(models=models)
+    w = models[0].get_layer("style").get_weights()
+    np.testing.assert_allclose(emb, w[0] + w[1], rtol=1e-6)
+    got = np.loadtxt(os.path.join(K.OUT_DIR, "style_embedding_vec.tsv"), delimiter="\t")
+    assert got.shape == (23, 64)
+    rows = [ln.rstrip("\n").split("\t") for ln in open(os.path.join(K.OUT_DIR, "style_embedding_labels.tsv"))]
+    assert rows[0] == ["Genre", "Artist"] and len(rows) == 24
+    assert [r[0] for r in rows[1:]].count("classical") == 6 and rows[4] == ["classical", "data/classical/burgmueller"]
+
+
 WORKER = r'''
 import os, sys
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
@@ -203,45 +219,54 @@ def test_checkpoint_name_map_and_hdf5_detection(tmp_path, monkeypatch, capsys):
 
 
 def test_cluster_fault_repeats_the_step_on_the_per_tile_kernel(monkeypatch, capsys):
-    """A cluster fault (expired wait / misplaced cluster, include/deepj_hip.h) makes the step's numbers NaN.  The
-    host side must notice BEFORE the optimizer step, switch to the per-tile kernel (DEEPJ_CLUSTER=0) and repeat the
-    step, so that the result equals a fault-free step; a fault with the cluster kernel already off is an error."""
-    os.environ.pop("DEEPJ_CLUSTER", None)
+    """A cluster fault (expired wait / misplaced cluster, include/deepj_hip.h) makes the step's numbers NaN and is
+    reported next to the loss ([loss, faults], one read-back).  The host side must notice BEFORE the optimizer step,
+    switch THIS model family's engines to the per-tile kernel (dj_config.kernel_flags |= DJ_KF_NO_CLUSTER -- no
+    environment variable, no other model) and repeat the step, so that the result equals a fault-free step; a fault
+    with the cluster kernel already off is an error."""
+    from music_generator_amd._lib import KF_NO_CLUSTER
+    monkeypatch.delenv("DEEPJ_CLUSTER", raising=False)
     x, y = _data(2)
 
     def run(faulty):
         model, _, _ = _tiny_models(input_dropout=0.0, dropout=0.0)
-        calls = {"n": 0}
+        made = []
         orig_engine = model._s.backend.engine
 
         def engine(*a, **k):
             e = orig_engine(*a, **k)
-            def cluster_faults():
-                calls["n"] += 1
-                return 3 if (faulty and calls["n"] == 1) else 0
-            e.cluster_faults = cluster_faults
+            if faulty and not made:
+                e.inject_faults = [3]
+            made.append(e)
             return e
         model._s.backend.engine = engine
         loss = model.train_on_batch(x, y)
-        return loss, model.get_weights(), calls["n"]
+        return loss, model, made
 
-    l0, w0, n0 = run(False)
-    assert n0 == 1 and os.environ.get("DEEPJ_CLUSTER") is None
-    l1, w1, n1 = run(True)
-    assert n1 == 2 and os.environ.get("DEEPJ_CLUSTER") == "0"
+    l0, m0, e0 = run(False)
+    assert m0._s.kernel_flags == 0 and all(e.kernel_flags == 0 for e in e0)
+    l1, m1, e1 = run(True)
+    assert m1._s.kernel_flags == KF_NO_CLUSTER and all(e.kernel_flags == KF_NO_CLUSTER for e in e1)
+    assert "DEEPJ_CLUSTER" not in os.environ                        # per-model state, not process state
     assert "falling back to the per-tile kernel" in capsys.readouterr().out
-    assert l1 == l0 and all(np.array_equal(a, b) for a, b in zip(w0, w1))
+    assert l1 == l0 and all(np.array_equal(a, b) for a, b in zip(m0.get_weights(), m1.get_weights()))
+    # engines created later inherit the flag; an unrelated model family does not
+    later = m1._s.engine(3, 4, train=False)
+    assert later.kernel_flags == KF_NO_CLUSTER
+    other, _, _ = _tiny_models(input_dropout=0.0, dropout=0.0)
+    other.train_on_batch(x, y)
+    assert other._s.kernel_flags == 0
     # cluster kernel already disabled and still a fault: not recoverable
     model, _, _ = _tiny_models(input_dropout=0.0, dropout=0.0)
+    model._s.add_kernel_flags(KF_NO_CLUSTER)
     orig_engine = model._s.backend.engine
 
     def bad_engine(*a, **k):
         e = orig_engine(*a, **k)
-        e.cluster_faults = lambda: 1
+        e.inject_faults = [1]
         return e
     model._s.backend.engine = bad_engine
     before = [w.copy() for w in model.get_weights()]
     with pytest.raises(RuntimeError, match="cluster faults"):
         model.train_on_batch(x, y)
     assert all(np.array_equal(a, b) for a, b in zip(before, model.get_weights()))     # nothing was applied
-    os.environ.pop("DEEPJ_CLUSTER", None)              # set by the product code, not through monkeypatch

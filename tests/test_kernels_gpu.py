@@ -447,3 +447,70 @@ def test_lstm_bwd_remainder_input_gradient(gpu_device):
     torch.testing.assert_close(got[:, 256:259], ref[:, 256:259], rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
     assert float(got[:, 259].abs().max()) == 0.0                           # 4th stored column: zero weight row
     assert bool((got[:, :256] == 7.0).all()) and bool((got[:, 260:] == 7.0).all())
+
+
+@pytest.mark.parametrize("H,S,Ls", [(256, 96, 9), (128, 64, 12)])
+def test_gate_stash_quantiser_bounds_dz(gpu_device, H, S, Ls):
+    """The 8-bit activated-gate stash of the bf16 kernels (include/deepj_hip.h 'Gate stash': |error| <= 1/508 for
+    i, f, o and 1/254 for g, codes 0 / 255 = saturated hard_sigmoid) tested as a QUANTISER: the same forward is run by
+    the bf16 kernels (8-bit stash) and by the fp32 kernels (z stash, exact activations in BPTT) on identical operand
+    values; BPTT of both on the same upstream gradient; the difference in dz and in the bias gradient is bounded at
+    ~2x what the encoding explains, far below the whole-step gradient tolerance.  Pre-activations are scaled so that
+    a good share of the gates saturate (codes 0 and 255 both present)."""
+    L, lib = _lib()
+    D, sigm = 24, 0
+    x, W, U, b = _lstm_setup(S, Ls, D, H, 3 * H + S)
+    bf = lambda t: t.to(torch.bfloat16).float()
+    zx = bf((x @ W + b) * 2.5)                 # |z| spreads past the +-2.5 knees of hard_sigmoid
+    Ur = bf(U)
+    dH = bf(torch.randn(S, Ls, H, generator=torch.Generator().manual_seed(5)) * 0.1)
+    zrows, tiles = to_rows(zx)
+    R = zrows.shape[0]
+    res = {}
+    for dtype in ("f32", "bf16"):
+        esz = 2 if dtype == "bf16" else 4
+        Zd = _op(to_frag(zrows), dtype).to(gpu_device)
+        upf = torch.empty(H * 4 * H * esz, dtype=torch.uint8, device=gpu_device)
+        upb = torch.empty_like(upf)
+        L.check(lib.dj_lstm_pack(DT[dtype], H, L.ptr(Ur.to(gpu_device)), L.ptr(upf), L.ptr(upb), _st()), "pack")
+        Hd = torch.zeros(R, H, dtype=Zd.dtype, device=gpu_device)
+        Cd = torch.zeros(R * H, dtype=Zd.dtype, device=gpu_device)
+        Gd = stash_buffer(R, H, dtype, gpu_device)
+        L.check(lib.dj_lstm_fwd(DT[dtype], H, tiles, Ls, L.ptr(Zd), L.ptr(Gd), L.ptr(upf), L.ptr(Hd), L.ptr(Cd), sigm,
+                                _st()), "fwd")
+        dHd = _op(to_rows(dH)[0], dtype).to(gpu_device)
+        db = torch.zeros(4 * H, dtype=torch.float32, device=gpu_device)
+        dZd = torch.zeros(R, 4 * H, dtype=Zd.dtype, device=gpu_device)
+        L.check(lib.dj_lstm_bwd(DT[dtype], H, tiles, Ls, L.ptr(Gd), L.ptr(upb), L.ptr(Cd), L.ptr(dHd), L.ptr(dZd), 0,
+                                L.ptr(db), sigm, _st()), "bwd")
+        res[dtype] = (from_rows(dZd.float().cpu(), S, Ls), db.cpu(), from_rows(from_frag(Gd.float().cpu(), R, 4 * H), S, Ls),
+                      from_rows(Hd.float().cpu(), S, Ls))
+    dz32, db32, z32, h32 = res["f32"]
+    dz16, db16, code, h16 = res["bf16"]
+    # the forward passes agree to bf16 rounding of h (the recurrence feeds it back)
+    assert float((h16 - h32).abs().max()) < 2e-2
+    # saturation is exercised on both sides, and the reserved codes mark exactly the saturated gates of the fp32 run
+    gates = torch.cat([z32[..., :2 * H], z32[..., 3 * H:]], -1)
+    codes = torch.cat([code[..., :2 * H], code[..., 3 * H:]], -1)
+    assert float((codes == 0).float().mean()) > 0.02 and float((codes == 255).float().mean()) > 0.02
+    clear = (gates.abs() - 2.5).abs() > 0.1          # away from the knee by more than the bf16 noise of z
+    assert bool(((codes == 0) == (gates < -2.5))[clear].all()) and bool(((codes == 255) == (gates > 2.5))[clear].all())
+    # a saturated gate has derivative 0: dz of that gate is exactly zero in both runs
+    dzg16 = torch.cat([dz16[..., :2 * H], dz16[..., 3 * H:]], -1)
+    assert float(dzg16[(codes == 0) | (codes == 255)].abs().max()) == 0.0
+    # dz of a gate whose pre-activation sits AT a knee of hard_sigmoid can differ by the whole value between the two
+    # runs (the bf16 forward's z noise flips the 0.2 / 0 derivative): that is forward rounding, not the stash -- the
+    # element-wise bound is taken over the gates that are clear of the knees (g has none); the rms and the bias
+    # gradient are taken over everything
+    ok = torch.ones_like(dz32, dtype=torch.bool)
+    ok[..., :2 * H] = clear[..., :2 * H]
+    ok[..., 3 * H:] = clear[..., 2 * H:]
+    assert float(ok.float().mean()) > 0.9
+    scale = float(dz32.abs().max())
+    err = float((dz16 - dz32)[ok].abs().max()) / scale
+    err_all = float((dz16 - dz32).abs().max()) / scale
+    rms = float((dz16 - dz32).pow(2).mean().sqrt()) / float(dz32.pow(2).mean().sqrt())
+    dberr = float((db16 - db32).abs().max()) / float(db32.abs().max())
+    print("stash quantiser H=%d: max|ddz|/max|dz| %.2e clear of the knees (%.2e with them), rms ratio %.2e, dbias %.2e"
+          % (H, err, err_all, rms, dberr))
+    assert err < 3e-2 and rms < 1.5e-2 and dberr < 2.5e-2, (err, err_all, rms, dberr)

@@ -46,6 +46,11 @@ def _grad_report(ocfg, g_hip, g_ref):
     return worst, rows
 
 
+# bf16 mode, worst gradient tensor relative to its max: 2e-2 is ~2-4x what these cases show (DESIGN.md "Tolerances":
+# 5e-3 on the production-kernel case; the small cases print theirs) -- a regression of the 8-bit gate stash or of a
+# bf16 operand path by a factor of a few fails here instead of hiding in an 8e-2 allowance
+BF16_GRAD_TOL = 2e-2
+
 CASES = [
     # name, cfg kwargs, B, T, input_dropout, dropout
     ("ref_dims_nodrop", dict(), 2, 8, 0.0, 0.0),
@@ -64,11 +69,11 @@ CASES = [
 
 
 @pytest.fixture(params=["default", "fused_xw"])
-def xw_mode(request, monkeypatch):
+def xw_mode(request, djenv):
     """The library fuses x*W into the recurrent kernel only from 128 sequence tiles up (the BASELINE
     shape); DEEPJ_FUSE_XW_MIN_TILES=1 makes the small parity shapes take that kernel too."""
     if request.param == "fused_xw":
-        monkeypatch.setenv("DEEPJ_FUSE_XW_MIN_TILES", "1")
+        djenv.set("DEEPJ_FUSE_XW_MIN_TILES", "1")
     return request.param
 
 
@@ -107,16 +112,17 @@ def test_train_step_bf16_close(gpu_device, xw_mode, kw):
     np.testing.assert_allclose(out, out_ref, rtol=3e-2, atol=3e-3)     # bf16 operands: ~2^-8 relative
     assert abs(loss - loss_ref) <= 2e-2 * max(1.0, abs(loss_ref))
     worst, rows = _grad_report(ocfg, g, g_ref)
-    assert worst < 8e-2, sorted(rows, key=lambda r: -r[1])[:6]
+    print("bf16 step vs oracle (%s): |dloss| %.2e, worst grad tensor %.2e" % (kw or "ref dims", abs(loss - loss_ref), worst))
+    assert worst < BF16_GRAD_TOL, sorted(rows, key=lambda r: -r[1])[:6]
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_train_step_production_kernels_vs_oracle(gpu_device, monkeypatch, dtype):
+def test_train_step_production_kernels_vs_oracle(gpu_device, djenv, dtype):
     """The kernel selection of the bench shape, as ONE forward + BPTT step against the oracle, dropout on:
     B16 x T16 x N128 gives 64 time-axis sequence tiles, so bf16 runs the weight-stationary cluster kernel
     (both time layers) feeding the glue, stash, BPTT and weight-gradient kernels; the note axis (8 tiles) is
     forced onto its fused x*W / fused dX kernels.  fp32 at the north_star tolerance, bf16 at bf16 tolerance."""
-    monkeypatch.setenv("DEEPJ_FUSE_XW_MIN_TILES", "1")
+    djenv.set("DEEPJ_FUSE_XW_MIN_TILES", "1")
     B, T, seed, pin, pdr = 16, 16, 1234567, 0.2, 0.5
     ocfg, dcfg = _cfgs(time_steps=T, num_notes=128, dtype=dtype)
     params = O.init_params(ocfg, seed=11)
@@ -137,7 +143,7 @@ def test_train_step_production_kernels_vs_oracle(gpu_device, monkeypatch, dtype)
     else:
         np.testing.assert_allclose(out, out_ref, rtol=3e-2, atol=3e-3)
         assert abs(loss - loss_ref) <= 2e-2 * max(1.0, abs(loss_ref)), (loss, loss_ref)
-        assert worst < 8e-2, sorted(rows, key=lambda r: -r[1])[:6]
+        assert worst < BF16_GRAD_TOL, sorted(rows, key=lambda r: -r[1])[:6]
     print("production-kernel parity (%s): |dloss| %.2e, worst grad tensor %.2e" % (dtype, abs(loss - loss_ref), worst))
 
 
@@ -173,7 +179,7 @@ def test_predict_models_fp32(gpu_device):
 
 
 @pytest.mark.parametrize("G,T,N", [(3, 128, 48), (5, 16, 40), (1, 7, 128)], ids=["gen_window", "ragged_tiles", "one_piece"])
-def test_time_axis_pair_launch_matches_layer_by_layer(gpu_device, monkeypatch, G, T, N):
+def test_time_axis_pair_launch_matches_layer_by_layer(gpu_device, djenv, G, T, N):
     """Inference of the bf16 time axis runs both 256-unit layers as one wavefront launch (dj_lstm.hip ClPair): its
     output must be bit-identical to the layer-by-layer launches (same arithmetic, the glue folded into the lower
     layer's store), close to the fp32 oracle, and leave no cluster fault."""
@@ -184,12 +190,17 @@ def test_time_axis_pair_launch_matches_layer_by_layer(gpu_device, monkeypatch, G
     notes, chosen, beat, style, target = O.synthetic_batch(ocfg, G, seed=4, T=T)
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(gpu_device)
     eng = Engine(dcfg, G, T, device=gpu_device)
-    monkeypatch.delenv("DEEPJ_CLUSTER_PAIR", raising=False)
+    from music_generator_amd._lib import KF_NO_CLUSTER_PAIR
+    djenv.unset("DEEPJ_CLUSTER_PAIR")
     pair = eng.time_model_predict(flat, d(notes), d(beat), d(style)).float().cpu().numpy()
     pair2 = eng.time_model_predict(flat, d(notes), d(beat), d(style)).float().cpu().numpy()
-    monkeypatch.setenv("DEEPJ_CLUSTER_PAIR", "0")
+    eng.set_kernel_flags(KF_NO_CLUSTER_PAIR)                 # per-engine switch (dj_config.kernel_flags)
     seq = eng.time_model_predict(flat, d(notes), d(beat), d(style)).float().cpu().numpy()
-    monkeypatch.delenv("DEEPJ_CLUSTER_PAIR", raising=False)
+    eng.set_kernel_flags(0)
+    djenv.set("DEEPJ_CLUSTER_PAIR", "0")                     # the same switch as a process default
+    seq_env = eng.time_model_predict(flat, d(notes), d(beat), d(style)).float().cpu().numpy()
+    djenv.unset("DEEPJ_CLUSTER_PAIR")
+    np.testing.assert_array_equal(seq, seq_env)
     assert eng.cluster_faults() == 0
     assert np.isfinite(pair).all()
     np.testing.assert_array_equal(pair, pair2)
@@ -199,7 +210,7 @@ def test_time_axis_pair_launch_matches_layer_by_layer(gpu_device, monkeypatch, G
 
 
 @pytest.mark.parametrize("G,T,N", [(3, 128, 48), (5, 16, 40), (1, 7, 128)], ids=["gen_window", "ragged_tiles", "one_piece"])
-def test_time_axis_fp32_cluster_matches_per_tile_kernel(gpu_device, monkeypatch, G, T, N):
+def test_time_axis_fp32_cluster_matches_per_tile_kernel(gpu_device, djenv, G, T, N):
     """fp32 inference of the time axis with at most 8 sequence tiles runs on clusters of 8 workgroups with U resident in
     LDS (lstm_fwd_cluster_f32_kernel): bit-identical to the per-tile kernel (same sums in the same order), within the
     north_star's 1e-3 of the oracle, no cluster fault."""
@@ -210,11 +221,12 @@ def test_time_axis_fp32_cluster_matches_per_tile_kernel(gpu_device, monkeypatch,
     notes, chosen, beat, style, target = O.synthetic_batch(ocfg, G, seed=6, T=T)
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(gpu_device)
     eng = Engine(dcfg, G, T, device=gpu_device)
-    monkeypatch.delenv("DEEPJ_CLUSTER_F32", raising=False)
+    from music_generator_amd._lib import KF_NO_CLUSTER_F32
+    djenv.unset("DEEPJ_CLUSTER_F32")
     cl = eng.time_model_predict(flat, d(notes), d(beat), d(style)).cpu().numpy()
-    monkeypatch.setenv("DEEPJ_CLUSTER_F32", "0")
+    eng.set_kernel_flags(KF_NO_CLUSTER_F32)
     pt = eng.time_model_predict(flat, d(notes), d(beat), d(style)).cpu().numpy()
-    monkeypatch.delenv("DEEPJ_CLUSTER_F32", raising=False)
+    eng.set_kernel_flags(0)
     assert eng.cluster_faults() == 0
     np.testing.assert_array_equal(cl, pt)
     tref = O.time_model_predict(ocfg, params, notes, beat, style)
@@ -258,6 +270,9 @@ def test_keras_surface_on_hip(gpu_device, tmp_path):
     np.testing.assert_allclose(hm[2].predict([feat, ch, st[:, None]]), om[2].predict([feat, ch, st[:, None]]),
                                rtol=1e-3, atol=1e-5)
     assert abs(hm[0].evaluate(x, y) - om[0].evaluate(x, y)) < 1e-4
+    # f-4: the style-embedding export on the trained HIP weights (device kernel) vs the oracle twin
+    from music_generator_amd import visualize
+    np.testing.assert_allclose(visualize.style_embeddings(hm), visualize.style_embeddings(om), rtol=1e-5, atol=1e-6)
     ck = str(tmp_path / "m.npz")
     hm[0].save_weights(ck)
     hm2 = build_models(time_steps=T, seed=9)
@@ -265,28 +280,29 @@ def test_keras_surface_on_hip(gpu_device, tmp_path):
     np.testing.assert_array_equal(hm2[0].get_weights()[5], hm[0].get_weights()[5])
 
 
-def test_injected_cluster_fault_is_never_silent(gpu_device, monkeypatch, capsys):
+def test_injected_cluster_fault_is_never_silent(gpu_device, djenv, capsys):
     """DEEPJ_DEBUG_CLUSTER_FAULT makes the bf16 cluster kernels fail their placement check on the device (rows
     poisoned with NaN, the event counted in the workspace).  What the host side must make of it: train_on_batch
-    notices before the optimizer step, switches the process to the per-tile kernel and repeats the step -- the result
-    equals a fault-free step on the per-tile kernel; predict, evaluate and generation raise instead of returning NaN
-    (or silence sampled from NaN)."""
+    reads the census WITH the loss (one copy), notices before the optimizer step, switches THIS model's engines to the
+    per-tile kernel (dj_config.kernel_flags; the process environment is not touched, other models keep the cluster
+    kernels) and repeats the step -- the result equals a fault-free step on the per-tile kernel; predict, evaluate and
+    generation raise instead of returning NaN (or silence sampled from NaN)."""
     from music_generator_amd import generate as Gn
-    from music_generator_amd._lib import DeepJError
+    from music_generator_amd._lib import DeepJError, KF_NO_CLUSTER
     from music_generator_amd.data import synthetic_batch
     from music_generator_amd.dataset import compute_genre
     from music_generator_amd.model import build_models
     T = 8
     a = synthetic_batch(48, T, 3, seed=2)
     x, y = [a[0], a[1], a[2], a[3]], [a[4]]
-    monkeypatch.delenv("DEEPJ_DEBUG_CLUSTER_FAULT", raising=False)
-    monkeypatch.setenv("DEEPJ_CLUSTER", "0")                 # reference: the per-tile kernels, no fault
+    djenv.unset("DEEPJ_DEBUG_CLUSTER_FAULT")
+    djenv.unset("DEEPJ_CLUSTER")
     ref = build_models(time_steps=T, dtype="bf16", input_dropout=0.0, dropout=0.0, seed=4)
+    ref[0]._s.add_kernel_flags(KF_NO_CLUSTER)                # reference: the per-tile kernels, no fault
     l_ref = ref[0].train_on_batch(x, y)
     w_ref = ref[0].get_weights()
-    monkeypatch.delenv("DEEPJ_CLUSTER")
     hm = build_models(time_steps=T, dtype="bf16", input_dropout=0.0, dropout=0.0, seed=4)
-    monkeypatch.setenv("DEEPJ_DEBUG_CLUSTER_FAULT", "1")
+    djenv.set("DEEPJ_DEBUG_CLUSTER_FAULT", "1")
     with pytest.raises(DeepJError, match="cluster faults"):
         hm[0].predict(x)
     with pytest.raises(DeepJError, match="cluster faults"):
@@ -297,21 +313,25 @@ def test_injected_cluster_fault_is_never_silent(gpu_device, monkeypatch, capsys)
         list(Gn.generate(gm, 1, [compute_genre(i) for i in range(3)]))
     l_f = hm[0].train_on_batch(x, y)                         # falls back and repeats the step
     assert "falling back to the per-tile kernel" in capsys.readouterr().out
-    assert os.environ.get("DEEPJ_CLUSTER") == "0"
-    monkeypatch.delenv("DEEPJ_DEBUG_CLUSTER_FAULT")
+    assert hm[0]._s.kernel_flags == KF_NO_CLUSTER and "DEEPJ_CLUSTER" not in os.environ
+    assert gm[0]._s.kernel_flags == 0                        # another model family is not downgraded
     assert np.isfinite(l_f) and abs(l_f - l_ref) < 1e-5 * abs(l_ref)     # (fp32 atomics reorder the loss / gradient sums)
     for wa, wb in zip(hm[0].get_weights(), w_ref):
         np.testing.assert_allclose(wa, wb, rtol=0, atol=1e-4)             # one Nadam step of lr 2e-3 on equal gradients
-    monkeypatch.delenv("DEEPJ_CLUSTER", raising=False)       # the fallback set it for the process
-    os.environ.pop("DEEPJ_CLUSTER", None)
+    l_g = hm[0].train_on_batch(x, y)                         # stays on the per-tile kernel: no fault, no message
+    assert np.isfinite(l_g) and "falling back" not in capsys.readouterr().out
+    assert np.isfinite(hm[0].predict(x)).all()               # its inference engines inherited the flag
+    djenv.unset("DEEPJ_DEBUG_CLUSTER_FAULT")
     # and the hook is gone: a fresh model runs the cluster kernels without a fault
     ok = build_models(time_steps=T, dtype="bf16", input_dropout=0.0, dropout=0.0, seed=4)
     assert np.isfinite(ok[0].predict(x)).all()
+    assert np.isfinite(ok[0].train_on_batch(x, y)) and ok[0]._s.kernel_flags == 0
 
 
 def test_generate_with_hip_models_matches_oracle_models(gpu_device):
     """generate() (reference sampling semantics, NumPy RNG stream) with the HIP models vs the
-    same harness with the CPU-oracle models, 16 time steps x 3 pieces x 48 notes: identical sampled
+    same harness with the CPU-oracle models, 160 time steps x 3 pieces x 48 notes -- longer than the 128-step
+    window, so the last 32 steps see a window made of generated notes only (no zero prefix): identical sampled
     rolls under the same seed.  A Bernoulli decision u <= p can only differ between two
     implementations if u lies closer to p than their p's differ; the device sampler counts the
     draws within 1e-5 of p (fp32 outputs agree to ~1e-6), so the comparison is CERTIFIED rather than
@@ -329,17 +349,20 @@ def test_generate_with_hip_models_matches_oracle_models(gpu_device):
         w[names.index("note_dense/bias")] = np.array([0.3, 0.0], np.float32)
         m[0].set_weights(w)
     styles = [compute_genre(i) for i in range(3)]
-    steps = 16
-    np.random.seed(5)
-    a = np.array(list(Gn.generate(hm, 1, styles)))
+    steps = 160
+    np.random.seed(1)                   # a stream without a near tie in these 160 steps (seeds 1, 6, 7, 9, 10: none)
+    a = np.array(list(Gn.generate(hm, steps // 16, styles)))
     stats = dict(Gn.last_run_stats)
-    assert stats["draws"] >= steps * 3 * 48 and stats["near_ties"] >= 0
+    assert a.shape[0] == steps and stats["draws"] >= steps * 3 * 48 and stats["near_ties"] >= 0
     sure = steps if stats["near_ties"] == 0 else stats["first_near_tie_step"]
-    assert sure >= 1, stats                                  # P(near tie in step 0) ~ 3e-3
-    np.random.seed(5)
-    g = Gn.generate(om, 1, styles)
+    # ~45 k draws at 2e-5 each: a near tie somewhere is likely (60 %), one before step 144 would leave the
+    # fully-generated window untested -- the seed is fixed, so this is a property of the build, not luck per run
+    assert sure >= 144, stats
+    np.random.seed(1)
+    g = Gn.generate(om, steps // 16, styles)
     b = np.array([next(g) for _ in range(sure)])
-    assert a[:sure, :, :, 0].sum() > 10                      # both draw branches are exercised
+    assert a[:sure, :, :, 0].sum() > 10 * sure                # both draw branches are exercised, in every step
+    assert (a[16:sure, :, :, 0].sum(axis=(1, 2)) > 0).all()   # no all-silent step: the window really fills up
     np.testing.assert_array_equal(a[:sure, :, :, :2], b[:, :, :, :2])       # play / replay decisions
     np.testing.assert_allclose(a[:sure, :, :, 2], b[:, :, :, 2], rtol=1e-3, atol=1e-5)   # volumes
 
@@ -449,14 +472,16 @@ def test_prepared_generation_step_equals_resident_step(gpu_device, dtype):
 def test_resident_graph_generation_1024_steps(gpu_device, monkeypatch):
     """BASELINE configs[3] at its stated length: 3 style vectors, 1024-step pieces, hipGraph-replayed
     device-resident step vs the step-wise API on the same weights: bit-equal rolls, same NumPy RNG
-    position, same near-tie census (reference generate.py:98-121)."""
+    position, same near-tie census (reference generate.py:98-121).  The head bias (-6) makes most steps silent at
+    T = 1, so the run spends most of its time in the heated branch of apply_temperature / end_time
+    (generate.py:60-71,81-91) and still plays notes."""
     from music_generator_amd import generate as Gn
     from music_generator_amd.dataset import compute_genre
     from music_generator_amd.model import build_models
     hm = build_models(seed=33)
     w = hm[0].get_weights()
     names = [n for n, _, _ in hm[0]._s.layout]
-    w[names.index("note_dense/bias")] = np.array([-0.5, 0.0], np.float32)
+    w[names.index("note_dense/bias")] = np.array([-6.0, 0.0], np.float32)
     hm[0].set_weights(w)
     styles = [compute_genre(i) for i in range(3)]
     bars = 1024 // 16
@@ -474,9 +499,12 @@ def test_resident_graph_generation_1024_steps(gpu_device, monkeypatch):
     np.testing.assert_array_equal(pos_res, pos_stp)
     assert st_res == st_stp and st_res["draws"] == 1024 * 3 * 48 + int(res[..., 0].sum())
     assert 0 < res[..., 0].sum() < res[..., 0].size
+    silent = res.reshape(1024, 3, -1).any(axis=2) == 0                      # [steps, pieces]
+    assert silent.any() and (~silent).any()                                # silence AND notes
+    assert st_res["silent_steps"] == int(silent.sum()) and st_res["max_temperature"] >= 1.3, st_res
 
 
-def test_full_size_properties(gpu_device, monkeypatch):
+def test_full_size_properties(gpu_device, djenv):
     """BASELINE shape (B64 x T128 x N128), where the CPU oracle is out of reach: size-independent
     properties instead.  (1) The fp32 gradient is the derivative of the fp32 loss: central
     difference along a random direction, dropout masks fixed by the seed.  (2) The two forward
@@ -490,11 +518,9 @@ def test_full_size_properties(gpu_device, monkeypatch):
     P0 = torch.from_numpy(init_params_numpy(cfg32, seed=1234)).to(gpu_device)
 
     def run(cfg, P, fuse_min_tiles=None):
-        if fuse_min_tiles is not None:
-            monkeypatch.setenv("DEEPJ_FUSE_XW_MIN_TILES", str(fuse_min_tiles))
-        else:
-            monkeypatch.delenv("DEEPJ_FUSE_XW_MIN_TILES", raising=False)
-        eng = Engine(cfg, B, T, device=gpu_device, input_dropout=0.2, dropout=0.5)
+        djenv.unset("DEEPJ_FUSE_XW_MIN_TILES")
+        eng = Engine(cfg, B, T, device=gpu_device, input_dropout=0.2, dropout=0.5,
+                     fuse_xw_min_tiles=fuse_min_tiles or 0)          # dj_config.fuse_xw_min_tiles
         G = torch.empty_like(P)
         out = torch.empty((B, T, N, 3), dtype=torch.float32, device=gpu_device)
         loss = eng.train_fwd_bwd(P, G, *batch, seed=seed, out=out)

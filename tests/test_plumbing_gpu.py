@@ -76,3 +76,26 @@ def test_generate_main_writes_decodable_files(gpu_device, tmp_path, monkeypatch,
             L = on.max() + 1
             assert got[:L, 36:84, 0][roll[:L, :, 0] == 0].sum() == 0      # nothing that was not sampled
             assert got[:L, 36:84, 0].sum() > 0
+
+
+def test_visualize_main_on_hip_models(gpu_device, tmp_path, monkeypatch, capsys):
+    """SURVEY f-4 on the product backend (reference visualize.py:11-43): build_or_load -> get_layer('style') applied to
+    the identity ON THE GPU (dj_style_embedding) -> the two TSV files the reference writes, with its names, its
+    (Genre, Artist) header and one row per style; the matrix equals kernel + bias of the style Dense layer."""
+    monkeypatch.chdir(tmp_path)
+    from music_generator_amd import constants as K, util, visualize
+    models = util.build_or_load()
+    w, b = models[0].get_layer('style').get_weights()
+    emb = visualize.main(models=models)
+    assert emb.shape == (K.NUM_STYLES, K.STYLE_UNITS) and emb.dtype == np.float32
+    np.testing.assert_allclose(emb, w + b, rtol=1e-6, atol=1e-7)
+    got = np.loadtxt(os.path.join(K.OUT_DIR, 'style_embedding_vec.tsv'), delimiter='\t')
+    np.testing.assert_allclose(got, emb, rtol=1e-6)
+    rows = [ln.rstrip('\n').split('\t') for ln in open(os.path.join(K.OUT_DIR, 'style_embedding_labels.tsv'))]
+    assert rows[0] == ['Genre', 'Artist'] and len(rows) == 1 + K.NUM_STYLES
+    assert rows[1] == ['baroque', 'data/baroque/bach'] and rows[-1][0] == 'romantic'
+    # non-identity input through the same device kernel
+    x = np.random.RandomState(0).rand(5, K.NUM_STYLES)
+    np.testing.assert_allclose(models[0].get_layer('style')(x), x.astype(np.float32) @ w + b, rtol=1e-5, atol=1e-6)
+    visualize.main()                                            # the CLI form: build_or_load inside
+    assert "Writing to out directory" in capsys.readouterr().out
