@@ -46,10 +46,10 @@ def _grad_report(ocfg, g_hip, g_ref):
     return worst, rows
 
 
-# bf16 mode, worst gradient tensor relative to its max: 2e-2 is ~2-4x what these cases show (DESIGN.md "Tolerances":
+# bf16 mode, worst gradient tensor relative to its max: 1.5e-2 is ~2.5-4x what these cases show (DESIGN.md "Tolerances":
 # 5e-3 on the production-kernel case; the small cases print theirs) -- a regression of the 8-bit gate stash or of a
 # bf16 operand path by a factor of a few fails here instead of hiding in an 8e-2 allowance
-BF16_GRAD_TOL = 2e-2
+BF16_GRAD_TOL = 1.5e-2
 
 CASES = [
     # name, cfg kwargs, B, T, input_dropout, dropout

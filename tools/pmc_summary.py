@@ -39,7 +39,7 @@ def category(name):
 
 
 def main():
-    fd, wd, prefix = sys.argv[1:4]
+    fd, wd, prefix = sys.argv[1:4]      # e.g. gpurun_out/pmc_NAME/fetch gpurun_out/pmc_NAME/write profiles/rNN_x
     fe, wr = load(fd, "FETCH_SIZE"), load(wd, "WRITE_SIZE")
     rows, cat = [], defaultdict(lambda: [0.0, 0])
     for k in sorted(fe, key=lambda k: -sum(fe[k])):
