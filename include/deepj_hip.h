@@ -180,7 +180,8 @@ int32_t dj_generate_step_prepared(const dj_config* cfg, const float* params, voi
  * operand dtype, 1 = row-major fp32, 2 = FRAGMENT-TILED C in the operand dtype (the layout
  * dj_lstm_fwd consumes: 32x32 block (rb, cb) stored as [64 lanes][16 accumulator registers];
  * element (s, c) of the block at ((rb*(N/32) + cb)*64 + 32*((s>>2)&1) + c)*16 + (s&3) + 4*(s>>3);
- * needs M % 32 == 0 and N % 32 == 0).  The x*W products of the Keras LSTM layers
+ * needs M % 32 == 0 and N % 32 == 0), 3 = like 0 but ACCUMULATED, C += A Bt^T + bias (bf16 only: the
+ * per-step recurrent product h_{t-1} U added to x_t W + b in place, scaled model).  The x*W products of the Keras LSTM layers
  * (model.py:84,122) and the BPTT input gradient dX = dZ * W^T. */
 int32_t dj_gemm_nt(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* Bt,
                    int32_t ldb, void* C, int32_t ldc, int32_t c_mode, const float* bias, void* stream);

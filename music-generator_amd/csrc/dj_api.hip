@@ -918,7 +918,7 @@ int32_t dj_profile_read(int32_t cat, double* total_ms, int64_t* scopes) {
 int32_t dj_gemm_nt(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int32_t lda, const void* Bt,
                    int32_t ldb, void* C, int32_t ldc, int32_t c_mode, const float* bias, void* stream) {
   if (dtype != DJ_F32 && dtype != DJ_BF16) return 1106;
-  if (c_mode < 0 || c_mode > 2) return 1005;
+  if (c_mode < 0 || c_mode > 3) return 1005;
   return dj_launch_gemm_nt(dtype, M, N, K, A, lda, Bt, ldb, C, ldc, c_mode, bias, (hipStream_t)stream);
 }
 int32_t dj_gemm_nt_tiled_a(int32_t dtype, int32_t M, int32_t N, int32_t K, const void* A, int64_t a_tile_stride,

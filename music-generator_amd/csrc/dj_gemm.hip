@@ -824,12 +824,23 @@ __device__ __forceinline__ void store4(float* p, float a, float b, float c, floa
   *(float4*)p = make_float4(a, b, c, d);
 }
 
+// the 4 values store4 would overwrite (accumulating epilogue, c_mode 3)
+__device__ __forceinline__ void load4(const bf16_t* p, float* x) {
+  const uint2 v = *(const uint2*)p;
+  x[0] = __uint_as_float(v.x << 16); x[1] = __uint_as_float(v.x & 0xFFFF0000u);
+  x[2] = __uint_as_float(v.y << 16); x[3] = __uint_as_float(v.y & 0xFFFF0000u);
+}
+__device__ __forceinline__ void load4(const float* p, float* x) {
+  const float4 v = *(const float4*)p;
+  x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+}
+
 template <typename TC, bool CFRAG>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int K, const bf16_t* __restrict__ A,
                                                                int lda, const bf16_t* __restrict__ Bt, int ldb,
                                                                TC* __restrict__ C, int ldc,
                                                                const float* __restrict__ bias, int ntn, int ntm,
-                                                               int xcd_map, int a_rbs, int c_rbs, int64_t a_cts) {
+                                                               int xcd_map, int a_rbs, int c_rbs, int64_t a_cts, int c_acc) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
@@ -970,11 +981,17 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
                 for (int e = 0; e < 4; ++e)
                   v[e] = acc[i][j][4 * g + e] + ((bias && col + e < N) ? bias[col + e] : 0.f);
                 if (col + 4 <= N) {
+                  if (c_acc) {                   // C += A Bt^T: this lane re-reads the 4 values it is about to write
+                    float o[4];
+                    load4(crow + col, o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += o[e];
+                  }
                   store4(crow + col, v[0], v[1], v[2], v[3]);
                 } else {
 #pragma unroll
                   for (int e = 0; e < 4; ++e)
-                    if (col + e < N) crow[col + e] = dj_from_f32<TC>(v[e]);
+                    if (col + e < N) crow[col + e] = dj_from_f32<TC>(v[e] + (c_acc ? dj_to_f32(crow[col + e]) : 0.f));
                 }
               }
             }
@@ -1004,7 +1021,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, in
                                                                 int lda, const bf16_t* __restrict__ Bt, int ldb,
                                                                 TC* __restrict__ C, int ldc,
                                                                 const float* __restrict__ bias, int ntn, int ntm,
-                                                                int a_rbs, int c_rbs, int64_t a_cts) {
+                                                                int a_rbs, int c_rbs, int64_t a_cts, int c_acc) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 2, wc = w & 3;
@@ -1186,11 +1203,17 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, in
                 for (int e = 0; e < 4; ++e)
                   v[e] = acc[i][j][4 * g + e] + ((bias && col + e < N) ? bias[col + e] : 0.f);
                 if (col + 4 <= N) {
+                  if (c_acc) {                   // C += A Bt^T: this lane re-reads the 4 values it is about to write
+                    float o[4];
+                    load4(crow + col, o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += o[e];
+                  }
                   store4(crow + col, v[0], v[1], v[2], v[3]);
                 } else {
 #pragma unroll
                   for (int e = 0; e < 4; ++e)
-                    if (col + e < N) crow[col + e] = dj_from_f32<TC>(v[e]);
+                    if (col + e < N) crow[col + e] = dj_from_f32<TC>(v[e] + (c_acc ? dj_to_f32(crow[col + e]) : 0.f));
                 }
               }
             }
@@ -1222,9 +1245,17 @@ int dj_launch_gemm_nt_ex(int dtype, int M, int N, int K, const void* A, int lda,
   if (a_rbs < 1 || c_rbs < 1 || (c_mode == 2 && c_rbs != 1)) return 1006;
   const int epl = dtype == DJ_F32 ? 4 : 8;
   if ((K % epl) || (lda % epl) || (ldb % epl)) return 1001;
-  const int c_is_f32 = c_mode == 1, c_frag = c_mode == 2;
+  // c_mode 3: row-major C in the operand dtype, ACCUMULATED (C += A Bt^T + bias); bf16 kernels only
+  const int c_is_f32 = c_mode == 1, c_frag = c_mode == 2, c_acc = c_mode == 3;
+  if (c_acc && dtype != DJ_BF16) return 1005;
   if (c_frag && ((M % 32) || (N % 32))) return 1004;
-  if (dtype == DJ_BF16 && N > 128) {
+  // wide outputs take 256 x 256 tiles -- unless that leaves compute units idle: fewer than 256 tiles (one per CU) and the
+  // 256 x 128 tiling has twice as many (the per-step BPTT product of the scaled model, [8192 x 4096] x [4096 x 1024]:
+  // 128 tiles of 256 x 256 ran on half of the chip)
+  const bool few_wide_tiles = (int64_t)((N + NT3_BN - 1) / NT3_BN) * ((M + NT3_BM - 1) / NT3_BM) < 256 &&
+                              (int64_t)((N + NT2_BN - 1) / NT2_BN) * ((M + NT2_BM - 1) / NT2_BM) >=
+                                  2 * (int64_t)((N + NT3_BN - 1) / NT3_BN) * ((M + NT3_BM - 1) / NT3_BM);
+  if (dtype == DJ_BF16 && N > 128 && !few_wide_tiles) {
     // wide outputs: 256 x 256 tiles; a remainder of at most 128 columns goes to the 256 x 128 kernel
     const int rem = N % NT3_BN;
     if (rem > 0 && rem <= 128 && N > NT3_BN && !c_frag) {
@@ -1254,13 +1285,13 @@ int dj_launch_gemm_nt_ex(int dtype, int M, int N, int K, const void* A, int lda,
     if (ldc % 4) return 1007;
     if (c_frag)
       hipLaunchKernelGGL((gemm_nt_bf16_wide_kernel<bf16_t, true>), dim3(grid3), dim3(512), smem, st, M, N, K,
-                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs, a_cts);
+                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs, a_cts, c_acc);
     else if (c_is_f32)
       hipLaunchKernelGGL((gemm_nt_bf16_wide_kernel<float, false>), dim3(grid3), dim3(512), smem, st, M, N, K,
-                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs, a_cts);
+                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs, a_cts, c_acc);
     else
       hipLaunchKernelGGL((gemm_nt_bf16_wide_kernel<bf16_t, false>), dim3(grid3), dim3(512), smem, st, M, N, K,
-                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs, a_cts);
+                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs, a_cts, c_acc);
     return (int)hipGetLastError();
   }
   if (dtype == DJ_BF16) {
@@ -1294,15 +1325,15 @@ int dj_launch_gemm_nt_ex(int dtype, int M, int N, int K, const void* A, int lda,
     if (c_frag)
       hipLaunchKernelGGL((gemm_nt_bf16_dma_kernel<bf16_t, true>), dim3(grid2), dim3(512), smem, st, M, N, K,
                          (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn2, ntm2, xcd_map,
-                         a_rbs, c_rbs, a_cts);
+                         a_rbs, c_rbs, a_cts, c_acc);
     else if (c_is_f32)
       hipLaunchKernelGGL((gemm_nt_bf16_dma_kernel<float, false>), dim3(grid2), dim3(512), smem, st, M, N, K,
                          (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn2, ntm2, xcd_map,
-                         a_rbs, c_rbs, a_cts);
+                         a_rbs, c_rbs, a_cts, c_acc);
     else
       hipLaunchKernelGGL((gemm_nt_bf16_dma_kernel<bf16_t, false>), dim3(grid2), dim3(512), smem, st, M, N, K,
                          (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn2, ntm2, xcd_map,
-                         a_rbs, c_rbs, a_cts);
+                         a_rbs, c_rbs, a_cts, c_acc);
     return (int)hipGetLastError();
   }
   // fp32 (parity mode): register-staged 128 x 128 kernel on v_mfma_f32_32x32x2_f32

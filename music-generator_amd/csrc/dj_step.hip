@@ -13,7 +13,9 @@
 // Buffers are row-major in the sequence-tiled row order of dj_common.h (dj_row); "all sequences
 // at step t" is addressed with the row-block stride of dj_launch_gemm_nt_rbs.  The cell state and
 // its gradient are carried between launches in fp32 (as the persistent kernels carry them in
-// registers); z, c, h stashes have the operand dtype.
+// registers); z, c, h stashes have the operand dtype.  bf16: the forward GEMM of a step ACCUMULATES
+// h_{t-1} U into the stash rows of z_t in its epilogue (no fp32 r buffer, the gate kernel reads z and
+// writes h, c only); the gate kernels move 16 bytes per access.
 #include "dj_common.h"
 #include "dj_kernels.h"
 
@@ -140,6 +142,119 @@ __global__ __launch_bounds__(256) void step_bwd_kernel(const T* __restrict__ Z, 
   for (int g = 0; g < 4; ++g) st4<T>(dZ + pr * 4 * H + g * H + u, dz[g]);
 }
 
+// ---- bf16 forms: one thread = 8 consecutive units of one sequence (16-byte accesses; the 4-unit kernels above moved
+// their bf16 operands 8 bytes at a time and ran at 2.5 TB/s in BPTT).
+__device__ __forceinline__ void ld8(const bf16_t* p, float* x) {
+  const uint4 v = *(const uint4*)p;
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    x[2 * i] = __uint_as_float(w[i] << 16);
+    x[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+  }
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float* x) {
+  bf16_t t[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) t[e] = dj_from_f32<bf16_t>(x[e]);
+  *(uint4*)p = *(const uint4*)t;
+}
+__device__ __forceinline__ void ld8f(const float* p, float* x) {
+  ld4<float>(p, x);
+  ld4<float>(p + 4, x + 4);
+}
+__device__ __forceinline__ void st8f(float* p, const float* x) {
+  st4<float>(p, x);
+  st4<float>(p + 4, x + 4);
+}
+
+// Forward cell of step t.  Z holds the FINAL pre-activations z_t = (x_t W + b) + h_{t-1} U: the recurrent product was
+// accumulated into the stash in place by the GEMM's epilogue (dj_launch_gemm_nt c_mode 3), so there is no fp32 r round
+// trip (2 x 16 KiB per row at H = 1024) and Z is not written again -- z is rounded to bf16 ONCE, and the value BPTT reads
+// back is the value the forward activations saw.
+template <bool SIGM>
+__global__ __launch_bounds__(256) void step_fwd8_kernel(const bf16_t* __restrict__ Z, float* __restrict__ cst,
+                                                        bf16_t* __restrict__ Hs, bf16_t* __restrict__ Cs, int H, int nrows,
+                                                        int steps, int t) {
+  const uint32_t q = (uint32_t)H >> 3;
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (uint32_t)nrows * q) return;
+  const uint32_t vq = idx / q;
+  const int v = (int)vq, u = (int)(idx - vq * q) * 8;
+  const int64_t pr = step_row(v, steps, t);
+  float z[4][8], c[8], hn[8];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) ld8(Z + pr * 4 * H + g * H + u, z[g]);
+  if (t > 0) {
+    ld8f(cst + (int64_t)v * H + u, c);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c[e] = 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float ig = dj_ract<SIGM>(z[0][e]), fg = dj_ract<SIGM>(z[1][e]), gg = dj_tanh(z[2][e]),
+                og = dj_ract<SIGM>(z[3][e]);
+    c[e] = fg * c[e] + ig * gg;
+    hn[e] = og * dj_tanh(c[e]);
+  }
+  st8f(cst + (int64_t)v * H + u, c);
+  st8(Hs + pr * H + u, hn);
+  if (Cs) st8(Cs + pr * H + u, c);
+}
+
+template <bool SIGM>
+__global__ __launch_bounds__(256) void step_bwd8_kernel(const bf16_t* __restrict__ Z, const bf16_t* __restrict__ Cs,
+                                                        const bf16_t* __restrict__ dH, const float* __restrict__ Rb,
+                                                        float* __restrict__ dcs, bf16_t* __restrict__ dZ, int H, int nrows,
+                                                        int steps, int t) {
+  const uint32_t q = (uint32_t)H >> 3;
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (uint32_t)nrows * q) return;
+  const uint32_t vq = idx / q;
+  const int v = (int)vq, u = (int)(idx - vq * q) * 8;
+  const int64_t pr = step_row(v, steps, t);
+  float z[4][8], ct[8], cp[8], dh[8], dcc[8];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) ld8(Z + pr * 4 * H + g * H + u, z[g]);
+  ld8(Cs + pr * H + u, ct);
+  ld8(dH + pr * H + u, dh);
+  if (t > 0) {
+    ld8(Cs + (pr - 32) * H + u, cp);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cp[e] = 0.f;
+  }
+  if (t < steps - 1) {
+    float r[8];
+    ld8f(Rb + (int64_t)v * H + u, r);
+    ld8f(dcs + (int64_t)v * H + u, dcc);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dh[e] += r[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dcc[e] = 0.f;
+  }
+  float dzi[8], dzf[8], dzg[8], dzo[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float zi = z[0][e], zf = z[1][e], zg = z[2][e], zo = z[3][e];
+    const float ig = dj_ract<SIGM>(zi), fg = dj_ract<SIGM>(zf), gg = dj_tanh(zg), og = dj_ract<SIGM>(zo);
+    const float tc = dj_tanh(ct[e]);
+    const float dc = dcc[e] + dh[e] * og * (1.f - tc * tc);
+    dzo[e] = dh[e] * tc * dj_ract_grad<SIGM>(zo, og);
+    dzi[e] = dc * gg * dj_ract_grad<SIGM>(zi, ig);
+    dzf[e] = dc * cp[e] * dj_ract_grad<SIGM>(zf, fg);
+    dzg[e] = dc * ig * (1.f - gg * gg);
+    dcc[e] = dc * fg;
+  }
+  st8f(dcs + (int64_t)v * H + u, dcc);
+  st8(dZ + pr * 4 * H + u, dzi);
+  st8(dZ + pr * 4 * H + H + u, dzf);
+  st8(dZ + pr * 4 * H + 2 * H + u, dzg);
+  st8(dZ + pr * 4 * H + 3 * H + u, dzo);
+}
+
 // out[c] += sum over rows of A[r, c]: 256 columns per workgroup column tile, rows split over gridDim.y
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, int64_t rows, int cols, int64_t rps,
@@ -159,6 +274,25 @@ int step_fwd_t(int H, int ntiles, int steps, void* Z, const void* Ut, void* Hs, 
   const int nrows = ntiles * 32;
   const int64_t n = (int64_t)nrows * (H >> 2);
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if constexpr (sizeof(T) == 2) {
+    // bf16: z_t += h_{t-1} U in the GEMM's epilogue, straight into the stash rows of step t (row-block-strided C view)
+    const int64_t n8 = (int64_t)nrows * (H >> 3);
+    const dim3 grid8((unsigned)((n8 + 255) / 256));
+    for (int t = 0; t < steps; ++t) {
+      if (t > 0) {
+        int rc = dj_launch_gemm_nt_rbs(dtype, nrows, 4 * H, H, (const T*)Hs + (int64_t)(t - 1) * 32 * H, H, steps, Ut, H,
+                                       (T*)Z + (int64_t)t * 32 * 4 * H, 4 * H, steps, 3, nullptr, st);
+        if (rc) return rc;
+      }
+      if (sigm)
+        hipLaunchKernelGGL(step_fwd8_kernel<true>, grid8, block, 0, st, (const bf16_t*)Z, cst, (bf16_t*)Hs, (bf16_t*)Cs, H,
+                           nrows, steps, t);
+      else
+        hipLaunchKernelGGL(step_fwd8_kernel<false>, grid8, block, 0, st, (const bf16_t*)Z, cst, (bf16_t*)Hs, (bf16_t*)Cs, H,
+                           nrows, steps, t);
+    }
+    return (int)hipGetLastError();
+  }
   for (int t = 0; t < steps; ++t) {
     if (t > 0) {
       // r_t = h_{t-1} U  (Bt = U^T [4H, H], k-contiguous)
@@ -188,7 +322,16 @@ int step_bwd_t(int H, int ntiles, int steps, const void* Z, const void* Uc, cons
                                      Uc, 4 * H, Rb, H, 1, 1, nullptr, st);
       if (rc) return rc;
     }
-    if (sigm)
+    if constexpr (sizeof(T) == 2) {
+      const int64_t n8 = (int64_t)nrows * (H >> 3);
+      const dim3 grid8((unsigned)((n8 + 255) / 256));
+      if (sigm)
+        hipLaunchKernelGGL(step_bwd8_kernel<true>, grid8, block, 0, st, (const bf16_t*)Z, (const bf16_t*)Cs,
+                           (const bf16_t*)dH, Rb, dcs, (bf16_t*)dZ, H, nrows, steps, t);
+      else
+        hipLaunchKernelGGL(step_bwd8_kernel<false>, grid8, block, 0, st, (const bf16_t*)Z, (const bf16_t*)Cs,
+                           (const bf16_t*)dH, Rb, dcs, (bf16_t*)dZ, H, nrows, steps, t);
+    } else if (sigm)
       hipLaunchKernelGGL((step_bwd_kernel<T, true>), grid, block, 0, st, (const T*)Z, (const T*)Cs, (const T*)dH, Rb, dcs,
                          (T*)dZ, H, nrows, steps, t);
     else

@@ -134,6 +134,17 @@ def test_gemm_nt(gpu_device, dtype, M, N, K):
         L.check(lib.dj_gemm_nt_tiled_a(DT[dtype], M, N, K, L.ptr(At), M * 256, L.ptr(Bd), K, L.ptr(Ct), ldc, 0,
                                        L.ptr(bias.to(gpu_device)), _st()), "gemm_nt tiled A")
         assert torch.equal(Ct, Cd)
+    if dtype == "bf16":
+        # c_mode 3: C += A Bt^T + bias in place (the per-step recurrent product of the scaled model's forward sweep)
+        C0 = _op(torch.randn(M, ldc, generator=g), dtype)
+        Ca = C0.clone().to(gpu_device)
+        L.check(lib.dj_gemm_nt(DT[dtype], M, N, K, L.ptr(Ad), K, L.ptr(Bd), K, L.ptr(Ca), ldc, 3,
+                               L.ptr(bias.to(gpu_device)), _st()), "gemm_nt acc")
+        torch.testing.assert_close(Ca.float().cpu()[:, :N], C0.float()[:, :N] + ref, rtol=rt, atol=at * K ** 0.5)
+        if ldc > N:
+            assert torch.equal(Ca.cpu()[:, N:], C0[:, N:])           # padding columns untouched
+    else:
+        assert lib.dj_gemm_nt(DT[dtype], M, N, K, L.ptr(Ad), K, L.ptr(Bd), K, L.ptr(Cd), ldc, 3, None, _st()) >= 1000
     if M % 32 == 0 and N % 32 == 0:
         Cf = torch.zeros(M * N, dtype=Ad.dtype, device=gpu_device)
         L.check(lib.dj_gemm_nt(DT[dtype], M, N, K, L.ptr(Ad), K, L.ptr(Bd), K, L.ptr(Cf), N, 2,
