@@ -116,6 +116,25 @@ def test_train_step_bf16_close(gpu_device, xw_mode, kw):
     assert worst < BF16_GRAD_TOL, sorted(rows, key=lambda r: -r[1])[:6]
 
 
+def test_train_step_bf16_scaled_widths(gpu_device):
+    """BASELINE configs[4]'s widths (3 x 1024 units per axis) in bf16 on a small shape: the per-step path with the
+    recurrent product accumulated into the stash by the GEMM epilogue (dj_gemm_nt c_mode 3 on a row-block-strided view),
+    the 16-byte gate kernels and the 256 x 128 tile choice, against the fp32 oracle at bf16 tolerance, dropout on."""
+    T, B, seed, pin, pdr = 6, 3, 77, 0.2, 0.5
+    kw = dict(time_axis_layers=3, note_axis_layers=3, time_axis_units=1024, note_axis_units=1024, num_notes=24)
+    ocfg, dcfg = _cfgs(time_steps=T, dtype="bf16", **kw)
+    params = O.init_params(ocfg, seed=11)
+    flat = O.flatten_params(ocfg, params)
+    batch = O.synthetic_batch(ocfg, B, seed=3, T=T)
+    loss_ref, out_ref, g_ref = O.loss_and_grads(ocfg, params, batch, O.make_masks(ocfg, B, seed, pin, pdr, T=T))
+    loss, out, g, _ = _run_train(dcfg, B, T, flat, batch, seed, pin, pdr, gpu_device)
+    np.testing.assert_allclose(out, out_ref, rtol=3e-2, atol=3e-3)
+    assert abs(loss - loss_ref) <= 2e-2 * max(1.0, abs(loss_ref))
+    worst, rows = _grad_report(ocfg, g, g_ref)
+    print("bf16 3x1024 step vs oracle: |dloss| %.2e, worst grad tensor %.2e" % (abs(loss - loss_ref), worst))
+    assert worst < BF16_GRAD_TOL, sorted(rows, key=lambda r: -r[1])[:6]
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_train_step_production_kernels_vs_oracle(gpu_device, djenv, dtype):
     """The kernel selection of the bench shape, as ONE forward + BPTT step against the oracle, dropout on:
