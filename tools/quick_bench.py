@@ -30,7 +30,7 @@ def run(dtype, B=64, T=128, N=128, steps=3, pin=0.2, pdr=0.5, micro=1, **kw):
         losses.append(loss.clone())
     torch.cuda.synchronize(); dt = (time.time() - t0) / steps
     print(f"[{dtype}] B={B}x{micro} T={T} N={N}: {dt*1e3:.2f} ms/step, {micro*B*T*N/dt/1e6:.2f} M note-steps/s, "
-          f"losses {[round(float(l), 5) for l in losses]}", flush=True)
+          f"losses {[round(float(l[0]), 5) for l in losses]}", flush=True)
     return eng
 
 if __name__ == "__main__":
