@@ -68,6 +68,7 @@ typedef struct dj_config {
 int32_t dj_env_reload(void);
 
 int32_t dj_abi_version(void);
+int32_t dj_config_size(void);   /* sizeof(dj_config) of the library: a binding checks its own struct against it */
 
 /* Flat fp32 parameter vector in the reference's layer-creation order with Keras tensor
  * layouts (model.py:128-169).  dj_param_info enumerates the tensors:

@@ -34,6 +34,7 @@ _lib = None
 _P = C.c_void_p
 _SIGS = {
     "dj_abi_version": (C.c_int32, []),
+    "dj_config_size": (C.c_int32, []),
     "dj_env_reload": (C.c_int32, []),
     "dj_style_embedding": (C.c_int32, [C.POINTER(DjConfig), _P, _P, C.c_int32, _P, _P]),
     "dj_workspace_cluster_fault_words": (C.c_int32, [C.POINTER(DjConfig), _P, C.c_int64, C.POINTER(C.c_int32)]),
@@ -113,6 +114,8 @@ def load():
         fn.argtypes = args
     if lib.dj_abi_version() != 2:
         raise DeepJError("libdeepj_hip.so ABI version mismatch")
+    if lib.dj_config_size() != C.sizeof(DjConfig):
+        raise DeepJError("dj_config layout mismatch: library %d bytes, binding %d" % (lib.dj_config_size(), C.sizeof(DjConfig)))
     _lib = lib
     return lib
 

@@ -547,6 +547,7 @@ int32_t dj_workspace_faults_async(const dj_config* cfg, void* ws, int64_t ws_byt
 }
 
 int32_t dj_abi_version(void) { return DJ_ABI_VERSION; }
+int32_t dj_config_size(void) { return (int32_t)sizeof(dj_config); }
 
 int64_t dj_param_count(const dj_config* cfg) {
   Plan p;
