@@ -155,3 +155,30 @@ def test_temperature_path_hip_models_vs_oracle_models(gpu_device):
     np.testing.assert_array_equal(a[:sure, :, :, :2], b[:, :, :, :2])
     np.testing.assert_allclose(a[:sure, :, :, 2], b[:, :, :, 2], rtol=1e-3, atol=1e-5)
     assert st_o["max_temperature"] == want_t[:sure].max()
+
+
+@pytest.mark.parametrize("G", [1, 8])
+def test_fused_generation_piece_counts(gpu_device, monkeypatch, G):
+    """generate() with one piece (generate.py --styles i j: a single mean style vector, generate.py:146-148) and with
+    eight (the most the single-workgroup sampler takes): the resident hipGraph path against the reference-shaped loop
+    over predict() on the same HIP weights -- same rolls in every step the near-tie census certifies, same RNG position."""
+    from music_generator_amd.model import build_models
+    from music_generator_amd.util import one_hot
+    hm = build_models(seed=12)
+    _set_head_bias(hm, 0.4)
+    rs = np.random.RandomState(G)
+    styles = [np.mean([one_hot(int(i), 23) for i in rs.randint(0, 23, size=2)], axis=0) for _ in range(G)]
+    steps = 8
+    monkeypatch.delenv("DEEPJ_GENERATE_STEPWISE", raising=False)
+    monkeypatch.delenv("DEEPJ_GENERATE_SLOW", raising=False)
+    res, st, _, _ = _run(hm, 1, styles, seed=3)
+    assert res.shape == (16, G, 48, 3) and res[..., 0].sum() > 10 * G
+    sure = 16 if st["near_ties"] == 0 else st["first_near_tie_step"]
+    sure = min(sure, steps)
+    assert sure >= 4, st
+    _, _, pos_res, _ = _run(hm, 1, styles, seed=3, steps=sure)
+    monkeypatch.setenv("DEEPJ_GENERATE_SLOW", "1")
+    slow, _, pos_slow, _ = _run(hm, 1, styles, seed=3, steps=sure)
+    np.testing.assert_array_equal(res[:sure, :, :, :2], slow[:, :, :, :2])
+    np.testing.assert_allclose(res[:sure, :, :, 2], slow[:, :, :, 2], rtol=1e-3, atol=1e-5)
+    assert pos_res == pos_slow
