@@ -203,56 +203,92 @@ __global__ __launch_bounds__(256) void step_fwd8_kernel(const bf16_t* __restrict
   if (Cs) st8(Cs + pr * H + u, c);
 }
 
+// BPTT cell of step t.  One workgroup = 32 sequences x 64 units (thread = 8 units of one sequence: a row of the block is
+// one 128-byte line per gate), so the bias gradient can be summed over the block's rows through LDS and added to a
+// per-row-block partial buffer dbpart [nrows / 32][4H] -- owned column by column by exactly one thread per step, no
+// atomics -- instead of a second pass over all of dZ at the end of the sweep (17 GB per layer pass at the scaled shape).
 template <bool SIGM>
 __global__ __launch_bounds__(256) void step_bwd8_kernel(const bf16_t* __restrict__ Z, const bf16_t* __restrict__ Cs,
                                                         const bf16_t* __restrict__ dH, const float* __restrict__ Rb,
-                                                        float* __restrict__ dcs, bf16_t* __restrict__ dZ, int H, int nrows,
-                                                        int steps, int t) {
-  const uint32_t q = (uint32_t)H >> 3;
-  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (uint32_t)nrows * q) return;
-  const uint32_t vq = idx / q;
-  const int v = (int)vq, u = (int)(idx - vq * q) * 8;
-  const int64_t pr = step_row(v, steps, t);
-  float z[4][8], ct[8], cp[8], dh[8], dcc[8];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) ld8(Z + pr * 4 * H + g * H + u, z[g]);
-  ld8(Cs + pr * H + u, ct);
-  ld8(dH + pr * H + u, dh);
-  if (t > 0) {
-    ld8(Cs + (pr - 32) * H + u, cp);
-  } else {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) cp[e] = 0.f;
-  }
-  if (t < steps - 1) {
-    float r[8];
-    ld8f(Rb + (int64_t)v * H + u, r);
-    ld8f(dcs + (int64_t)v * H + u, dcc);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dh[e] += r[e];
-  } else {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dcc[e] = 0.f;
-  }
+                                                        float* __restrict__ dcs, bf16_t* __restrict__ dZ,
+                                                        float* __restrict__ dbpart, int H, int nrows, int steps, int t) {
+  __shared__ float red[32][4 * 64 + 1];
+  const int tid = threadIdx.x, r = tid >> 3, cg = tid & 7;
+  const int v = blockIdx.y * 32 + r, u = blockIdx.x * 64 + cg * 8;
+  const bool live = v < nrows && u < H;
   float dzi[8], dzf[8], dzg[8], dzo[8];
+  if (live) {
+    const int64_t pr = step_row(v, steps, t);
+    float z[4][8], ct[8], cp[8], dh[8], dcc[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ld8(Z + pr * 4 * H + g * H + u, z[g]);
+    ld8(Cs + pr * H + u, ct);
+    ld8(dH + pr * H + u, dh);
+    if (t > 0) {
+      ld8(Cs + (pr - 32) * H + u, cp);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cp[e] = 0.f;
+    }
+    if (t < steps - 1) {
+      float rr[8];
+      ld8f(Rb + (int64_t)v * H + u, rr);
+      ld8f(dcs + (int64_t)v * H + u, dcc);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dh[e] += rr[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dcc[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float zi = z[0][e], zf = z[1][e], zg = z[2][e], zo = z[3][e];
+      const float ig = dj_ract<SIGM>(zi), fg = dj_ract<SIGM>(zf), gg = dj_tanh(zg), og = dj_ract<SIGM>(zo);
+      const float tc = dj_tanh(ct[e]);
+      const float dc = dcc[e] + dh[e] * og * (1.f - tc * tc);
+      dzo[e] = dh[e] * tc * dj_ract_grad<SIGM>(zo, og);
+      dzi[e] = dc * gg * dj_ract_grad<SIGM>(zi, ig);
+      dzf[e] = dc * cp[e] * dj_ract_grad<SIGM>(zf, fg);
+      dzg[e] = dc * ig * (1.f - gg * gg);
+      dcc[e] = dc * fg;
+    }
+    st8f(dcs + (int64_t)v * H + u, dcc);
+    st8(dZ + pr * 4 * H + u, dzi);
+    st8(dZ + pr * 4 * H + H + u, dzf);
+    st8(dZ + pr * 4 * H + 2 * H + u, dzg);
+    st8(dZ + pr * 4 * H + 3 * H + u, dzo);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dzi[e] = dzf[e] = dzg[e] = dzo[e] = 0.f;
+  }
+  if (!dbpart) return;                       // uniform
+  // column sums over the block's 32 rows (the values as stored: rounded to bf16 like the dZ a column-sum pass would read)
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const float zi = z[0][e], zf = z[1][e], zg = z[2][e], zo = z[3][e];
-    const float ig = dj_ract<SIGM>(zi), fg = dj_ract<SIGM>(zf), gg = dj_tanh(zg), og = dj_ract<SIGM>(zo);
-    const float tc = dj_tanh(ct[e]);
-    const float dc = dcc[e] + dh[e] * og * (1.f - tc * tc);
-    dzo[e] = dh[e] * tc * dj_ract_grad<SIGM>(zo, og);
-    dzi[e] = dc * gg * dj_ract_grad<SIGM>(zi, ig);
-    dzf[e] = dc * cp[e] * dj_ract_grad<SIGM>(zf, fg);
-    dzg[e] = dc * ig * (1.f - gg * gg);
-    dcc[e] = dc * fg;
+    red[r][0 * 64 + cg * 8 + e] = dj_to_f32(dj_from_f32<bf16_t>(dzi[e]));
+    red[r][1 * 64 + cg * 8 + e] = dj_to_f32(dj_from_f32<bf16_t>(dzf[e]));
+    red[r][2 * 64 + cg * 8 + e] = dj_to_f32(dj_from_f32<bf16_t>(dzg[e]));
+    red[r][3 * 64 + cg * 8 + e] = dj_to_f32(dj_from_f32<bf16_t>(dzo[e]));
   }
-  st8f(dcs + (int64_t)v * H + u, dcc);
-  st8(dZ + pr * 4 * H + u, dzi);
-  st8(dZ + pr * 4 * H + H + u, dzf);
-  st8(dZ + pr * 4 * H + 2 * H + u, dzg);
-  st8(dZ + pr * 4 * H + 3 * H + u, dzo);
+  __syncthreads();
+  const int g = tid >> 6, uu = tid & 63;     // this thread's column of the block: gate g, unit blockIdx.x * 64 + uu
+  if (blockIdx.x * 64 + uu < H) {
+    float sum = 0.f;
+#pragma unroll 8
+    for (int rr = 0; rr < 32; ++rr) sum += red[rr][g * 64 + uu];
+    float* dst = dbpart + (int64_t)blockIdx.y * 4 * H + g * H + blockIdx.x * 64 + uu;
+    *dst += sum;
+  }
+}
+
+// dbias[c] += sum over row blocks of dbpart[rb][c]
+__global__ __launch_bounds__(256) void dbpart_fold_kernel(const float* __restrict__ dbpart, int nrb, int cols,
+                                                          float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int rb = 0; rb < nrb; ++rb) s += dbpart[(int64_t)rb * cols + c];
+  out[c] += s;
 }
 
 // out[c] += sum over rows of A[r, c]: 256 columns per workgroup column tile, rows split over gridDim.y
@@ -315,6 +351,14 @@ int step_bwd_t(int H, int ntiles, int steps, const void* Z, const void* Uc, cons
   const int nrows = ntiles * 32;
   const int64_t n = (int64_t)nrows * (H >> 2);
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  // bf16: the bias gradient is summed inside the gate kernel into per-row-block partials (the part of the fp32 scratch
+  // between the r / carry areas that BPTT does not use: (nrows / 32) * 4H floats behind Rb's nrows * H)
+  float* dbpart = nullptr;
+  if (sizeof(T) == 2 && dbias) {
+    dbpart = Rb + (int64_t)nrows * H;
+    hipError_t e = hipMemsetAsync(dbpart, 0, (size_t)(nrows / 32) * 4 * H * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  }
   for (int t = steps - 1; t >= 0; --t) {
     if (t < steps - 1) {
       // recurrent part of dh_t = dz_{t+1} U^T  (Bt = U [H, 4H], k-contiguous)
@@ -323,14 +367,13 @@ int step_bwd_t(int H, int ntiles, int steps, const void* Z, const void* Uc, cons
       if (rc) return rc;
     }
     if constexpr (sizeof(T) == 2) {
-      const int64_t n8 = (int64_t)nrows * (H >> 3);
-      const dim3 grid8((unsigned)((n8 + 255) / 256));
+      const dim3 grid8((unsigned)((H + 63) / 64), (unsigned)((nrows + 31) / 32));
       if (sigm)
         hipLaunchKernelGGL(step_bwd8_kernel<true>, grid8, block, 0, st, (const bf16_t*)Z, (const bf16_t*)Cs,
-                           (const bf16_t*)dH, Rb, dcs, (bf16_t*)dZ, H, nrows, steps, t);
+                           (const bf16_t*)dH, Rb, dcs, (bf16_t*)dZ, dbpart, H, nrows, steps, t);
       else
         hipLaunchKernelGGL(step_bwd8_kernel<false>, grid8, block, 0, st, (const bf16_t*)Z, (const bf16_t*)Cs,
-                           (const bf16_t*)dH, Rb, dcs, (bf16_t*)dZ, H, nrows, steps, t);
+                           (const bf16_t*)dH, Rb, dcs, (bf16_t*)dZ, dbpart, H, nrows, steps, t);
     } else if (sigm)
       hipLaunchKernelGGL((step_bwd_kernel<T, true>), grid, block, 0, st, (const T*)Z, (const T*)Cs, (const T*)dH, Rb, dcs,
                          (T*)dZ, H, nrows, steps, t);
@@ -338,7 +381,9 @@ int step_bwd_t(int H, int ntiles, int steps, const void* Z, const void* Uc, cons
       hipLaunchKernelGGL((step_bwd_kernel<T, false>), grid, block, 0, st, (const T*)Z, (const T*)Cs, (const T*)dH, Rb,
                          dcs, (T*)dZ, H, nrows, steps, t);
   }
-  if (dbias) {
+  if (dbpart) {
+    hipLaunchKernelGGL(dbpart_fold_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, st, dbpart, nrows / 32, 4 * H, dbias);
+  } else if (dbias) {
     const int64_t rows = (int64_t)nrows * steps;
     int splits = (int)((rows + 511) / 512);
     if (splits > 1024) splits = 1024;

@@ -119,8 +119,9 @@ def test_train_step_bf16_close(gpu_device, xw_mode, kw):
 def test_train_step_bf16_scaled_widths(gpu_device):
     """BASELINE configs[4]'s widths (3 x 1024 units per axis) in bf16 on a small shape: the per-step path with the
     recurrent product accumulated into the stash by the GEMM epilogue (dj_gemm_nt c_mode 3 on a row-block-strided view),
-    the 16-byte gate kernels and the 256 x 128 tile choice, against the fp32 oracle at bf16 tolerance, dropout on."""
-    T, B, seed, pin, pdr = 6, 3, 77, 0.2, 0.5
+    the 16-byte gate kernels with the bias gradient summed in-kernel and the 256 x 128 tile choice, against the fp32 oracle
+    at bf16 tolerance, dropout on."""
+    T, B, seed, pin, pdr = 6, 6, 77, 0.2, 0.5
     kw = dict(time_axis_layers=3, note_axis_layers=3, time_axis_units=1024, note_axis_units=1024, num_notes=24)
     ocfg, dcfg = _cfgs(time_steps=T, dtype="bf16", **kw)
     params = O.init_params(ocfg, seed=11)
