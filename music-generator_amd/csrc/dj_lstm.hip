@@ -620,7 +620,7 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
 // Exchange state lives in a CALLER-OWNED scratch (dj_lstm_cluster_scratch_bytes; one per workspace, i.e. per
 // engine / stream -- never shared between concurrent sweeps):
 //     [0, 16 KiB)     per cluster two 128-byte lines: line 0 = the step counter, line 1 = the members' XCC ids
-//                     (zeroed by a memset node in front of every launch)
+//                     (zeroed by cl_reset_kernel in front of every launch)
 //     [16 KiB, +128)  fault words: [0] expired waits, [1] clusters whose members sat on different XCDs (sticky
 //                     until dj_lstm_cluster_faults reads them)
 //     [.., +8 MiB)    hx: [tile][step parity][k-chunk][lane] x 16 bytes
@@ -1881,8 +1881,7 @@ int cluster_cus() {
 // line), so that the host-side handling (fallback in fit, errors in predict / generation) can be exercised on hardware.
 // Counters and XCC ids of every cluster start at zero in every launch.  A KERNEL, not hipMemsetAsync: under hipGraph
 // replay a memset node followed by the cluster kernel was observed to take effect AFTER the kernel's round-0 arrivals
-// in some replay histories (ROCm 7.2; every wait of that launch then expires, tools/scratch history in DESIGN.md
-// section 8) -- kernel -> kernel edges do not have that problem.
+// in some replay histories (ROCm 7.2; every wait of that launch then expires: DESIGN.md section 8, round 3) -- kernel -> kernel edges do not have that problem.
 __global__ void cl_reset_kernel(uint4* p) { p[blockIdx.x * 256 + threadIdx.x] = make_uint4(0, 0, 0, 0); }
 int cluster_reset(void* scratch, hipStream_t st) {
   static_assert(CL_OFF_FAULT % (256 * 16) == 0, "reset grid");
@@ -1913,7 +1912,7 @@ int launch_fwd_cluster(int ntiles, int steps, const void* X, int DP, int NKX, co
   if (ntiles < 1 || ntiles > 256 || NKX * R::KC > 256 || DP > 256 || DP % 8 || !scratch || ((uintptr_t)scratch & 127))
     return 1016;
   const size_t smem = (size_t)(4 * NKX * 64 + 4 * R::NKC * 64) * 16 + (size_t)8 * 4096;
-  // counters and XCC ids of every cluster start at zero in every launch (a memset node under graph capture)
+  // counters and XCC ids of every cluster start at zero in every launch (cl_reset_kernel: a kernel node under graph capture)
   if (int rc = cluster_reset(scratch, st)) return rc;
   if (int rc = cluster_fault_hook(scratch, st)) return rc;
   return sigm ? launch_fwd_cluster_s<true>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st)
