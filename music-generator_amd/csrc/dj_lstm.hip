@@ -1877,17 +1877,18 @@ int cluster_cus() {
   }
   return cus[dev];
 }
-// Test hook: with DEEPJ_DEBUG_CLUSTER_FAULT set, the next launches fail their placement check (word 2 of the fault
-// line), so that the host-side handling (fallback in fit, errors in predict / generation) can be exercised on hardware.
 // Counters and XCC ids of every cluster start at zero in every launch.  A KERNEL, not hipMemsetAsync: under hipGraph
 // replay a memset node followed by the cluster kernel was observed to take effect AFTER the kernel's round-0 arrivals
-// in some replay histories (ROCm 7.2; every wait of that launch then expires: DESIGN.md section 8, round 3) -- kernel -> kernel edges do not have that problem.
+// in some replay histories (ROCm 7.2; every wait of that launch then expires: DESIGN.md section 8, round 3) -- kernel ->
+// kernel edges do not have that problem.
 __global__ void cl_reset_kernel(uint4* p) { p[blockIdx.x * 256 + threadIdx.x] = make_uint4(0, 0, 0, 0); }
 int cluster_reset(void* scratch, hipStream_t st) {
   static_assert(CL_OFF_FAULT % (256 * 16) == 0, "reset grid");
   hipLaunchKernelGGL(cl_reset_kernel, dim3(CL_OFF_FAULT / (256 * 16)), dim3(256), 0, st, (uint4*)scratch);
   return (int)hipGetLastError();
 }
+// Test hook: with DEEPJ_DEBUG_CLUSTER_FAULT set, the next launches fail their placement check (word 2 of the fault
+// line), so that the host-side handling (fallback in fit, errors in predict / generation) can be exercised on hardware.
 int cluster_fault_hook(void* scratch, hipStream_t st) {
   static void* armed[16] = {};                        // scratches whose hook word is set (a handful of engines at most)
   const bool want = (dj_env_flags() & DJ_KF_DEBUG_CLUSTER_FAULT) != 0;
