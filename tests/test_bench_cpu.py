@@ -124,3 +124,27 @@ def test_bench_self_launch_through_the_real_launcher_fails_loudly_without_gpus()
     assert r.returncode != 0
     assert "bench.py needs a HIP device" in (r.stderr + r.stdout)
     assert '"metric"' not in r.stdout
+
+
+def test_pmc_traffic_from_rocprof_passes(tmp_path):
+    """bench.py --pmc-dir: HBM bytes per launch from the two rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
+    counter_collection CSVs anywhere under the directory): read = 2 x FETCH_SIZE KB (gfx950 tallies 128-byte requests at
+    64 bytes, MI355X_MICROARCH.md), write = WRITE_SIZE KB, averaged per launch and summed per bench category."""
+    import bench
+    bwd = "_ZN12_GLOBAL__N_115lstm_bwd_kernelIDF16bLi256ELb0ELi0EEEvPKNS_6StashTIT_E4typeE"
+    note = "_ZN12_GLOBAL__N_115lstm_bwd_kernelIDF16bLi128ELb0ELi1EEEvPKNS_6StashTIT_E4typeE"
+    other = "void at::native::vectorized_elementwise_kernel"
+    hdr = "Correlation_Id,Kernel_Name,Counter_Name,Counter_Value\n"
+    f = tmp_path / "fetch" / "runc"
+    w = tmp_path / "write" / "runc"
+    f.mkdir(parents=True); w.mkdir(parents=True)
+    (f / "1_counter_collection.csv").write_text(hdr + "".join(
+        '%d,"%s",FETCH_SIZE,%f\n' % (i, k, v) for i, (k, v) in enumerate([(bwd, 1000.0), (bwd, 1200.0), (note, 500.0), (other, 9.0)])))
+    (w / "2_counter_collection.csv").write_text(hdr + "".join(
+        '%d,"%s",WRITE_SIZE,%f\n' % (i, k, v) for i, (k, v) in enumerate([(bwd, 2000.0), (bwd, 2000.0), (note, 100.0)])))
+    got = bench.pmc_traffic_from_dir(str(tmp_path), bench.pmc_category)
+    assert set(got) == {"lstm_bwd_time", "lstm_bwd_note"}
+    assert got["lstm_bwd_time"] == 2 * 1024 * 1100.0 + 1024 * 2000.0          # per launch: 2 x mean fetch + mean write
+    assert got["lstm_bwd_note"] == 2 * 1024 * 500.0 + 1024 * 100.0
+    assert bench.pmc_category("lstm_fwd_cluster_kernelILb0ELi16EE") == "lstm_fwd_time"
+    assert bench.pmc_category("lstm_wgrad_bf16_kernel") == "gemm_dw" and bench.pmc_category(other) is None
