@@ -10,6 +10,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -115,3 +116,65 @@ def test_rccl_world1_drives_bench_step_and_model_step(gpu_device, tmp_path):
     assert o["model_faults"] == [0, 0, 0, 0]
     assert o["model_param_maxdiff"] < 3 * 2e-3 and o["model_update_rel_l2"] < 5e-3, o
     assert all(abs(a - b) < 1e-4 * abs(b) for a, b in zip(*o["model_loss"])), o["model_loss"]
+
+
+WORKER2 = r'''
+import json, os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from music_generator_amd.data import synthetic_batch
+from music_generator_amd.engine import DeepJConfig
+from music_generator_amd.model import build_models
+from music_generator_amd._lib import KF_NO_CLUSTER
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", world_size=2, rank=int(sys.argv[1]))
+rank = dist.get_rank()
+try:
+    t = torch.ones(4, device="cuda:0"); dist.all_reduce(t); assert float(t[0]) == 2.0
+except Exception as e:
+    print("RESULT " + json.dumps({{"skip": "gloo cannot all-reduce device tensors here: %s" % str(e)[:120]}}), flush=True)
+    sys.exit(0)
+B, T, N = 128, 16, 128                                  # global batch 128 -> 64 per rank: 256 time-axis tiles per rank, a full-chip cluster grid each
+cfg = DeepJConfig(num_notes=N, time_steps=T, dtype="bf16")
+a = synthetic_batch(N, T, B, seed=0)
+x, y = [a[0], a[1], a[2], a[3]], [a[4]]
+m = build_models(time_steps=T, config=cfg, seed=5)[0]
+np.random.seed(0)
+hist = m.fit(x, y, epochs=3, batch_size=B, verbose=0, shuffle=False)
+w = np.concatenate([v.ravel() for v in m.get_weights()])
+print("RESULT " + json.dumps({{"rank": rank, "loss": hist.history["loss"], "digest": float(np.dot(w, np.cos(np.arange(w.size) * 0.37))),
+                              "wnorm": float(np.linalg.norm(w)), "fell_back": bool(m._s.kernel_flags & KF_NO_CLUSTER)}}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_share_one_gpu(gpu_device, tmp_path):
+    """Data parallel with TWO ranks on the ONE GPU of the test box (gloo carries the collective; RCCL refuses two ranks on
+    one device): both processes run the real bf16 training step -- cluster kernels included -- at the same time on the
+    same device, which is exactly the situation the cluster kernels' run-time checks exist for (another process's
+    kernels keep members from being co-resident).  Whatever happens -- clean steps, or expired waits counted, summed over
+    the ranks in the step's one all-reduce and answered by both ranks falling back to the per-tile kernel together --
+    the run must end with a finite, falling loss and IDENTICAL weights on both ranks."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / "worker2.py"
+    script.write_text(WORKER2.format(root=ROOT, port=port))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DEEPJ_DIST_WORLD1"):
+        env.pop(k, None)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, (so[-1000:], se[-3000:])
+    res = [json.loads([ln for ln in so.splitlines() if ln.startswith("RESULT ")][-1][7:]) for so, _ in outs]
+    if "skip" in res[0]:
+        pytest.skip(res[0]["skip"])
+    print("two ranks on one GPU:", res)
+    a, b = sorted(res, key=lambda r: r["rank"])
+    assert a["digest"] == b["digest"] and a["wnorm"] == b["wnorm"]          # replicas stay bit-identical
+    assert a["loss"] == b["loss"] and all(np.isfinite(a["loss"])) and a["loss"][-1] < a["loss"][0]
+    assert a["fell_back"] == b["fell_back"]                                 # the census travels in the all-reduce
