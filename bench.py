@@ -437,12 +437,20 @@ def main():
         raise SystemExit(self_launch(sys.argv[1:], args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the DeepJ engine has no CPU path")
+    # rehearsal switches (tests/test_dist_gpu.py runs the N = 2 flow on a one-GPU box): every rank on cuda:0, gloo
+    # instead of RCCL (which refuses two ranks on one device).  Never set by the driver; the numbers of such a run mean nothing.
+    if os.environ.get("DEEPJ_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("DEEPJ_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if args.config == "scaled":
         return scaled_bench(args, dev, rank, world, dist)
@@ -555,7 +563,9 @@ def main():
             "config": {"workload": f"biaxial-LSTM train step, batch {B}/GPU x {T} steps x {N} notes "
                                    f"(BASELINE configs[1]), 2x256 time-axis + 2x128 note-axis LSTM, dropout {pin}/{pdr}, "
                                    f"Nadam; random-init weights",
-                       "global_batch": B * world, "seq_len": T, "num_notes": N, "parallelism": f"dp{world}"},
+                       "global_batch": B * world, "seq_len": T, "num_notes": N, "parallelism": f"dp{world}",
+                       **({"rehearsal": f"backend {backend}, all ranks on one device: not a measurement"}
+                          if (backend != "nccl" or os.environ.get("DEEPJ_BENCH_ONE_DEVICE") == "1") else {})},
             "model_tflops_per_s": round(flops_step * world * args.steps / elapsed / 1e12, 2),
             "final_loss": round(final_loss, 5),
             "roofline": roof, "kernel_ms_per_step": kernels, "kernel_rates": roof_all,

@@ -178,3 +178,24 @@ def test_two_ranks_share_one_gpu(gpu_device, tmp_path):
     assert a["digest"] == b["digest"] and a["wnorm"] == b["wnorm"]          # replicas stay bit-identical
     assert a["loss"] == b["loss"] and all(np.isfinite(a["loss"])) and a["loss"][-1] < a["loss"][0]
     assert a["fell_back"] == b["fell_back"]                                 # the census travels in the all-reduce
+
+
+def test_bench_two_rank_flow_on_one_gpu(gpu_device):
+    """`python bench.py --gpus 2` exactly as the driver types it, on the one-GPU test box: bench.py starts its own two ranks
+    (torch.distributed.run as a child), both rehearse on cuda:0 with gloo as the collective backend
+    (DEEPJ_BENCH_ONE_DEVICE / DEEPJ_BENCH_BACKEND: RCCL refuses two ranks on one device), warm up, barrier, time K steps of
+    make_step with its all-reduce, take the MAX over ranks, and rank 0 prints ONE JSON line for the whole job.  The flow of
+    the N > 1 bench on real kernels; the number itself is labelled a rehearsal."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DEEPJ_BENCH_ONE_DEVICE="1", DEEPJ_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DEEPJ_BENCH_LAUNCHER"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2" and "rehearsal" in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 2 * 64 * 128 * 128 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-3 * d["value"]
+    assert np.isfinite(d["final_loss"]) and d["cpu_baseline"] is None and "scaled" not in d
