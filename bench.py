@@ -8,11 +8,18 @@ One "step" = one full training step (teacher-forced forward + BPTT + Nadam, drop
 plus the RCCL gradient all-reduce when N > 1) over one synthetic batch of
 B=64 x T=128 x N=128 per GPU (BASELINE.json configs[1]; weak scaling: global batch
 64*N).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON
-line.  `roofline` is measured live with HIP events recorded by the library around
-every launch (dj_profile_*); `cpu_baseline` times the CPU oracle on a bounded sample
-(1 warm-up + 3 timed steps on 8 of the 64 sequences); `fp32_parity_mode` is the same step in
-the fp32 mode the 1e-3 parity gate runs in; `generation` is BASELINE configs[3] (3 pieces,
-1024 steps).  `--config scaled` times BASELINE configs[4] (3 x 1024 units per axis) instead.
+line.  With --gpus N > 1 and no launcher above it (no RANK in the environment) the process
+starts its own ranks: `python -m torch.distributed.run --nproc-per-node N bench.py <same args>`
+as a child, before any GPU call; output and exit code pass through.
+`roofline` is measured live with HIP events recorded by the library around every launch
+(dj_profile_*); `roofline.traffic` comes from rocprofv3 PMC passes of the same build when
+--pmc-dir names them (tools/profile_round.sh), else from the committed passes (labelled);
+`cpu_baseline` times the CPU oracle on a bounded sample (1 warm-up + 3 timed steps on 8 of the
+64 sequences); `fp32_parity_mode` is the same step in the fp32 mode the 1e-3 parity gate runs
+in; `generation` is BASELINE configs[3] (3 pieces, 1024 steps; bf16 and the certified fp32
+mode); `scaled` is BASELINE configs[4] (3 x 1024 units per axis, batch 128 x 256 x 128 as two
+micro-batches, 1 warm-up + 2 timed steps) with its own roofline.  `--config scaled` times
+configs[4] alone.
 """
 import argparse
 import ctypes as C
