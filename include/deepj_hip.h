@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DJ_ABI_VERSION 2
+#define DJ_ABI_VERSION 3
 #define DJ_DTYPE_F32 0  /* fp32 operands, v_mfma_f32_32x32x2_f32 (parity mode)            */
 #define DJ_DTYPE_BF16 1 /* bf16 operands/stash, fp32 accumulate + cell state (throughput) */
 
@@ -52,7 +52,8 @@ typedef struct dj_config {
 
 /* Kernel-selection flags (dj_config.kernel_flags: per engine; none changes results beyond summation order).  The
  * DEEPJ_* environment variables of the same meaning (DEEPJ_CLUSTER=0, DEEPJ_CLUSTER_PAIR=0, DEEPJ_CLUSTER_F32=0,
- * DEEPJ_CLUSTER_COOP=0, DEEPJ_FUSE_DX=0, DEEPJ_GEN_KSPLIT=0, DEEPJ_DEBUG_CLUSTER_FAULT=1, DEEPJ_FUSE_XW_MIN_TILES=n)
+ * DEEPJ_CLUSTER_COOP=0, DEEPJ_FUSE_DX=0, DEEPJ_GEN_KSPLIT=0, DEEPJ_BWD_PAIR=1, DEEPJ_DEBUG_CLUSTER_FAULT=1,
+ * DEEPJ_FUSE_XW_MIN_TILES=n)
  * are read ONCE, at the first call into the library, as process-wide defaults that are OR-ed with these bits; there
  * is no getenv on the launch path.  dj_env_reload() reads them again (tests that switch kernels inside one process).
  * A hipGraph captured from these calls keeps the selection in force at capture time.  dj_generate_prepare and
@@ -65,6 +66,7 @@ typedef struct dj_config {
 #define DJ_KF_NO_FUSE_DX 16         /* dX = dz W^T always as a GEMM                                                    */
 #define DJ_KF_NO_GEN_KSPLIT 32      /* note sampler: one thread per gate column                                       */
 #define DJ_KF_DEBUG_CLUSTER_FAULT 64 /* cluster launches fail their placement check (fault-handling tests)            */
+#define DJ_KF_BWD_PAIR 128          /* opt-in: BPTT of the bf16 H = 256 layers on workgroup pairs (dj_lstm_bwd_pair)   */
 int32_t dj_env_reload(void);
 
 int32_t dj_abi_version(void);
@@ -252,6 +254,18 @@ int32_t dj_lstm_pack_wt(int32_t dtype, int32_t H, const float* W, int32_t D, voi
 int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack_bwd,
                        const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias,
                        int32_t recurrent_sigmoid, const void* wtpack, int32_t D, void* dX, int32_t DP, void* stream);
+/* The same sweep as dj_lstm_bwd (bf16, H = 256 only; code 1016 otherwise) with every tile split over a PAIR of
+ * workgroups (dj_lstm.hip, lstm_bwd_pair_kernel): each member owns 128 hidden units -- its gate math, its half of dz, its
+ * half of the U^T columns -- and the halves of dz_t meet through the dZ output itself (the partner reads it back from the
+ * XCD's L2), so two workgroups of different tiles share a compute unit and their VALU / vector-memory phases interleave.
+ * Needs the cluster scratch below (counter lines, fault words) and the device to itself (bounded waits; faults are
+ * counted and poison the tile's gradients like the forward cluster's).  Opt-in for dj_train_fwd_bwd (DJ_KF_BWD_PAIR /
+ * DEEPJ_BWD_PAIR=1; off whenever DJ_KF_NO_CLUSTER is set): at the BASELINE shape it measured 1.53-1.64 ms per launch
+ * against 1.39-1.60 ms for dj_lstm_bwd -- with two workgroups streaming U^T on one compute unit the sweep stays bound by
+ * the CU's vector-memory path.  Results equal dj_lstm_bwd's up to fp32 summation order. */
+int32_t dj_lstm_bwd_pair(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack_bwd,
+                         const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias,
+                         int32_t recurrent_sigmoid, void* cluster_scratch, void* stream);
 /* The bf16 H = 256 forward sweep (any tile count; in inference with <= 64 tiles both time-axis layers in one wavefront
  * launch, with <= 8 tiles four waves per tile) and the fp32 H = 256 inference sweep of <= 8 tiles (dj_predict /
  * dj_time_model_predict / dj_generate_* in the parity mode) run as weight-stationary clusters of 8 workgroups that meet

@@ -22,7 +22,7 @@ class DjConfig(C.Structure):
 
 # dj_config.kernel_flags (include/deepj_hip.h DJ_KF_*)
 KF_NO_CLUSTER, KF_NO_CLUSTER_PAIR, KF_NO_CLUSTER_F32, KF_NO_CLUSTER_COOP = 1, 2, 4, 8
-KF_NO_FUSE_DX, KF_NO_GEN_KSPLIT, KF_DEBUG_CLUSTER_FAULT = 16, 32, 64
+KF_NO_FUSE_DX, KF_NO_GEN_KSPLIT, KF_DEBUG_CLUSTER_FAULT, KF_BWD_PAIR = 16, 32, 64, 128
 
 
 class DeepJError(RuntimeError):
@@ -69,6 +69,8 @@ _SIGS = {
                                       _P, _P, C.c_int32, _P, _P]),
     "dj_lstm_bwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int32,
                                 _P]),
+    "dj_lstm_bwd_pair": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int32,
+                                     _P, _P]),
     "dj_lstm_bwd_dx": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int32,
                                    _P, C.c_int32, _P, C.c_int32, _P]),
     "dj_lstm_pack_wt": (C.c_int32, [C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),
@@ -112,7 +114,7 @@ def load():
             raise DeepJError(f"{LIB_PATH} does not export {name}")
         fn.restype = res
         fn.argtypes = args
-    if lib.dj_abi_version() != 2:
+    if lib.dj_abi_version() != 3:
         raise DeepJError("libdeepj_hip.so ABI version mismatch")
     if lib.dj_config_size() != C.sizeof(DjConfig):
         raise DeepJError("dj_config layout mismatch: library %d bytes, binding %d" % (lib.dj_config_size(), C.sizeof(DjConfig)))

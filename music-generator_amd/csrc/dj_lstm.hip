@@ -1709,6 +1709,260 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const StashElem<T>* __r
 
 #undef DJ_DH_LOAD
 
+// ---------------------------------------------------------------- backward, two workgroups per tile (bf16, H = 256)
+// The per-tile kernel above holds a compute unit with ONE tile whose step is a strict chain: gate math (VALU: ~900
+// vector instructions per wave, two waves per SIMD) -> dz tile -> dz U^T (512 KB of U^T fragments through the CU's
+// vector-memory path) -> next gate math.  While one phase runs the other pipe idles, and with 256 tiles for 256 compute
+// units there is no second tile to fill it.  Here a tile is split over a PAIR of workgroups of four waves (blocks b and
+// b + 8: one XCD under round-robin dispatch, verified like the forward cluster's placement): member `part` owns hidden
+// units [128 part, 128 part + 128) -- its gate math, its half of dz, its half of the U^T columns (256 KB per step) --
+// so every compute unit hosts TWO workgroups of different tiles whose phases interleave.  Per step a member
+//   1. computes dz of its units (lane-local, as above) into the LDS tile and stores it to dZ -- the kernel's output IS
+//      the exchange: the partner reads it back from the XCD's L2 (sc1 loads), nothing extra is written;
+//   2. waits for its own stores (vmcnt), every wave then arrives on the pair's counter line (8 arrivals per round);
+//   3. multiplies the OWN half of the k range (its dz columns are already in LDS) -- the partner's stores and
+//      arrivals travel meanwhile;
+//   4. waits for the partner's round, fetches the partner's half of dz_t (32 KB) into the LDS tile, multiplies it.
+// Waits are bounded and counted like the forward cluster's (fault words of the same scratch; the tile's cell gradient is
+// poisoned with NaN, the host repeats the step on the per-tile kernel).  The k order differs from the per-tile kernel
+// (own half first), so results agree to fp32 summation order, not bit for bit.
+constexpr int BP_MAXPAIRS = 256;
+constexpr int BP_ARR = 8;                                  // arrivals per round: 2 members x 4 waves
+constexpr size_t BP_OFF_CNT = CL_BYTES;                    // behind the forward cluster's region: one 128-byte line per
+constexpr size_t BP_BYTES = (size_t)BP_MAXPAIRS * 128;     //   pair, [0] = counter, [8 + part] = XCC ids
+constexpr size_t CL_BYTES_ALL = CL_BYTES + BP_BYTES;
+
+template <bool SIGM>
+__global__ __launch_bounds__(256, 2) void lstm_bwd_pair_kernel(const uint8_t* __restrict__ Z,
+                                                               const bf16_t* __restrict__ UTpack,
+                                                               const bf16_t* __restrict__ C,
+                                                               const bf16_t* __restrict__ dH, bf16_t* __restrict__ dZ,
+                                                               float* __restrict__ dbias, int steps, int64_t dz_cts,
+                                                               int ldz, int* __restrict__ cl, int ntiles, int mate) {
+  using T = bf16_t;
+  constexpr int H = 256, HP = 128;
+  using R = RecCfg<T, H>;
+  using Frag = typename DjFrag<T>::type;
+  constexpr int LDP = HP + R::EPL;                         // row stride of the dH staging tile (own 128 columns)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* dzs = (T*)smem_raw;                                   // [32][LDZ]: dz_t, all 4H columns
+  T* dhs = dzs + 32 * R::LDZ;                              // [32][LDP]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  // pair (b, b + mate): `mate` is 8 (neighbours in dispatch order) or half the grid; a multiple of 8 either way, so
+  // both members sit on one XCD under round-robin dispatch
+  const int bidx = (int)blockIdx.x;
+  int part, pid;
+  if (mate == 8) {
+    part = (bidx >> 3) & 1;
+    pid = (bidx & 7) + 8 * (bidx >> 4);
+  } else {
+    part = bidx >= mate;
+    pid = bidx - part * mate;
+  }
+  if (pid >= ntiles) return;                               // both members of a pair without a tile leave
+  const int64_t tile = pid;
+  const int wb = 4 * part + w;                             // this wave's 32-unit block
+  int* cnt = (int*)((unsigned char*)cl + BP_OFF_CNT) + pid * 32;
+  int* xccs = cnt + 8;
+  int* fault = cl + CL_CNT_INTS;
+
+  float dcc[16], dbs[4];
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    dcc[r] = 0.f;
+    acc[r] = 0.f;
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) dbs[g] = 0.f;
+
+  // round 0: publish the XCD this member runs on, meet the partner, compare
+  const int my_xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15) + 1;   // HW_REG_XCC_ID[3:0]
+  const int my_cu = (int)((__builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11))) & 255) + 1;   // HW_REG_HW_ID[15:8]: cu, sh, se
+  if (tid == 0) {
+    __hip_atomic_store(xccs + part, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(xccs + 2 + part, my_cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  {
+    const bool ok = cl_wait(cnt, BP_ARR, lane);
+    int other = my_xcc;
+    if (ok && lane < 2) other = __hip_atomic_load(xccs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // statistic (fault word 3, not a fault): pairs whose members share a compute unit -- they run in lockstep on one
+    // tile and gain nothing from each other
+    if (ok && tid == 0 && part == 0 &&
+        __hip_atomic_load(xccs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_cu)
+      atomicAdd(fault + 3, 1);
+    const bool same = __all(other == my_xcc) && __hip_atomic_load(fault + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+    if (!ok || !same) {
+      if (lane == 0 && w == 0) atomicAdd(fault + (ok ? 1 : 0), 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dcc[r] = __builtin_nanf("");
+    }
+  }
+
+  // fragment streams and LDS views of the two halves of the k range (k = gate * 256 + unit): half `part` is this
+  // member's own, the other the partner's; 8 k-chunks per gate and half
+  const Frag* up = (const Frag*)UTpack + (int64_t)wb * R::NKCB * 64 + lane;
+  const Frag* up_own = up + 8 * part * 64;
+  const Frag* up_oth = up + 8 * (1 - part) * 64;
+  const T* ap_own = dzs + l31 * R::LDZ + HP * part;
+  const T* ap_oth = dzs + l31 * R::LDZ + HP * (1 - part);
+  auto zaddr = [&](int64_t rb, int g) { return Z + ((rb * R::NCB + (g * H + wb * 32) / 32) * 64 + lane) * 16; };
+  auto caddr = [&](int64_t rb) { return C + ((rb * R::NCBH + wb) * 64 + lane) * 16; };
+  // dH_t, own 128 columns: 32 rows x 16 vectors of 16 bytes = 2 per thread (named scalars: see the kernel above)
+  auto dh_ld = [&](int64_t rb, int i) {
+    const int v = tid + 256 * i, row = v >> 4, cv = (v & 15) * 8;
+    return *(const uint4*)(dH + (rb * 32 + row) * H + HP * part + cv);
+  };
+  auto dh_st = [&](int i, uint4 val) {
+    const int v = tid + 256 * i, row = v >> 4, cv = (v & 15) * 8;
+    *(uint4*)(dhs + row * LDP + cv) = val;
+  };
+  // half a dz tile between LDS and dZ: 32 rows x 4 gates x 256 bytes = 8 vectors of 16 bytes per thread; one column
+  // tile (gate) per pass, 4 rows x 256 bytes per wave instruction
+  auto dz_off = [&](int i, int half, int& lds_off) {
+    const int g = i >> 1, v2 = tid + 256 * (i & 1), row = v2 >> 4, cv = (v2 & 15) * 8 + HP * half;
+    lds_off = row * R::LDZ + g * H + cv;
+    return (int64_t)g * dz_cts + (int64_t)row * ldz + cv;
+  };
+  // dz_t U^T in two halves of 32 k-chunks -- the own half of the k range, then the partner's -- each through a ring of
+  // RD fragments.  Chunk i of a half: gate i / 8, chunk i % 8 of that half's 8 per gate.  Rolled loops of RD (fully
+  // unrolled, hipcc hoists every fragment load and spills).
+  constexpr int RD = 8;
+  auto choff = [](int i) { return (16 * (i / 8) + i % 8) * 64; };
+  auto ring_fill = [&](Frag (&bq)[RD], const Frag* ub) {
+#pragma unroll
+    for (int p = 0; p < RD; ++p) bq[p] = ub[choff(p)];
+  };
+  // consume chunks [RD * it, RD * it + RD) of the half at (ab), refill with the RD chunks that follow in the stream
+  auto prod_turn = [&](Frag (&bq)[RD], const T* ab, int it, const Frag* refill) {
+#pragma unroll
+    for (int u = 0; u < RD; ++u) {
+      const int i = u;            // chunk within the turn; (RD * it) enters through the pointers
+      Frag a = dj_lds_frag(ab + 256 * (i / 8) + 16 * (i % 8), h);
+      dj_mfma(acc, a, bq[u]);
+      if (refill) bq[u] = refill[choff(u)];
+      if ((u & 3) == 3) asm volatile("" ::: "memory");     // keeps the refills where they are written (register budget)
+    }
+    (void)it;
+  };
+
+  Frag16<T> cnext, cprev;
+  GateDec<T, SIGM> gd;
+  uint4 dh0 = dh_ld(tile * steps + steps - 1, 0), dh1 = dh_ld(tile * steps + steps - 1, 1);
+  cnext.load(caddr(tile * steps + steps - 1));
+
+  for (int t = steps - 1; t >= 0; --t) {
+    const int64_t rb = tile * steps + t;
+    dh_st(0, dh0);
+    dh_st(1, dh1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gd.load(g, zaddr(rb, g));
+    if (t > 0) {
+      cprev.load(caddr(rb - 1));
+      dh0 = dh_ld(rb - 1, 0);
+      dh1 = dh_ld(rb - 1, 1);
+    }
+    lds_barrier();     // dH_t staged; every wave has left the previous step's product (its reads of the dz tile)
+    float dhv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dhv[r] = dj_to_f32(dhs[dj_crow(r, lane) * LDP + w * 32 + l31]) + acc[r];
+    {
+      const int u = wb * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = dj_crow(r, lane);
+        float ig, fg, gg, og, di, df, dO;
+        gd.get(r, ig, fg, gg, og, di, df, dO);
+        const float ct = cnext.get(r);
+        const float cp = (t > 0) ? cprev.get(r) : 0.f;
+        const float dh = dhv[r];
+        const float tc = dj_tanh(ct);
+        const float dzo = dh * tc * dO;
+        const float dc = dcc[r] + dh * og * (1.f - tc * tc);
+        const float dzi = dc * gg * di;
+        const float dzf = dc * cp * df;
+        const float dzg = dc * ig * (1.f - gg * gg);
+        dcc[r] = dc * fg;
+        T* dp = dzs + row * R::LDZ + u;
+        dp[0] = dj_from_f32<T>(dzi);
+        dp[H] = dj_from_f32<T>(dzf);
+        dp[2 * H] = dj_from_f32<T>(dzg);
+        dp[3 * H] = dj_from_f32<T>(dzo);
+        dbs[0] += dzi;
+        dbs[1] += dzf;
+        dbs[2] += dzg;
+        dbs[3] += dzo;
+      }
+      if (t > 0) cnext.copy_from(cprev);
+    }
+    lds_barrier();     // this member's half of dz_t is complete in LDS
+    bf16_t* dzg_ = dZ + rb * 32 * ldz;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int lo;
+      const int64_t go = dz_off(i, part, lo);
+      *(uint4*)(dzg_ + go) = *(const uint4*)(dzs + lo);
+    }
+    if (t > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      // the stores above are the exchange: once acknowledged (they are in the XCD's L2), this wave arrives
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      Frag bq[RD];
+      // opaque per step: as loop invariants hipcc keeps all 64 fragment addresses in registers (and spills them)
+      const Frag *uo = up_own, *ut = up_oth;
+      asm volatile("" : "+v"(uo), "+v"(ut));
+      ring_fill(bq, uo);
+      constexpr int NTURN = 32 / RD, GPT = RD / 8;         // turns per half, gates per turn
+#pragma unroll 1
+      for (int it = 0; it + 1 < NTURN; ++it) prod_turn(bq, ap_own + 256 * GPT * it, it, uo + 16 * GPT * (it + 1) * 64);
+      prod_turn(bq, ap_own + 256 * GPT * (NTURN - 1), NTURN - 1, nullptr);
+      // the partner half's first fragments travel during the exchange.  (Requested from inside the own half's last
+      // turn instead -- one continuous stream -- the sweep was 4 % slower; a ring of 16 was 6 % slower: with two
+      // workgroups streaming on one compute unit the fragment stream is bound by the CU's vector-memory path, not by
+      // bytes in flight.)
+      ring_fill(bq, ut);
+      if (!cl_wait(cnt, BP_ARR * (steps - t + 1), lane)) {
+        if (lane == 0) atomicAdd(fault, 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dcc[r] = __builtin_nanf("");
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+      uint4 pz[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        int lo;
+        const int64_t go = dz_off(i, 1 - part, lo);
+        pz[i] = ld_sc1((const uint4*)(dzg_ + go));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        int lo;
+        dz_off(i, 1 - part, lo);
+        *(uint4*)(dzs + lo) = pz[i];
+      }
+      lds_barrier();   // the partner's half of dz_t is in LDS
+#pragma unroll 1
+      for (int it = 0; it + 1 < NTURN; ++it) prod_turn(bq, ap_oth + 256 * GPT * it, it, ut + 16 * GPT * (it + 1) * 64);
+      prod_turn(bq, ap_oth + 256 * GPT * (NTURN - 1), NTURN - 1, nullptr);
+    }
+  }
+  if (dbias) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v = dbs[g];
+      v += __shfl_xor(v, 32);
+      if (h == 0) atomicAdd(dbias + g * H + wb * 32 + l31, v);
+    }
+  }
+}
+
 template <typename T, int H> int launch_pack(const float* U, void* fwd, void* bwd, hipStream_t st) {
   int n = H * 4 * H;
   dim3 grid((n + 255) / 256), block(256);
@@ -1883,7 +2137,7 @@ int cluster_cus() {
 // kernel edges do not have that problem.
 __global__ void cl_reset_kernel(uint4* p) { p[blockIdx.x * 256 + threadIdx.x] = make_uint4(0, 0, 0, 0); }
 int cluster_reset(void* scratch, hipStream_t st) {
-  static_assert(CL_OFF_FAULT % (256 * 16) == 0, "reset grid");
+  static_assert(CL_OFF_FAULT % (256 * 16) == 0 && BP_BYTES % (256 * 16) == 0 && BP_OFF_CNT % 128 == 0, "reset grid");
   hipLaunchKernelGGL(cl_reset_kernel, dim3(CL_OFF_FAULT / (256 * 16)), dim3(256), 0, st, (uint4*)scratch);
   return (int)hipGetLastError();
 }
@@ -1953,6 +2207,67 @@ int launch_fwd_cluster_pair(int ntiles, int steps, const ClPairArgs& a, int sigm
   return (int)hipGetLastError();
 }
 
+// BPTT of a bf16 H = 256 layer on pairs of workgroups (lstm_bwd_pair_kernel): at most 256 tiles per launch, two
+// workgroups per compute unit, the whole grid co-resident.  Returns 1017 when the device cannot hold it (the caller then
+// uses the per-tile kernel).
+int bwd_pair_blocks_per_cu() {
+  static int bpc[DJ_MAX_DEVICES] = {};
+  const int dev = dj_current_device();
+  if (!bpc[dev]) {
+    const size_t smem = (size_t)(32 * RecCfg<bf16_t, 256>::LDZ + 32 * (128 + 8)) * sizeof(bf16_t);
+    const void* fns[2] = {(const void*)lstm_bwd_pair_kernel<false>, (const void*)lstm_bwd_pair_kernel<true>};
+    int least = 1 << 30;
+    for (const void* fn : fns) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return 0;
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, smem) != hipSuccess) return 0;
+      least = n < least ? n : least;
+    }
+    bpc[dev] = least > 0 ? least : -1;
+  }
+  return bpc[dev] > 0 ? bpc[dev] : 0;
+}
+int launch_bwd_pair(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
+                    int64_t dz_cts_in, float* dbias, int sigm, void* scratch, hipStream_t st) {
+  using R = RecCfg<bf16_t, 256>;
+  constexpr int H = 256;
+  if (!scratch || ((uintptr_t)scratch & 127)) return 1016;
+  const int64_t dz_cts = dz_cts_in ? dz_cts_in : 256;
+  const int ldz = dz_cts_in ? 256 : 4 * H;
+  if (dz_cts_in && dz_cts_in < (int64_t)ntiles * steps * 32 * 256) return 1018;
+  const int64_t slots = (int64_t)cluster_cus() * bwd_pair_blocks_per_cu() / 2;       // pairs the device holds at once
+  const int cap = (int)(slots < BP_MAXPAIRS ? slots / 8 * 8 : BP_MAXPAIRS);
+  if (cap < 8) return 1017;
+  const size_t smem = (size_t)(32 * R::LDZ + 32 * (128 + 8)) * sizeof(bf16_t);
+  const uint8_t* z = (const uint8_t*)Z;
+  const bf16_t *c = (const bf16_t*)C, *dh = (const bf16_t*)dH;
+  bf16_t* dz = (bf16_t*)dZ;
+  while (ntiles > 0) {
+    const int n = ntiles < cap ? ntiles : cap;
+    // counter lines of the pairs start at zero in every launch (a kernel, not a memset node: cluster_reset above)
+    hipLaunchKernelGGL(cl_reset_kernel, dim3(BP_BYTES / (256 * 16)), dim3(256), 0, st,
+                       (uint4*)((unsigned char*)scratch + BP_OFF_CNT));
+    if (int rc = cluster_fault_hook(scratch, st)) return rc;
+    const dim3 grid((n + 7) / 8 * 16);
+    static const int far = getenv("DEEPJ_BWD_PAIR_FAR") ? atoi(getenv("DEEPJ_BWD_PAIR_FAR")) : 0;
+    const int mate = far ? (int)grid.x / 2 : 8;
+    if (sigm)
+      hipLaunchKernelGGL((lstm_bwd_pair_kernel<true>), grid, dim3(256), smem, st, z, (const bf16_t*)UTpack, c, dh, dz, dbias,
+                         steps, dz_cts, ldz, (int*)scratch, n, mate);
+    else
+      hipLaunchKernelGGL((lstm_bwd_pair_kernel<false>), grid, dim3(256), smem, st, z, (const bf16_t*)UTpack, c, dh, dz, dbias,
+                         steps, dz_cts, ldz, (int*)scratch, n, mate);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
+    const int64_t rows = (int64_t)n * steps * 32;
+    z += rows * 4 * H;
+    c += rows * H;
+    dh += rows * H;
+    dz += rows * ldz;
+    ntiles -= n;
+  }
+  return 0;
+}
+
 }  // namespace
 
 // fp32 H = 256 inference sweep of at most 8 tiles on clusters of 8 workgroups (lstm_fwd_cluster_f32_kernel).  Returns
@@ -2016,11 +2331,16 @@ int dj_launch_lstm_fwd(int dtype, int H, int ntiles, int steps, const void* Zx, 
 }
 // bytes per row of the gate stash of a layer with H units (fragment-tiled; GateEnc above)
 int64_t dj_lstm_stash_row_bytes(int dtype, int H) { return (int64_t)4 * H * (dtype == DJ_F32 ? 4 : 1); }
-int64_t dj_lstm_cluster_scratch_bytes_impl() { return (int64_t)CL_BYTES; }
+int64_t dj_lstm_cluster_scratch_bytes_impl() { return (int64_t)CL_BYTES_ALL; }
 int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* UTpack, const void* C,
                        const void* dH, void* dZ, int64_t dz_cts, float* dbias, int sigm, const void* WTpack, int D, void* dX,
-                       int DP, hipStream_t st) {
+                       int DP, void* cluster_scratch, hipStream_t st) {
   if (ntiles <= 0 || steps <= 0) return 0;
+  // bf16 H = 256 (time axis): two workgroups per tile where the device holds the grid (lstm_bwd_pair_kernel)
+  if (cluster_scratch && dtype == DJ_BF16 && H == 256 && !WTpack) {
+    const int rc = launch_bwd_pair(ntiles, steps, Z, UTpack, C, dH, dZ, dz_cts, dbias, sigm, cluster_scratch, st);
+    if (rc != 1017) return rc;
+  }
   const int NQ = (D + 31) / 32;
   if (WTpack && (!dX || D < 1 || DP < 8 || (DP % 8) || NQ * 32 < DP)) return 1013;
   DJ_DISPATCH_TH(launch_bwd, ntiles, steps, Z, UTpack, C, dH, dZ, dz_cts, dbias, sigm, WTpack, NQ, dX, DP, st)
