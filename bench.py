@@ -256,9 +256,10 @@ def generation_bench(dtype, steps):
 
 def scaled_record(dtype, micro, steps, warmup, dropout, dev, rank, world, dist):
     """BASELINE configs[4]: 3 x 1024 units per axis, batch 128 x 256 steps x 128 notes per GPU.  The batch runs as
-    `micro` equal micro-batches through one workspace with gradient accumulation (dj_train_fwd_bwd_acc) and ONE
-    optimizer step; as with data-parallel ranks, pitch_bins couples samples within a micro-batch only.  Returns the
-    JSON record (rank 0) or None."""
+    `micro` equal micro-batches through one workspace with gradient accumulation and ONE optimizer step -- EXACTLY the
+    step on the batch of 128 (dj_train_fwd_bwd_mb): the pitch_bins table is that of the whole batch (dj_pitch_bins, one
+    small launch per step inside the timed region) and every dropout mask is the full batch's mask of the micro-batch's
+    rows.  Returns the JSON record (rank 0) or None."""
     from music_generator_amd import _lib
     from music_generator_amd.data import synthetic_batch
     from music_generator_amd.engine import DeepJConfig, Engine, Nadam, init_params_numpy
@@ -276,8 +277,11 @@ def scaled_record(dtype, micro, steps, warmup, dropout, dev, rank, world, dist):
     lib = _lib.load()
 
     def step(i):
+        seed = i * world + rank
+        bins = eng.pitch_bins(data[0], seed=seed)
         for m in range(micro):
-            loss = eng.train_fwd_bwd(P, G, *parts[m], seed=(i * world + rank) * micro + m, accumulate=m > 0)
+            loss = eng.train_fwd_bwd(P, G, *parts[m], seed=seed, accumulate=m > 0, full_batch=B, batch_offset=m * k,
+                                     bins_full=bins)
         if world > 1:
             dist.all_reduce(G)
         opt.step(P, G, grad_scale=1.0 / (micro * world))
@@ -328,7 +332,7 @@ def scaled_record(dtype, micro, steps, warmup, dropout, dev, rank, world, dist):
         "ms_per_step": round(elapsed / steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": f"scaled biaxial-LSTM train step (BASELINE configs[4]): 3x1024 time-axis + 3x1024 "
-                               f"note-axis LSTM, batch {B}/GPU as {micro} micro-batches x {T} steps x {N} notes, "
+                               f"note-axis LSTM, batch {B}/GPU as {micro} exact micro-batches (pitch_bins and dropout masks of the full batch) x {T} steps x {N} notes, "
                                f"dropout {pin}/{pdr}, Nadam; random-init weights",
                    "global_batch": B * world, "seq_len": T, "num_notes": N, "parallelism": f"dp{world}",
                    "micro_batches": micro, "workspace_gib": ws_gib},

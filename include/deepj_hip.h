@@ -101,6 +101,23 @@ int32_t dj_train_fwd_bwd_acc(const dj_config* cfg, const float* params, float* g
                              float* out, float* loss, void* workspace, int64_t workspace_bytes, uint64_t seed,
                              int32_t accumulate, void* stream);
 
+/* EXACT micro-batching.  The reference's pitch_bins feature (model.py:43-49) is a raw reshape over the whole batch: a
+ * sample's feature depends on the other samples it is evaluated with, so splitting a batch naively changes the model.
+ * dj_train_fwd_bwd_mb runs samples [batch_offset, batch_offset + cfg->batch) of a batch of full_batch samples as the
+ * reference would inside that batch: the feature reads bins_full [octave, full_batch, T] (dj_pitch_bins on the FULL
+ * batch's notes with cfg->batch = full_batch, the same seed and train = 1) and every dropout mask is the full batch's
+ * mask of these rows.  Summed over the micro-batches (accumulate != 0 from the second on; grad_scale = cfg->batch /
+ * full_batch in dj_nadam_step, loss = mean of the calls' losses for equal sizes) the result is the gradient of ONE step
+ * on the full batch -- the scaled model's batch of 128 in two halves through one workspace (tests: against the oracle at
+ * the full batch).  bins_full == NULL (then full_batch = batch_offset = 0) is dj_train_fwd_bwd_acc.  Code 1211: bad
+ * offsets. */
+int32_t dj_pitch_bins(const dj_config* cfg_full, const float* notes_full, float* bins_full, uint64_t seed, int32_t train,
+                      void* stream);
+int32_t dj_train_fwd_bwd_mb(const dj_config* cfg, const float* params, float* grads, const float* notes,
+                            const float* chosen, const float* beat, const float* style, const float* target, float* out,
+                            float* loss, void* workspace, int64_t workspace_bytes, uint64_t seed, int32_t accumulate,
+                            int32_t full_batch, int32_t batch_offset, const float* bins_full, void* stream);
+
 /* Keras-2 Nadam update (model.py:152 optimizer='nadam'): one fused pass over the flat
  * vectors.  step_t is 1-based; m_schedule_host is read and updated on the host.
  * grad_scale pre-multiplies the gradient (1/world_size after an all-reduce(sum)). */

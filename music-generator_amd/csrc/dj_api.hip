@@ -177,11 +177,12 @@ int make_plan(const dj_config* cfg, Plan& p) {
   return 0;
 }
 
-DjDrop mkdrop(uint64_t seed, int site, float prob, bool train) {
+DjDrop mkdrop(uint64_t seed, int site, float prob, bool train, uint32_t row0 = 0) {
   DjDrop d;
   d.key = dj_dropkey(seed, (uint32_t)site);
   d.thr = (train && prob > 0.f) ? (uint32_t)ceil((double)prob * 65536.0) : 0u;
   d.scale = (float)(1.0 / (1.0 - (double)prob));
+  d.row0 = row0;
   return d;
 }
 
@@ -195,8 +196,18 @@ struct Ctx {
   // generation with dj_generate_prepare done: packed weights, style embedding / projections and the transposed conv
   // kernel in the workspace are current (they depend on the parameters and the style vector only)
   bool static_ready = false;
+  // micro-batch of a larger batch (dj_train_fwd_bwd_mb): this call holds samples [b0, b0 + B) of a batch of Bfull; the
+  // dropout masks are those of the full batch's rows and pitch_bins (model.py:43-49, a reshape over the WHOLE batch)
+  // reads the full batch's table bins_ext [octave, Bfull, T]
+  int b0 = 0, Bfull = 0;
+  const float* bins_ext = nullptr;
   template <typename X = void> X* at(int64_t off) const { return (X*)(ws + off); }
 };
+// dropout site of this call: per-note sites index rows (b T + t) N + n, the beat site rows b T + t (oracle make_masks)
+DjDrop mkdrop(const Ctx& c, int site, float prob, bool train) {
+  const int64_t bt0 = (int64_t)c.b0 * c.p.T;
+  return mkdrop(c.seed, site, prob, train, (uint32_t)(site == DJ_SITE_BEAT ? bt0 : bt0 * c.p.N));
+}
 
 #define RUN(x)                 \
   do {                         \
@@ -355,16 +366,18 @@ int time_axis_forward(const Ctx& c, const float* notes, const float* beat) {
   const Plan& p = c.p;
   const int dt = p.c.dtype;
   const float pin = p.c.input_dropout, pdr = p.c.dropout;
-  DjDrop d_notes = mkdrop(c.seed, DJ_SITE_NOTES, pin, c.train);
-  RUN(dj_launch_bins(notes, c.at<float>(p.w_bins), p.B, p.T, p.N, p.c.octave, d_notes, c.st));
+  DjDrop d_notes = mkdrop(c, DJ_SITE_NOTES, pin, c.train);
+  if (!c.bins_ext) RUN(dj_launch_bins(notes, c.at<float>(p.w_bins), p.B, p.T, p.N, p.c.octave, d_notes, c.st));
   if (!c.static_ready) RUN(style_proj_all(c, p.tl, p.w_sp_t, p.Lt));
   FeatArgs fa;
-  fa.notes = notes; fa.beat = beat; fa.bins = c.at<float>(p.w_bins); fa.sp0 = c.at<float>(p.w_sp_t[0]);
+  fa.notes = notes; fa.beat = beat; fa.bins = c.bins_ext ? c.bins_ext : c.at<float>(p.w_bins);
+  fa.sp0 = c.at<float>(p.w_sp_t[0]);
   fa.Wc = c.P + p.p_conv_W; fa.bc = c.P + p.p_conv_b;
   fa.B = p.B; fa.T = p.T; fa.N = p.N; fa.NB = p.NB; fa.octave = p.c.octave; fa.F = p.F; fa.FP = p.FP;
-  fa.d_notes = d_notes; fa.d_beat = mkdrop(c.seed, DJ_SITE_BEAT, pin, c.train);
-  fa.d_conv = mkdrop(c.seed, DJ_SITE_CONV, pdr, c.train);
-  fa.d_style = mkdrop(c.seed, DJ_SITE_TSTYLE + 0, pdr, c.train);
+  fa.Bfull = c.bins_ext ? c.Bfull : p.B; fa.bt0 = c.bins_ext ? c.b0 * p.T : 0;
+  fa.d_notes = d_notes; fa.d_beat = mkdrop(c, DJ_SITE_BEAT, pin, c.train);
+  fa.d_conv = mkdrop(c, DJ_SITE_CONV, pdr, c.train);
+  fa.d_style = mkdrop(c, DJ_SITE_TSTYLE + 0, pdr, c.train);
   {
     ProfScope ps(PC_FEATURE_FWD, c.st);
     // conv as im2col GEMM on the MFMA units: Xcol -> Y = Xcol Wc + bc -> tanh / dropout / assembly
@@ -393,9 +406,9 @@ int time_axis_forward(const Ctx& c, const float* notes, const float* beat) {
       GlueArgs g;
       g.B = p.B; g.T = p.T; g.N = p.N; g.Hd = p.Ht; g.D = L.D; g.DP = L.DP; g.in_na = 0; g.out_na = 0;
       g.sp = c.at<float>(p.w_sp_t[l]); g.chosen = nullptr;
-      g.d_out = mkdrop(c.seed, DJ_SITE_TOUT + (l - 1), pdr, c.train);
-      g.d_style = mkdrop(c.seed, DJ_SITE_TSTYLE + l, pdr, c.train);
-      g.d_chosen = mkdrop(c.seed, DJ_SITE_CHOSEN, pin, c.train);
+      g.d_out = mkdrop(c, DJ_SITE_TOUT + (l - 1), pdr, c.train);
+      g.d_style = mkdrop(c, DJ_SITE_TSTYLE + l, pdr, c.train);
+      g.d_chosen = mkdrop(c, DJ_SITE_CHOSEN, pin, c.train);
       ProfScope ps(PC_GLUE_FWD, c.st);
       RUN(dj_launch_glue_fwd(dt, &g, c.at(p.w_H_t[l - 1]), c.at(p.w_X_t[l]), c.st));
     }
@@ -417,16 +430,16 @@ int note_axis_forward(const Ctx& c, int64_t wHin, int in_na, int d_out_site, con
     GlueArgs g;
     g.B = p.B; g.T = p.T; g.N = p.N; g.D = L.D; g.DP = L.DP; g.out_na = 1;
     g.sp = c.at<float>(p.w_sp_n[l]);
-    g.d_style = mkdrop(c.seed, DJ_SITE_NSTYLE + l, pdr, c.train);
-    g.d_chosen = mkdrop(c.seed, DJ_SITE_CHOSEN, pin, c.train);
+    g.d_style = mkdrop(c, DJ_SITE_NSTYLE + l, pdr, c.train);
+    g.d_chosen = mkdrop(c, DJ_SITE_CHOSEN, pin, c.train);
     if (l == 0) {
       g.Hd = p.Ht; g.in_na = in_na; g.chosen = chosen;
-      g.d_out = mkdrop(c.seed, d_out_site, pdr, c.train && d_out_site >= 0);
+      g.d_out = mkdrop(c, d_out_site, pdr, c.train && d_out_site >= 0);
       ProfScope ps(PC_GLUE_FWD, c.st);
       RUN(dj_launch_glue_fwd(dt, &g, c.at(wHin), c.at(p.w_X_n[0]), c.st));
     } else {
       g.Hd = p.Hn; g.in_na = 1; g.chosen = nullptr;
-      g.d_out = mkdrop(c.seed, DJ_SITE_NOUT + (l - 1), pdr, c.train);
+      g.d_out = mkdrop(c, DJ_SITE_NOUT + (l - 1), pdr, c.train);
       ProfScope ps(PC_GLUE_FWD, c.st);
       RUN(dj_launch_glue_fwd(dt, &g, c.at(p.w_H_n[l - 1]), c.at(p.w_X_n[l]), c.st));
     }
@@ -440,7 +453,7 @@ int note_axis_forward(const Ctx& c, int64_t wHin, int in_na, int d_out_site, con
   h.dWn = grads ? grads + p.p_nd_W : nullptr; h.dbn = grads ? grads + p.p_nd_b : nullptr;
   h.dWv = grads ? grads + p.p_vd_W : nullptr; h.dbv = grads ? grads + p.p_vd_b : nullptr;
   h.inv_count = (float)(1.0 / ((double)p.BT * p.N));
-  h.d_out = mkdrop(c.seed, DJ_SITE_NOUT + (p.Ln - 1), pdr, c.train);
+  h.d_out = mkdrop(c, DJ_SITE_NOUT + (p.Ln - 1), pdr, c.train);
   if (target && !grads) {   // loss only: head gradients land in scratch (dX_n is unused in inference)
     float* dummy = c.at<float>(p.w_dX_n);
     h.dWn = dummy; h.dbn = dummy + 2 * p.Hn; h.dWv = dummy + 2 * p.Hn + 2; h.dbv = dummy + 3 * p.Hn + 2;
@@ -623,11 +636,33 @@ int32_t dj_train_fwd_bwd_acc(const dj_config* cfg, const float* params, float* g
                              const float* chosen, const float* beat, const float* style, const float* target,
                              float* out, float* loss, void* ws, int64_t ws_bytes, uint64_t seed, int32_t accumulate,
                              void* stream) {
+  return dj_train_fwd_bwd_mb(cfg, params, grads, notes, chosen, beat, style, target, out, loss, ws, ws_bytes, seed,
+                             accumulate, 0, 0, nullptr, stream);
+}
+
+// pitch_bins table of a whole batch (model.py:43-45): bins[i, b, t] = sum_k dropped_notes[b, t, i + 12 k, 0]
+int32_t dj_pitch_bins(const dj_config* cfg, const float* notes, float* bins, uint64_t seed, int32_t train, void* stream) {
+  Plan p;
+  RUN(make_plan(cfg, p));
+  if (!notes || !bins) return 1210;
+  return dj_launch_bins(notes, bins, p.B, p.T, p.N, p.c.octave, mkdrop(seed, DJ_SITE_NOTES, p.c.input_dropout, train != 0),
+                        (hipStream_t)stream);
+}
+
+int32_t dj_train_fwd_bwd_mb(const dj_config* cfg, const float* params, float* grads, const float* notes,
+                            const float* chosen, const float* beat, const float* style, const float* target,
+                            float* out, float* loss, void* ws, int64_t ws_bytes, uint64_t seed, int32_t accumulate,
+                            int32_t full_batch, int32_t batch_offset, const float* bins_full, void* stream) {
   Plan p;
   RUN(make_plan(cfg, p));
   RUN(check_ws(p, ws, ws_bytes));
   if (!params || !grads || !notes || !chosen || !beat || !style || !target || !loss) return 1210;
+  if (bins_full && (batch_offset < 0 || full_batch < batch_offset + p.B)) return 1211;
+  if (!bins_full && (full_batch || batch_offset)) return 1211;
   Ctx c{p, params, (char*)ws, (hipStream_t)stream, true, seed};
+  if (bins_full) {
+    c.b0 = batch_offset; c.Bfull = full_batch; c.bins_ext = bins_full;
+  }
   const int dt = p.c.dtype;
   float* G = grads;
   if (!accumulate) DJ_CHECK(hipMemsetAsync(G, 0, p.nparams * sizeof(float), c.st));   // every gradient kernel adds into G
@@ -649,16 +684,16 @@ int32_t dj_train_fwd_bwd_acc(const dj_config* cfg, const float* params, float* g
     GlueArgs g;
     g.B = p.B; g.T = p.T; g.N = p.N; g.D = L.D; g.DP = L.DP; g.out_na = 1;
     g.sp = c.at<float>(p.w_sp_n[l]); g.chosen = nullptr;
-    g.d_style = mkdrop(seed, DJ_SITE_NSTYLE + l, pdr, true);
-    g.d_chosen = mkdrop(seed, DJ_SITE_CHOSEN, pin, true);
+    g.d_style = mkdrop(c, DJ_SITE_NSTYLE + l, pdr, true);
+    g.d_chosen = mkdrop(c, DJ_SITE_CHOSEN, pin, true);
     if (l == 0) {
       g.Hd = p.Ht; g.in_na = 0;
-      g.d_out = mkdrop(seed, DJ_SITE_TOUT + (p.Lt - 1), pdr, true);
+      g.d_out = mkdrop(c, DJ_SITE_TOUT + (p.Lt - 1), pdr, true);
       ProfScope ps(PC_GLUE_BWD, c.st);
       RUN(dj_launch_glue_bwd(dt, &g, c.at(p.w_dX_n), c.at(p.w_dH_t), c.at<float>(p.w_dpre_n[l]), c.st));
     } else {
       g.Hd = p.Hn; g.in_na = 1;
-      g.d_out = mkdrop(seed, DJ_SITE_NOUT + (l - 1), pdr, true);
+      g.d_out = mkdrop(c, DJ_SITE_NOUT + (l - 1), pdr, true);
       ProfScope ps(PC_GLUE_BWD, c.st);
       RUN(dj_launch_glue_bwd(dt, &g, c.at(p.w_dX_n), c.at(p.w_dH_n), c.at<float>(p.w_dpre_n[l]), c.st));
     }
@@ -671,9 +706,9 @@ int32_t dj_train_fwd_bwd_acc(const dj_config* cfg, const float* params, float* g
       GlueArgs g;
       g.B = p.B; g.T = p.T; g.N = p.N; g.Hd = p.Ht; g.D = L.D; g.DP = L.DP; g.in_na = 0; g.out_na = 0;
       g.sp = c.at<float>(p.w_sp_t[l]); g.chosen = nullptr;
-      g.d_out = mkdrop(seed, DJ_SITE_TOUT + (l - 1), pdr, true);
-      g.d_style = mkdrop(seed, DJ_SITE_TSTYLE + l, pdr, true);
-      g.d_chosen = mkdrop(seed, DJ_SITE_CHOSEN, pin, true);
+      g.d_out = mkdrop(c, DJ_SITE_TOUT + (l - 1), pdr, true);
+      g.d_style = mkdrop(c, DJ_SITE_TSTYLE + l, pdr, true);
+      g.d_chosen = mkdrop(c, DJ_SITE_CHOSEN, pin, true);
       ProfScope ps(PC_GLUE_BWD, c.st);
       RUN(dj_launch_glue_bwd(dt, &g, c.at(p.w_dX_t), c.at(p.w_dH_t), c.at<float>(p.w_dpre_t[l]), c.st));
     } else {
@@ -681,8 +716,9 @@ int32_t dj_train_fwd_bwd_acc(const dj_config* cfg, const float* params, float* g
       fa.notes = notes; fa.beat = beat; fa.bins = c.at<float>(p.w_bins); fa.sp0 = c.at<float>(p.w_sp_t[0]);
       fa.Wc = c.P + p.p_conv_W; fa.bc = c.P + p.p_conv_b;
       fa.B = p.B; fa.T = p.T; fa.N = p.N; fa.NB = p.NB; fa.octave = p.c.octave; fa.F = p.F; fa.FP = p.FP;
-      fa.d_notes = mkdrop(seed, DJ_SITE_NOTES, pin, true); fa.d_beat = mkdrop(seed, DJ_SITE_BEAT, pin, true);
-      fa.d_conv = mkdrop(seed, DJ_SITE_CONV, pdr, true); fa.d_style = mkdrop(seed, DJ_SITE_TSTYLE + 0, pdr, true);
+      fa.Bfull = p.B; fa.bt0 = 0;                       // pitch_bins has no gradient (its input is data)
+      fa.d_notes = mkdrop(c, DJ_SITE_NOTES, pin, true); fa.d_beat = mkdrop(c, DJ_SITE_BEAT, pin, true);
+      fa.d_conv = mkdrop(c, DJ_SITE_CONV, pdr, true); fa.d_style = mkdrop(c, DJ_SITE_TSTYLE + 0, pdr, true);
       ProfScope ps(PC_FEATURE_BWD, c.st);
       RUN(dj_launch_feature_bwd(dt, &fa, c.at(p.w_dX_t), c.at(p.w_Ycol), G + p.p_conv_b, c.at<float>(p.w_dpre_t[0]),
                                 c.st));

@@ -78,6 +78,7 @@ struct DjDrop {
   uint32_t key;     // hashed (seed, site): dj_dropkey()
   uint32_t thr;     // ceil(p * 2^16); 0 => dropout disabled
   float scale;      // 1/(1-p)
+  uint32_t row0;    // added to every row index: a micro-batch draws the masks of its rows of the FULL batch
 };
 // The (seed, site) pair is hashed BEFORE it meets the row, and the row is hashed before the key is added:
 // with key = seed ^ site*golden added to the raw row index, the masks of consecutive seeds (step k / k+1,
@@ -86,7 +87,7 @@ __host__ __device__ __forceinline__ uint32_t dj_dropkey(uint64_t seed, uint32_t 
   return dj_lowbias32(dj_lowbias32((uint32_t)(seed & 0xFFFFFFFFu) ^ (site * 0x9E3779B9u)) + (uint32_t)(seed >> 32));
 }
 __host__ __device__ __forceinline__ uint32_t dj_rowkey(const DjDrop& d, uint32_t row) {
-  return dj_lowbias32(dj_lowbias32(row) + d.key);
+  return dj_lowbias32(dj_lowbias32(row + d.row0) + d.key);
 }
 // returns the multiplier (0 or 1/(1-p)) for element (row, c)
 // One hash serves a pair of columns (2 x 16 bits): the elementwise kernels walk 8 consecutive columns per

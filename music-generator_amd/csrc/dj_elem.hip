@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void feature_asm_kernel(FeatArgs a, T* __restr
         }
         const float spc = col < a.F ? a.sp0[(int64_t)bt * a.F + col] : 0.f;
         // pitch_bins quirk (model.py:43-49): flat index f = bt N + n, value bins[((f / BT) % octave) BT + f % BT]
-        const int64_t bT = (int64_t)a.B * a.T, f0 = (int64_t)bt * a.N + n0;
+        const int64_t bT = (int64_t)a.Bfull * a.T, f0 = (int64_t)(a.bt0 + bt) * a.N + n0;
         const int64_t fr = f0 % bT;                    // uniform
         const int fqm = (int)((f0 / bT) % a.octave);   // uniform; both advanced per note below WITHOUT divisions:
         // the lanes of a wave hold different columns, so every branch below is walked by the whole wave in every
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void feature_asm_kernel(FeatArgs a, T* __restr
         } else if (col <= a.octave) {
           v = ((n % a.octave) == col - 1) ? 1.f : 0.f;             // model.py:32-41
         } else if (col == a.octave + 1) {                          // model.py:43-49 raw-reshape quirk
-          int64_t f = (int64_t)bt * a.N + n, bT = (int64_t)a.B * a.T;
+          int64_t f = (int64_t)(a.bt0 + bt) * a.N + n, bT = (int64_t)a.Bfull * a.T;
           v = a.bins[((f / bT) % a.octave) * bT + (f % bT)];
         } else if (col < a.F) {                                    // beat, model.py:66
           int j = col - conv_col0 - CONV_O;

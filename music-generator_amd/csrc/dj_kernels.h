@@ -9,11 +9,12 @@ uint32_t dj_env_flags();
 struct FeatArgs {
   const float* notes;   // [B,T,N,3]
   const float* beat;    // [B,T,NB]
-  const float* bins;    // [12,B,T]
+  const float* bins;    // [12,Bfull,T]: of the whole batch these B samples are rows bt0 / T ... of (dj_pitch_bins)
   const float* sp0;     // [B*T, F] tanh'd style projection of time layer 0
   const float* Wc;      // [24,3,64] conv kernel (Keras layout)
   const float* bc;      // [64]
   int B, T, N, NB, octave;
+  int Bfull, bt0;       // batch the pitch_bins reshape runs over (model.py:47) and this call's first (b, t) row in it
   int F, FP;            // logical / padded feature width (94 / 96)
   DjDrop d_notes, d_beat, d_conv, d_style;
 };

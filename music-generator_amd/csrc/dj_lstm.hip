@@ -191,7 +191,7 @@ template <bool SIGM> struct GateDec<bf16_t, SIGM> {
     const float v = fmaf(cd, 1.f / 254.f, -0.5f / 254.f);
     y = __builtin_amdgcn_fmed3f(v, 0.f, 1.f);
     if constexpr (SIGM) dy = y * (1.f - y);
-    else dy = (v > 0.f && v < 1.f) ? 0.2f : 0.f;                   // codes 1..254: inside the linear part
+    else dy = (y == v) ? 0.2f : 0.f;      // codes 1..254: inside the linear part (v is never exactly 0 or 1: one compare)
   }
   __device__ __forceinline__ void get(int r, float& ig, float& fg, float& gg, float& og, float& di, float& df,
                                       float& dO) const {

@@ -192,21 +192,40 @@ class Engine:
         if tuple(t.shape) != tuple(shape):
             raise ValueError(f"{what}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
 
-    def train_fwd_bwd(self, params, grads, notes, chosen, beat, style, target, seed=0, out=None, accumulate=False):
+    def pitch_bins(self, notes_full, seed=0, train=True):
+        """pitch_bins table [octave, B_full, T] of a WHOLE batch (model.py:43-45; dj_pitch_bins): what the micro-batches
+        of that batch read through train_fwd_bwd(..., full_batch=, batch_offset=, bins_full=)."""
+        bfull, T = int(notes_full.shape[0]), self.time_steps
+        self._check(notes_full, (bfull, T, self.cfg.num_notes, self.cfg.note_units), "notes_full")
+        cfull = self.cfg.cstruct(bfull, T, self.c.input_dropout, self.c.dropout, self.c.kernel_flags)
+        bins = torch.empty((self.cfg.octave, bfull, T), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.dj_pitch_bins(C.byref(cfull), _lib.ptr(notes_full), _lib.ptr(bins),
+                                              C.c_uint64(int(seed) & (2 ** 64 - 1)), 1 if train else 0, _stream_ptr()),
+                       "dj_pitch_bins")
+        return bins
+
+    def train_fwd_bwd(self, params, grads, notes, chosen, beat, style, target, seed=0, out=None, accumulate=False,
+                      full_batch=0, batch_offset=0, bins_full=None):
         """Forward + BPTT.  All arguments are device fp32 tensors; returns the loss
         tensor (device, shape [1]); grads is overwritten, or added to when `accumulate`
-        (gradient accumulation over micro-batches)."""
+        (gradient accumulation over micro-batches).  With `bins_full` (pitch_bins of the whole batch) the call is
+        samples [batch_offset, batch_offset + B) of a batch of `full_batch`, exactly (dj_train_fwd_bwd_mb)."""
         s3, sb, ss = self._shapes()
         for t, sh, nm in ((notes, s3, "notes"), (chosen, s3, "chosen"), (target, s3, "target"),
                           (beat, sb, "beat"), (style, ss, "style")):
             self._check(t, sh, nm)
         assert params.numel() == self.nparams and grads.numel() == self.nparams
+        if bins_full is not None:
+            self._check(bins_full, (self.cfg.octave, int(full_batch), self.time_steps), "bins_full")
         with torch.cuda.device(self.device):
-            rc = self.lib.dj_train_fwd_bwd_acc(C.byref(self.c), _lib.ptr(params), _lib.ptr(grads), _lib.ptr(notes),
-                                               _lib.ptr(chosen), _lib.ptr(beat), _lib.ptr(style), _lib.ptr(target),
-                                               _lib.ptr(out), _lib.ptr(self.loss), self.ws_ptr, self.ws_bytes,
-                                               C.c_uint64(int(seed) & (2 ** 64 - 1)), 1 if accumulate else 0,
-                                               _stream_ptr())
+            rc = self.lib.dj_train_fwd_bwd_mb(C.byref(self.c), _lib.ptr(params), _lib.ptr(grads), _lib.ptr(notes),
+                                              _lib.ptr(chosen), _lib.ptr(beat), _lib.ptr(style), _lib.ptr(target),
+                                              _lib.ptr(out), _lib.ptr(self.loss), self.ws_ptr, self.ws_bytes,
+                                              C.c_uint64(int(seed) & (2 ** 64 - 1)), 1 if accumulate else 0,
+                                              int(full_batch) if bins_full is not None else 0,
+                                              int(batch_offset) if bins_full is not None else 0, _lib.ptr(bins_full),
+                                              _stream_ptr())
             _lib.check(rc, "dj_train_fwd_bwd")
             # fault census of this call next to the loss, without a host round trip
             _lib.check(self.lib.dj_workspace_faults_async(C.byref(self.c), self.ws_ptr, self.ws_bytes,

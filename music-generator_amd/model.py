@@ -361,8 +361,9 @@ class TrainableModel(Model):
         B, T = notes.shape[0], notes.shape[1]
         # micro-batches (DEEPJ_MICRO_BATCH=k): a batch that is a multiple of k runs as B/k passes of k sequences
         # with gradient accumulation -- one workspace of k sequences, one optimizer step (how the scaled
-        # 3x1024 model takes its global batch of 128).  As with data-parallel ranks, pitch_bins (model.py:43-49)
-        # couples samples within a micro-batch only.
+        # 3x1024 model takes its global batch of 128).  EXACTLY the step on the whole batch: pitch_bins
+        # (model.py:43-49 couples the samples of a batch) is taken from the whole batch's table and the dropout
+        # masks are the whole batch's masks of each micro-batch's rows (dj_train_fwd_bwd_mb).
         micro = int(os.environ.get("DEEPJ_MICRO_BATCH", "0") or 0)
         parts = B // micro if (micro > 0 and B > micro and B % micro == 0 and hasattr(be, "resident")) else 1
         n = s.nparams
@@ -386,9 +387,11 @@ class TrainableModel(Model):
                 loss = eng.train_fwd_bwd(s.params, s.grads, *t, seed=seed)
             else:
                 k, loss = B // parts, None
+                bins = eng.pitch_bins(t[0].contiguous(), seed=seed)
                 for i in range(parts):
                     mb = [x_[i * k:(i + 1) * k].contiguous() for x_ in t]
-                    li = eng.train_fwd_bwd(s.params, s.grads, *mb, seed=(seed + 7919 * i) & 0xFFFFFFFF, accumulate=i > 0)
+                    li = eng.train_fwd_bwd(s.params, s.grads, *mb, seed=seed, accumulate=i > 0, full_batch=B,
+                                           batch_offset=i * k, bins_full=bins)
                     loss = li.clone() if loss is None else loss + li     # [sum of means, faults so far (cumulative)]
                     if loss.numel() > 1:
                         loss[1] = li[1]

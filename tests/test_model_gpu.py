@@ -604,16 +604,61 @@ def test_gradient_accumulation_over_micro_batches(gpu_device):
     np.testing.assert_allclose(gacc.cpu().numpy(), ref, rtol=1e-4, atol=1e-6 * float(np.abs(ref).max()))
 
 
+@pytest.mark.parametrize("kw,B,micro", [(dict(num_notes=24), 4, 2), (dict(num_notes=20), 6, 2), (dict(num_notes=48), 6, 3),
+                                        (dict(num_notes=24, time_axis_units=64, note_axis_units=96, time_axis_layers=3), 4, 1)])
+def test_exact_micro_batches_vs_oracle_full_batch(gpu_device, kw, B, micro):
+    """dj_pitch_bins + dj_train_fwd_bwd_mb: a batch run as micro-batches of `micro` samples through a workspace of that
+    size is the step on the WHOLE batch -- loss and every gradient tensor against the oracle evaluated at the full
+    batch (fp32, 1e-3 class tolerances, dropout on).  The reference's pitch_bins reshape (model.py:43-49) couples the
+    samples of a batch and dropout masks are indexed by the batch's rows, so a naive split is a different model: the
+    same micro-batches through dj_train_fwd_bwd_acc must NOT match (N = 20 also exercises N % 12 != 0; the last case
+    the per-step path of other layer widths)."""
+    from music_generator_amd.engine import Engine
+    T, seed, pin, pdr = 5, 4242, 0.2, 0.5
+    ocfg, dcfg = _cfgs(time_steps=T, **kw)
+    params = O.init_params(ocfg, seed=8)
+    flat = O.flatten_params(ocfg, params)
+    batch = O.synthetic_batch(ocfg, B, seed=6, T=T)
+    loss_ref, _, g_ref = O.loss_and_grads(ocfg, params, batch, O.make_masks(ocfg, B, seed, pin, pdr, T=T))
+    dn = [torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(gpu_device) for a in batch]
+    P = torch.from_numpy(flat).to(gpu_device)
+    eng = Engine(dcfg, micro, T, device=gpu_device, input_dropout=pin, dropout=pdr)
+    bins = eng.pitch_bins(dn[0], seed=seed)
+    G = torch.empty_like(P)
+    losses = []
+    for i in range(B // micro):
+        mb = [a[i * micro:(i + 1) * micro].contiguous() for a in dn]
+        losses.append(float(eng.train_fwd_bwd(P, G, *mb, seed=seed, accumulate=i > 0, full_batch=B, batch_offset=i * micro,
+                                              bins_full=bins).cpu()[0]))
+    g = G.cpu().numpy() * (micro / B)
+    loss = float(np.mean(losses))
+    assert abs(loss - loss_ref) <= 1e-4 * max(1.0, abs(loss_ref)), (loss, loss_ref)
+    worst, rows = _grad_report(ocfg, g, g_ref)
+    assert worst < 2e-3, sorted(rows, key=lambda r: -r[1])[:6]
+    # the naive split (each micro-batch as a batch of its own) is a different computation
+    G2 = torch.empty_like(P)
+    for i in range(B // micro):
+        mb = [a[i * micro:(i + 1) * micro].contiguous() for a in dn]
+        eng.train_fwd_bwd(P, G2, *mb, seed=seed, accumulate=i > 0)
+    worst2, _ = _grad_report(ocfg, G2.cpu().numpy() * (micro / B), g_ref)
+    assert worst2 > 10 * worst, (worst, worst2)
+    # argument checks: offsets outside the full batch
+    with pytest.raises(Exception):
+        eng.train_fwd_bwd(P, G2, *mb, seed=seed, full_batch=B, batch_offset=B - micro + 1, bins_full=bins)
+
+
 def test_fit_micro_batches(gpu_device, monkeypatch):
-    """DEEPJ_MICRO_BATCH: train_on_batch splits the batch into equal micro-batches with gradient
-    accumulation; with dropout off and a pitch-bin-free comparison impossible (the quirk couples samples within
-    a micro-batch) the check is that training runs, the loss is finite and the parameters move."""
+    """DEEPJ_MICRO_BATCH: train_on_batch splits the batch into equal micro-batches with gradient accumulation --
+    exactly the step on the whole batch (dj_train_fwd_bwd_mb): same loss and same weights after two steps as the
+    same model trained without the split (fp32; the sums are merely ordered differently)."""
     from music_generator_amd.engine import DeepJConfig
     from music_generator_amd.model import build_models
     cfg = DeepJConfig(num_notes=24, time_steps=6)
     ocfg = O.OracleConfig(num_notes=24, time_steps=6)
     batch = O.synthetic_batch(ocfg, 4, seed=2, T=6)
     x, y = [batch[0], batch[4], batch[2], batch[3]], [batch[4]]
+    ref = build_models(time_steps=6, config=cfg, seed=3)[0]
+    lr = [ref.train_on_batch(x, y), ref.train_on_batch(x, y)]
     monkeypatch.setenv("DEEPJ_MICRO_BATCH", "2")
     m = build_models(time_steps=6, config=cfg, seed=3)[0]
     before = m.get_weights()[0].copy()
@@ -621,3 +666,6 @@ def test_fit_micro_batches(gpu_device, monkeypatch):
     l2 = m.train_on_batch(x, y)
     assert np.isfinite(l1) and np.isfinite(l2) and l2 < l1 + 0.5
     assert float(np.abs(m.get_weights()[0] - before).max()) > 0
+    assert l1 == pytest.approx(lr[0], rel=1e-5) and l2 == pytest.approx(lr[1], rel=1e-4)
+    for a, b in zip(m.get_weights(), ref.get_weights()):
+        np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-5)
