@@ -78,6 +78,13 @@ template <typename T, int H> struct RecCfg {
   static constexpr bool STATF = sizeof(T) == 2 && H == 128;
 };
 
+// The BPTT kernel's wave geometry: RecCfg's.  (fp32 at H = 256 was also built with four waves of 64 hidden units --
+// NJ = 2, one wave per SIMD, the whole VGPR + AGPR file: no spill instead of 84-164 bytes per lane, but 19.1 instead of
+// 13.5 ms per training step in the sweep: the second wave per SIMD hides more latency than the spill costs.  The kernel
+// stays NJ-generic -- the packed U^T stream is indexed by 32-unit block (w * NJ + j) -- and a specialisation of this
+// struct with UW = 64, NJ = 2, NW = 4 selects that geometry.)
+template <typename T, int H> struct BwdCfg : RecCfg<T, H> {};
+
 // raw workgroup barrier: waits for this wave's LDS traffic only, so global prefetches
 // and stores stay in flight across it (cdna_hip_programming.md "Pipelining across barriers")
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -191,7 +198,7 @@ template <bool SIGM> struct GateDec<bf16_t, SIGM> {
     const float v = fmaf(cd, 1.f / 254.f, -0.5f / 254.f);
     y = __builtin_amdgcn_fmed3f(v, 0.f, 1.f);
     if constexpr (SIGM) dy = y * (1.f - y);
-    else dy = (y == v) ? 0.2f : 0.f;      // codes 1..254: inside the linear part (v is never exactly 0 or 1: one compare)
+    else dy = (fabsf(cd - 127.5f) < 127.25f) ? 0.2f : 0.f;        // codes 1..254: inside the linear part (one compare)
   }
   __device__ __forceinline__ void get(int r, float& ig, float& fg, float& gg, float& og, float& di, float& df,
                                       float& dO) const {
@@ -1378,7 +1385,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_pair_kernel(ClPairArgs a
 // the partial sums folded through LDS one step later; the GEMM then covers a multiple of 256 columns only.
 // LDS-resident part of the streamed U^T (bf16 H = 256 only): KL k-chunks per wave behind the dz and dH tiles
 template <typename T, int H> struct BwdUlds {
-  using R = RecCfg<T, H>;
+  using R = BwdCfg<T, H>;
   static constexpr int KL = (sizeof(T) == 2 && H == 256 && !R::STATB) ? 8 : 0;
   static constexpr size_t bytes = (size_t)R::NW * KL * 64 * 16;
   static constexpr size_t offset(int DX) {
@@ -1386,12 +1393,12 @@ template <typename T, int H> struct BwdUlds {
   }
 };
 template <typename T, int H, bool SIGM, int DX>
-__global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const StashElem<T>* __restrict__ Z, const T* __restrict__ UTpack,
+__global__ __launch_bounds__((BwdCfg<T, H>::NT)) void lstm_bwd_kernel(const StashElem<T>* __restrict__ Z, const T* __restrict__ UTpack,
                                                        const T* __restrict__ C, const T* __restrict__ dH,
                                                        T* __restrict__ dZ, float* __restrict__ dbias, int steps,
                                                        const T* __restrict__ WTpack, int NQ, T* __restrict__ dX,
                                                        int DP, int64_t dz_cts, int ldz) {
-  using R = RecCfg<T, H>;
+  using R = BwdCfg<T, H>;
   using Frag = typename DjFrag<T>::type;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* dzs = (T*)smem_raw;   // [32][LDZ]; its first 32*LDH elements double as the dH staging tile
@@ -1465,8 +1472,9 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const StashElem<T>* __r
   // scalars on purpose: as a loop-carried array written through a lambda they were kept in scratch
   // memory, and the scratch store right behind the prefetch made every step wait for its HBM loads.
   constexpr int VPR = H / R::EPL, NV = 32 * VPR / R::NT;
-  static_assert(NV == 2 || NV == 4, "dH staging assumes 2 or 4 vectors per thread");
-  uint4 dh0, dh1, dh2 = make_uint4(0, 0, 0, 0), dh3 = make_uint4(0, 0, 0, 0);
+  static_assert(NV == 2 || NV == 4 || NV == 8, "dH staging assumes 2, 4 or 8 vectors per thread");
+  const uint4 z4 = make_uint4(0, 0, 0, 0);
+  uint4 dh0, dh1, dh2 = z4, dh3 = z4, dh4 = z4, dh5 = z4, dh6 = z4, dh7 = z4;
   auto dh_ld = [&](int64_t rb, int i) {
     const int v = tid + R::NT * i, row = v / VPR, cv = (v % VPR) * R::EPL;
     return *(const uint4*)(dH + (rb * 32 + row) * H + cv);
@@ -1483,9 +1491,15 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const StashElem<T>* __r
   do {                           \
     dh0 = dh_ld((rbv), 0);       \
     dh1 = dh_ld((rbv), 1);       \
-    if constexpr (NV == 4) {     \
+    if constexpr (NV >= 4) {     \
       dh2 = dh_ld((rbv), 2);     \
       dh3 = dh_ld((rbv), 3);     \
+    }                            \
+    if constexpr (NV == 8) {     \
+      dh4 = dh_ld((rbv), 4);     \
+      dh5 = dh_ld((rbv), 5);     \
+      dh6 = dh_ld((rbv), 6);     \
+      dh7 = dh_ld((rbv), 7);     \
     }                            \
   } while (0)
   // TAILPF (bf16, H = 128 with the stationary U^T): the stash of step t-1 (z_{t-1}, c_{t-2}, dH_{t-1}) is
@@ -1522,9 +1536,15 @@ __global__ __launch_bounds__(2 * H) void lstm_bwd_kernel(const StashElem<T>* __r
     // stage dH_t into LDS, then pick it up in accumulator layout
     dh_st(0, dh0);
     dh_st(1, dh1);
-    if constexpr (NV == 4) {
+    if constexpr (NV >= 4) {
       dh_st(2, dh2);
       dh_st(3, dh3);
+    }
+    if constexpr (NV == 8) {
+      dh_st(4, dh4);
+      dh_st(5, dh5);
+      dh_st(6, dh6);
+      dh_st(7, dh7);
     }
     if constexpr (!TAILPF) {
 #pragma unroll
@@ -1985,7 +2005,7 @@ int launch_fwd(int ntiles, int steps, const void* Zx, void* Gst, const void* Upa
 template <typename T, int H, int DX>
 int launch_bwd_x(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
                  int64_t dz_cts_in, float* dbias, int sigm, const void* WTpack, int NQ, void* dX, int DP, hipStream_t st) {
-  using R = RecCfg<T, H>;
+  using R = BwdCfg<T, H>;
   const int64_t dz_cts = dz_cts_in ? dz_cts_in : 256;
   const int ldz = dz_cts_in ? 256 : 4 * H;
   if (dz_cts_in && dz_cts_in < (int64_t)ntiles * steps * 32 * 256) return 1018;
