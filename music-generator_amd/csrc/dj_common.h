@@ -158,9 +158,12 @@ __device__ __forceinline__ bf16x8 dj_lds_frag(const bf16_t* p, int h) { return *
 
 // ---------------------------------------------------------------- fragment-tiled stores
 // 16 accumulator registers of one lane -> 16 contiguous operand-typed elements
+// one v_cvt_pk_bf16_f32 (two scalar conversions + shift + or compile to four instructions)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  bf16_t a = (bf16_t)lo, b = (bf16_t)hi;
-  return (uint32_t)(*(const unsigned short*)&a) | ((uint32_t)(*(const unsigned short*)&b) << 16);
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 // 4 consecutive elements of one row as one 8-byte (bf16) / 16-byte (f32) store
 __device__ __forceinline__ void dj_store4(bf16_t* p, float a, float b, float c, float d) {

@@ -132,6 +132,21 @@ template <> struct Frag16<bf16_t> {
     v[1] = o.v[1];
   }
 };
+// two values of one lane into two LDS cells: bf16 converts the pair with ONE v_cvt_pk_bf16_f32 (ds_write_b16 +
+// ds_write_b16_d16_hi take the halves), fp32 stores them as they are
+__device__ __forceinline__ void dj_lds_put2(float* p0, float* p1, float a, float b) {
+  *p0 = a;
+  *p1 = b;
+}
+__device__ __forceinline__ void dj_lds_put2(bf16_t* p0, bf16_t* p1, float a, float b) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  const bf16x2_t q = __builtin_convertvector(v, bf16x2_t);
+  *p0 = q[0];
+  *p1 = q[1];
+}
+
 // ---------------------------------------------------------------- gate stash
 // What the forward sweep leaves for BPTT, per 32x32 block (rows x hidden units) and gate, fragment-tiled like the
 // MFMA accumulators ([64 lanes][16 values]; block (rb, cb) at element ((rb*NCB + cb)*64 + lane)*16):
@@ -1591,10 +1606,15 @@ __global__ __launch_bounds__((BwdCfg<T, H>::NT)) void lstm_bwd_kernel(const Stas
         float dzg = dc * ig * (1.f - gg * gg);
         dcc[j][r] = dc * fg;
         T* dp = dzs + row * R::LDZ + u;
-        dp[0] = dj_from_f32<T>(dzi);
-        dp[H] = dj_from_f32<T>(dzf);
-        dp[2 * H] = dj_from_f32<T>(dzg);
-        dp[3 * H] = dj_from_f32<T>(dzo);
+        if constexpr (R::STATB) {     // the H = 128 kernels sit at 512 registers: the paired form spills there
+          dp[0] = dj_from_f32<T>(dzi);
+          dp[H] = dj_from_f32<T>(dzf);
+          dp[2 * H] = dj_from_f32<T>(dzg);
+          dp[3 * H] = dj_from_f32<T>(dzo);
+        } else {
+          dj_lds_put2(dp, dp + H, dzi, dzf);
+          dj_lds_put2(dp + 2 * H, dp + 3 * H, dzg, dzo);
+        }
         dbs[0][j] += dzi;
         dbs[1][j] += dzf;
         dbs[2][j] += dzg;
@@ -1907,10 +1927,8 @@ __global__ __launch_bounds__(256, 2) void lstm_bwd_pair_kernel(const uint8_t* __
         const float dzg = dc * ig * (1.f - gg * gg);
         dcc[r] = dc * fg;
         T* dp = dzs + row * R::LDZ + u;
-        dp[0] = dj_from_f32<T>(dzi);
-        dp[H] = dj_from_f32<T>(dzf);
-        dp[2 * H] = dj_from_f32<T>(dzg);
-        dp[3 * H] = dj_from_f32<T>(dzo);
+        dj_lds_put2(dp, dp + H, dzi, dzf);
+        dj_lds_put2(dp + 2 * H, dp + 3 * H, dzg, dzo);
         dbs[0] += dzi;
         dbs[1] += dzf;
         dbs[2] += dzg;
