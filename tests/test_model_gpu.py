@@ -65,6 +65,13 @@ CASES = [
                            num_notes=12), 2, 4, 0.2, 0.5),
     ("mixed_512_96", dict(time_axis_units=512, note_axis_units=96, num_notes=24), 3, 5, 0.0, 0.5),
     ("step_time_persistent_note", dict(time_axis_units=64, note_axis_units=128, num_notes=40), 2, 6, 0.2, 0.0),
+    # edges: a single sample of a single step; one octave of notes; ragged sequence tiles on both axes (B N = 792 and
+    # B T = 66 sequences: 24.75 and 2.06 tiles); the reference's full window of 128 steps (constants.py:67) -- BPTT
+    # through 128 recurrence steps against the oracle's autograd
+    ("one_sample_one_step", dict(), 1, 1, 0.2, 0.5),
+    ("one_octave_n12", dict(num_notes=12), 2, 3, 0.2, 0.5),
+    ("ragged_b33", dict(num_notes=24), 33, 2, 0.2, 0.5),
+    ("ref_window_t128", dict(), 2, 128, 0.2, 0.5),
 ]
 
 
