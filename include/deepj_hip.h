@@ -52,7 +52,7 @@ typedef struct dj_config {
 
 /* Kernel-selection flags (dj_config.kernel_flags: per engine; none changes results beyond summation order).  The
  * DEEPJ_* environment variables of the same meaning (DEEPJ_CLUSTER=0, DEEPJ_CLUSTER_PAIR=0, DEEPJ_CLUSTER_F32=0,
- * DEEPJ_CLUSTER_COOP=0, DEEPJ_FUSE_DX=0, DEEPJ_GEN_KSPLIT=0, DEEPJ_BWD_PAIR=1, DEEPJ_DEBUG_CLUSTER_FAULT=1,
+ * DEEPJ_CLUSTER_COOP=0, DEEPJ_FUSE_DX=0, DEEPJ_GEN_KSPLIT=0, DEEPJ_BWD_PAIR=1, DEEPJ_BWD_DUAL=1, DEEPJ_DEBUG_CLUSTER_FAULT=1,
  * DEEPJ_FUSE_XW_MIN_TILES=n)
  * are read ONCE, at the first call into the library, as process-wide defaults that are OR-ed with these bits; there
  * is no getenv on the launch path.  dj_env_reload() reads them again (tests that switch kernels inside one process).
@@ -67,6 +67,7 @@ typedef struct dj_config {
 #define DJ_KF_NO_GEN_KSPLIT 32      /* note sampler: one thread per gate column                                       */
 #define DJ_KF_DEBUG_CLUSTER_FAULT 64 /* cluster launches fail their placement check (fault-handling tests)            */
 #define DJ_KF_BWD_PAIR 128          /* opt-in: BPTT of the bf16 H = 256 layers on workgroup pairs (dj_lstm_bwd_pair)   */
+#define DJ_KF_BWD_DUAL 256          /* the same with two tiles per pair, interleaved (dj_lstm_bwd_dual)                */
 int32_t dj_env_reload(void);
 
 int32_t dj_abi_version(void);
@@ -281,6 +282,11 @@ int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, 
  * against 1.39-1.60 ms for dj_lstm_bwd -- with two workgroups streaming U^T on one compute unit the sweep stays bound by
  * the CU's vector-memory path.  Results equal dj_lstm_bwd's up to fp32 summation order. */
 int32_t dj_lstm_bwd_pair(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack_bwd,
+                         const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias,
+                         int32_t recurrent_sigmoid, void* cluster_scratch, void* stream);
+/* Two tiles per workgroup pair: a wave alternates between them, the product dz U^T of one tile folded into the gate
+ * math of the other (lstm_bwd_dual_kernel).  Same arguments, requirements and fault handling as dj_lstm_bwd_pair. */
+int32_t dj_lstm_bwd_dual(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack_bwd,
                          const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias,
                          int32_t recurrent_sigmoid, void* cluster_scratch, void* stream);
 /* The bf16 H = 256 forward sweep (any tile count; in inference with <= 64 tiles both time-axis layers in one wavefront

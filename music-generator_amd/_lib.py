@@ -22,7 +22,7 @@ class DjConfig(C.Structure):
 
 # dj_config.kernel_flags (include/deepj_hip.h DJ_KF_*)
 KF_NO_CLUSTER, KF_NO_CLUSTER_PAIR, KF_NO_CLUSTER_F32, KF_NO_CLUSTER_COOP = 1, 2, 4, 8
-KF_NO_FUSE_DX, KF_NO_GEN_KSPLIT, KF_DEBUG_CLUSTER_FAULT, KF_BWD_PAIR = 16, 32, 64, 128
+KF_NO_FUSE_DX, KF_NO_GEN_KSPLIT, KF_DEBUG_CLUSTER_FAULT, KF_BWD_PAIR, KF_BWD_DUAL = 16, 32, 64, 128, 256
 
 
 class DeepJError(RuntimeError):
@@ -73,6 +73,8 @@ _SIGS = {
     "dj_lstm_bwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int32,
                                 _P]),
     "dj_lstm_bwd_pair": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int32,
+                                     _P, _P]),
+    "dj_lstm_bwd_dual": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int32,
                                      _P, _P]),
     "dj_lstm_bwd_dx": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int32,
                                    _P, C.c_int32, _P, C.c_int32, _P]),

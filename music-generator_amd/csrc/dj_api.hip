@@ -231,6 +231,7 @@ EnvDefaults read_env() {
   if (off("DEEPJ_FUSE_DX")) d.flags |= DJ_KF_NO_FUSE_DX;
   if (off("DEEPJ_GEN_KSPLIT")) d.flags |= DJ_KF_NO_GEN_KSPLIT;
   if (on("DEEPJ_BWD_PAIR")) d.flags |= DJ_KF_BWD_PAIR;
+  if (on("DEEPJ_BWD_DUAL")) d.flags |= DJ_KF_BWD_DUAL;
   if (on("DEEPJ_DEBUG_CLUSTER_FAULT")) d.flags |= DJ_KF_DEBUG_CLUSTER_FAULT;
   if (const char* e = getenv("DEEPJ_FUSE_XW_MIN_TILES")) d.fuse_xw_min_tiles = atoll(e);
   return d;
@@ -246,8 +247,9 @@ inline bool cluster_enabled(const dj_config& c) { return !(kflags(c) & DJ_KF_NO_
 // BPTT of the H = 256 layers on pairs of workgroups (opt-in: measured 3-5 % slower than the per-tile kernel, DESIGN.md
 // section 8 round 3): same co-residency / placement requirements as the forward cluster, so the cluster-fault fallback
 // (DJ_KF_NO_CLUSTER) switches it off too
-inline bool bwd_pair_enabled(const dj_config& c) {
-  return (kflags(c) & DJ_KF_BWD_PAIR) && !(kflags(c) & DJ_KF_NO_CLUSTER);
+inline int bwd_pair_mode(const dj_config& c) {
+  if (kflags(c) & DJ_KF_NO_CLUSTER) return 0;
+  return (kflags(c) & DJ_KF_BWD_DUAL) ? 2 : (kflags(c) & DJ_KF_BWD_PAIR) ? 1 : 0;
 }
 
 // Fuse x*W into the recurrent kernel when its extra L2 weight stream (D x 4H) is no larger than
@@ -481,7 +483,7 @@ int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int st
     if (rec_persistent(L.H)) {
       RUN(dj_launch_lstm_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUb), c.at(wC), c.at(wdH), c.at(wdZ), cts, G + L.b,
                              c.p.c.recurrent_sigmoid, fdx ? c.at(wWp) : nullptr, L.D, fdx ? c.at(wdX) : nullptr, L.DP,
-                             (L.H == 256 && bwd_pair_enabled(c.p.c)) ? c.at(c.p.w_cluster) : nullptr, c.st));
+                             (L.H == 256 && bwd_pair_mode(c.p.c)) ? c.at(c.p.w_cluster) : nullptr, bwd_pair_mode(c.p.c), c.st));
     } else {
       const void* Uc = dt == DJ_F32 ? (const void*)(c.P + L.U) : (const void*)c.at(wUb);
       RUN(dj_launch_lstm_step_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), Uc, c.at(wC), c.at(wdH), c.at(wdZ), G + L.b,
@@ -991,21 +993,28 @@ int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, con
                     const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias, int32_t sigm,
                     void* stream) {
   return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dz_tile_stride, dbias, sigm, nullptr, 0, nullptr,
-                            0, nullptr, (hipStream_t)stream);
+                            0, nullptr, 0, (hipStream_t)stream);
 }
 int32_t dj_lstm_bwd_pair(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack,
                          const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias, int32_t sigm,
                          void* cluster_scratch, void* stream) {
   if (!cluster_scratch || dtype != DJ_BF16 || H != 256) return 1016;
   return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dz_tile_stride, dbias, sigm, nullptr, 0, nullptr,
-                            0, cluster_scratch, (hipStream_t)stream);
+                            0, cluster_scratch, 1, (hipStream_t)stream);
+}
+int32_t dj_lstm_bwd_dual(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack,
+                         const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias, int32_t sigm,
+                         void* cluster_scratch, void* stream) {
+  if (!cluster_scratch || dtype != DJ_BF16 || H != 256) return 1016;
+  return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dz_tile_stride, dbias, sigm, nullptr, 0, nullptr,
+                            0, cluster_scratch, 2, (hipStream_t)stream);
 }
 int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack,
                        const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias, int32_t sigm,
                        const void* wtpack, int32_t D, void* dX, int32_t DP, void* stream) {
   if (!wtpack) return 1013;
   return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dz_tile_stride, dbias, sigm, wtpack, D, dX, DP,
-                            nullptr, (hipStream_t)stream);
+                            nullptr, 0, (hipStream_t)stream);
 }
 int32_t dj_lstm_cluster_faults(void* cluster_scratch) { return dj_lstm_cluster_faults_impl(cluster_scratch); }
 int32_t dj_workspace_cluster_faults(const dj_config* cfg, void* ws, int64_t ws_bytes) {

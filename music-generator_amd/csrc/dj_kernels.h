@@ -93,10 +93,11 @@ int64_t dj_lstm_stash_row_bytes(int dtype, int H);
 // available where dj_lstm_bwd_has_dx says so)
 // dz_cts: layout of the dZ output, as for dj_launch_lstm_wgrad (0 = row-major [rows, 4H])
 // cluster_scratch (optional; dj_lstm_cluster_scratch_bytes_impl() bytes, as for the forward cluster): bf16 H = 256 sweeps
-// then run on pairs of workgroups per tile (lstm_bwd_pair_kernel) where the device holds the grid
+// then run on pairs of workgroups where the device holds the grid -- bwd_mode 1: one tile per pair
+// (lstm_bwd_pair_kernel), 2: two tiles per pair, product and gate math interleaved (lstm_bwd_dual_kernel)
 int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* UTpack, const void* C,
                        const void* dH, void* dZ, int64_t dz_cts, float* dbias, int sigm, const void* WTpack, int D, void* dX,
-                       int DP, void* cluster_scratch, hipStream_t st);
+                       int DP, void* cluster_scratch, int bwd_mode, hipStream_t st);
 int dj_lstm_bwd_has_dx(int dtype, int H, int D);
 int dj_launch_lstm_pack_wt(int dtype, int H, const float* W, int D, void* out, hipStream_t st);
 int dj_lstm_fused_nkx(int dtype, int H, int D);

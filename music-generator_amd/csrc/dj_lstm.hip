@@ -43,6 +43,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "dj_kernels.h"
 
@@ -1951,9 +1952,11 @@ __global__ __launch_bounds__(256, 2) void lstm_bwd_pair_kernel(const uint8_t* __
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       Frag bq[RD];
-      // opaque per step: as loop invariants hipcc keeps all 64 fragment addresses in registers (and spills them)
-      const Frag *uo = up_own, *ut = up_oth;
-      asm volatile("" : "+v"(uo), "+v"(ut));
+      // opaque per step (as loop invariants hipcc keeps all 64 fragment addresses in registers and spills them);
+      // through an offset, so that the pointers keep their address space (global_load, not flat_load)
+      int64_t uoff = 0;
+      asm volatile("" : "+v"(uoff));
+      const Frag *uo = up_own + uoff, *ut = up_oth + uoff;
       ring_fill(bq, uo);
       constexpr int NTURN = 32 / RD, GPT = RD / 8;         // turns per half, gates per turn
 #pragma unroll 1
@@ -1991,6 +1994,280 @@ __global__ __launch_bounds__(256, 2) void lstm_bwd_pair_kernel(const uint8_t* __
       prod_turn(bq, ap_oth + 256 * GPT * (NTURN - 1), NTURN - 1, nullptr);
     }
   }
+  if (dbias) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v = dbs[g];
+      v += __shfl_xor(v, 32);
+      if (h == 0) atomicAdd(dbias + g * H + wb * 32 + l31, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- backward, TWO tiles on a pair of workgroups (bf16, H = 256)
+// The pair kernel above showed that two independent workgroups per compute unit do not interleave by themselves.  Here
+// the interleave is written into ONE instruction stream: a pair of workgroups (blocks b, b + 8; four waves each, ONE
+// per SIMD, so the whole VGPR + AGPR file is theirs) owns TWO sequence tiles, A and B; member `part` owns hidden units
+// [128 part, +128) of both, wave w the 32-unit block 4 part + w.  A wave alternates between the tiles:
+//     slot A(t):  gate math of A at step t  (VALU)   ||  dz_B(t+1) U^T  (MFMA + the U^T fragment stream)
+//     slot B(t):  gate math of B at step t           ||  dz_A(t) U^T
+// four k-chunks of the other tile's product behind each of the 16 gate-math elements, so the MFMAs and their
+// fragment loads run in the shadow of the gate math's vector instructions instead of after them.  The product's own
+// half of the k range comes first (the member's own dz columns, written one slot earlier); the partner's half of that
+// dz tile is fetched from L2 in the middle of the slot (element 8) -- the partner stored it half a slot ago, so the
+// exchange latency is off the chain -- and multiplied behind elements 8..15.  The U^T fragments are ONE endless stream
+// (own half, partner half, own half, ...: the same 64 chunks every slot, both tiles share the wave's slice) through a
+// ring that never drains.  Exchange, placement check and fault handling as in lstm_bwd_pair_kernel (counter line of
+// the pair: [0] tile A, [1] tile B).
+template <bool SIGM>
+__global__ __launch_bounds__(256) void lstm_bwd_dual_kernel(const uint8_t* __restrict__ Z, const bf16_t* __restrict__ UTpack,
+                                                            const bf16_t* __restrict__ C, const bf16_t* __restrict__ dH,
+                                                            bf16_t* __restrict__ dZ, float* __restrict__ dbias, int steps,
+                                                            int64_t dz_cts, int ldz, int* __restrict__ cl, int ntiles) {
+  using T = bf16_t;
+  constexpr int H = 256, HP = 128;
+  using R = RecCfg<T, H>;
+  using Frag = typename DjFrag<T>::type;
+  constexpr int LDP = HP + R::EPL;
+  constexpr int TILE_EL = 32 * R::LDZ + 32 * LDP;          // LDS elements per tile: dz tile [32][LDZ] + dH staging [32][LDP]
+  constexpr int RD = 16;                                   // U^T ring: 4 waves x 16 KB in flight per compute unit
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* const lds = (T*)smem_raw;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  const int bidx = (int)blockIdx.x, part = (bidx >> 3) & 1, pid = (bidx & 7) + 8 * (bidx >> 4);
+  if (2 * pid >= ntiles) return;                           // ntiles is even: both tiles of a pair exist or neither
+  const int64_t tile0 = 2 * pid;
+  const int wb = 4 * part + w;
+  int* line = (int*)((unsigned char*)cl + BP_OFF_CNT) + pid * 32;
+  int* xccs = line + 8;
+  int* fault = cl + CL_CNT_INTS;
+
+  float dcc[2][16], dbs[4];
+  f32x16 acc[2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dcc[x][r] = 0.f;
+      acc[x][r] = 0.f;
+    }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) dbs[g] = 0.f;
+
+  // round 0 (on tile A's counter): publish the XCD, meet the partner, compare
+  const int my_xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15) + 1;
+  if (tid == 0) __hip_atomic_store(xccs + part, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(line, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  {
+    const bool ok = cl_wait(line, BP_ARR, lane);
+    int other = my_xcc;
+    if (ok && lane < 2) other = __hip_atomic_load(xccs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool same = __all(other == my_xcc) && __hip_atomic_load(fault + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+    if (!ok || !same) {
+      if (lane == 0 && w == 0) atomicAdd(fault + (ok ? 1 : 0), 1);
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dcc[x][r] = __builtin_nanf("");
+    }
+  }
+
+  const Frag* up = (const Frag*)UTpack + (int64_t)wb * R::NKCB * 64 + lane;
+  const Frag* up_own = up + 8 * part * 64;
+  const Frag* up_oth = up + 8 * (1 - part) * 64;
+  auto choff = [](int i) { return (16 * (i / 8) + i % 8) * 64; };      // chunk i of a half: gate i / 8, chunk i % 8
+  auto zaddr = [&](int64_t rb, int g) { return Z + ((rb * R::NCB + (g * H + wb * 32) / 32) * 64 + lane) * 16; };
+  auto caddr = [&](int64_t rb) { return C + ((rb * R::NCBH + wb) * 64 + lane) * 16; };
+  auto dh_ld = [&](int64_t rb, int i) {
+    const int v = tid + 256 * i, row = v >> 4, cv = (v & 15) * 8;
+    return *(const uint4*)(dH + (rb * 32 + row) * H + HP * part + cv);
+  };
+  auto dz_off = [&](int i, int half, int& lds_off) {
+    const int g = i >> 1, v2 = tid + 256 * (i & 1), row = v2 >> 4, cv = (v2 & 15) * 8 + HP * half;
+    lds_off = row * R::LDZ + g * H + cv;
+    return (int64_t)g * dz_cts + (int64_t)row * ldz + cv;
+  };
+
+  Frag16<T> cnext[2], cprev[2];
+  GateDec<T, SIGM> gd[2];
+  uint4 dhr[2][2];
+  Frag bq[RD];
+#pragma unroll
+  for (int p = 0; p < RD; ++p) bq[p] = up_own[choff(p)];
+
+  // one slot: gate math of tile X at step t, with the product dz_Y(ty) U^T of the other tile folded in (do_p)
+  // (do_p is a compile-time flag: with a run-time branch around every product group hipcc's wait-count bookkeeping
+  // loses the order of the ring's loads across the joins and waits for nearly all of them before every MFMA)
+  auto slot = [&](auto xc, auto pc, int t) {
+    constexpr int X = decltype(xc)::value, Y = 1 - X;
+    constexpr bool do_p = decltype(pc)::value;
+    T* const dzx = lds + X * TILE_EL;
+    T* const dzy = lds + Y * TILE_EL;
+    const T* const dhx = dzx + 32 * R::LDZ;
+    T* const dhy = dzy + 32 * R::LDZ;
+    const int64_t rbx = (tile0 + X) * steps + t;
+    const int ty = X == 0 ? t + 1 : t;                     // slot A(t) carries P_B(t+1), slot B(t) carries P_A(t)
+    const int64_t rby = (tile0 + Y) * steps + ty;
+    const int tn = X == 0 ? t : t - 1;                     // the next gate slot is G_Y(tn)
+    // its stash is requested in the MIDDLE of this slot, once the exchange's loads have landed: vector memory returns
+    // in order, so HBM loads issued at the top of the slot held up every ring fragment behind them (the first eight
+    // elements took 6.7 k cycles against 3.9 k for the second eight), and in front of the exchange they held up its
+    // counter poll (4.4 k).  Here only the ring refills issued after them can be delayed, and those are not needed
+    // for four elements.
+    auto prefetch_next = [&]() {
+      if (tn >= 0) {
+        const int64_t rbn = (tile0 + Y) * steps + tn;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gd[Y].load(g, zaddr(rbn, g));
+        cprev[Y].load(caddr(tn > 0 ? rbn - 1 : rbn));
+        dhr[Y][0] = dh_ld(rbn, 0);
+        dhr[Y][1] = dh_ld(rbn, 1);
+      }
+    };
+    float dhv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dhv[r] = dj_to_f32(dhx[dj_crow(r, lane) * LDP + w * 32 + l31]) + acc[X][r];
+    if constexpr (do_p) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[Y][r] = 0.f;
+    }
+    const T* ap_own = dzy + l31 * R::LDZ + HP * part;
+    const T* ap_oth = dzy + l31 * R::LDZ + HP * (1 - part);
+    // opaque per slot (as loop invariants hipcc keeps all 64 fragment addresses in registers) -- through an OFFSET:
+    // a laundered pointer loses its address space and every fragment load becomes a flat_load, which hipcc can only
+    // wait for with vmcnt(0) lgkmcnt(0), i.e. each group of products waited for the refills issued just before it
+    int64_t uoff = 0;
+    asm volatile("" : "+v"(uoff));
+    const Frag *uo = up_own + uoff, *ut = up_oth + uoff;
+    const int u = wb * 32 + l31;
+    Frag an[4];
+    auto afrag_read = [&](int rr) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pos = 4 * rr + j, i = pos & 31;
+        an[j] = dj_lds_frag((pos < 32 ? ap_own : ap_oth) + 256 * (i / 8) + 16 * (i % 8), h);
+      }
+    };
+    if constexpr (do_p) afrag_read(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (r == 8) {
+        if constexpr (!do_p) prefetch_next();
+        if constexpr (do_p) {
+          // the partner's half of dz_Y(ty): stored half a slot ago, fetched into the LDS tile now
+          const int target = BP_ARR * ((steps - ty) + (Y == 0 ? 1 : 0));
+          if (!cl_wait(line + Y, target, lane)) {
+            if (lane == 0) atomicAdd(fault, 1);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) dcc[Y][q] = __builtin_nanf("");
+          }
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("" ::: "memory");
+          const bf16_t* gsrc = dZ + rby * 32 * ldz;
+          uint4 pz[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            int lo;
+            const int64_t go = dz_off(i, 1 - part, lo);
+            pz[i] = ld_sc1((const uint4*)(gsrc + go));
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            int lo;
+            dz_off(i, 1 - part, lo);
+            *(uint4*)(dzy + lo) = pz[i];
+          }
+          asm volatile("" ::: "memory");
+          prefetch_next();
+        }
+        lds_barrier();       // the partner's half of dz_Y is in LDS (every wave passes here, product or not)
+        if constexpr (do_p) afrag_read(8);
+      }
+      {
+        const int row = dj_crow(r, lane);
+        float ig, fg, gg, og, di, df, dO;
+        gd[X].get(r, ig, fg, gg, og, di, df, dO);
+        const float ct = cnext[X].get(r);
+        const float cp = (t > 0) ? cprev[X].get(r) : 0.f;
+        const float dh = dhv[r];
+        const float tc = dj_tanh(ct);
+        const float dzo = dh * tc * dO;
+        const float dc = dcc[X][r] + dh * og * (1.f - tc * tc);
+        const float dzi = dc * gg * di;
+        const float dzf = dc * cp * df;
+        const float dzg = dc * ig * (1.f - gg * gg);
+        dcc[X][r] = dc * fg;
+        T* dp = dzx + row * R::LDZ + u;
+        dj_lds_put2(dp, dp + H, dzi, dzf);
+        dj_lds_put2(dp + 2 * H, dp + 3 * H, dzg, dzo);
+        dbs[0] += dzi;
+        dbs[1] += dzf;
+        dbs[2] += dzg;
+        dbs[3] += dzo;
+      }
+      if constexpr (do_p) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int pos = 4 * r + j;                                   // 0..31 own half, 32..63 the partner's
+          dj_mfma(acc[Y], an[j], bq[pos % RD]);
+          const int pn = (pos + RD) & 63, in = pn & 31;                // the stream repeats every slot
+          bq[pos % RD] = (pn < 32 ? uo : ut)[choff(in)];
+        }
+        // the A fragments of the next group are read a whole element ahead (read right in front of their MFMAs they
+        // cost an LDS round trip per pair); the partner half's first group (element 8) is read behind the mid barrier
+        if (r != 7 && r != 15) afrag_read(r + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (t > 0) cnext[X].copy_from(cprev[X]);
+    if (tn >= 0) {           // stage dH of the next gate slot
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int v = tid + 256 * i, row = v >> 4, cv = (v & 15) * 8;
+        *(uint4*)(dhy + row * LDP + cv) = dhr[Y][i];
+      }
+    }
+    lds_barrier();           // dz_X(t), own half, complete in LDS; dH staged; every wave has left this slot's LDS reads
+    bf16_t* gdst = dZ + rbx * 32 * ldz;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int lo;
+      const int64_t go = dz_off(i, part, lo);
+      *(uint4*)(gdst + go) = *(const uint4*)(dzx + lo);
+    }
+    if (t > 0) {             // the stores are the exchange: acknowledged, this wave arrives on tile X's counter
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(line + X, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+
+  // prologue: the stash of G_A(steps - 1), its dH staged
+  {
+    const int64_t rb = tile0 * steps + steps - 1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gd[0].load(g, zaddr(rb, g));
+    cnext[0].load(caddr(rb));
+    cnext[1].load(caddr((tile0 + 1) * steps + steps - 1));
+    if (steps > 1) cprev[0].load(caddr(rb - 1));
+    T* const dh0 = lds + 32 * R::LDZ;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = tid + 256 * i, row = v >> 4, cv = (v & 15) * 8;
+      *(uint4*)(dh0 + row * LDP + cv) = dh_ld(rb, i);
+    }
+    lds_barrier();
+  }
+  // slot A(t) carries the product of B at t + 1, slot B(t) that of A at t: the first and the last slot have none
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  slot(I0{}, std::false_type{}, steps - 1);
+  for (int t = steps - 1; t > 0; --t) {
+    slot(I1{}, std::true_type{}, t);
+    slot(I0{}, std::true_type{}, t - 1);
+  }
+  slot(I1{}, std::false_type{}, 0);
   if (dbias) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -2306,6 +2583,61 @@ int launch_bwd_pair(int ntiles, int steps, const void* Z, const void* UTpack, co
   return 0;
 }
 
+// BPTT of a bf16 H = 256 layer with two tiles per workgroup pair (lstm_bwd_dual_kernel): one workgroup per compute unit
+// (150 KB of LDS), at most `compute units` tiles per launch, an even number of them (an odd last tile takes the
+// per-tile kernel).  Returns 1017 when the device cannot hold a group of 16 workgroups.
+template <typename T, int H, int DX>
+int launch_bwd_x(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
+                 int64_t dz_cts_in, float* dbias, int sigm, const void* WTpack, int NQ, void* dX, int DP, hipStream_t st);
+int launch_bwd_dual(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
+                    int64_t dz_cts_in, float* dbias, int sigm, void* scratch, hipStream_t st) {
+  using R = RecCfg<bf16_t, 256>;
+  constexpr int H = 256;
+  if (!scratch || ((uintptr_t)scratch & 127)) return 1016;
+  const int64_t dz_cts = dz_cts_in ? dz_cts_in : 256;
+  const int ldz = dz_cts_in ? 256 : 4 * H;
+  if (dz_cts_in && dz_cts_in < (int64_t)ntiles * steps * 32 * 256) return 1018;
+  const int cap = cluster_cus() / 16 * 16 < 2 * BP_MAXPAIRS ? cluster_cus() / 16 * 16 : 2 * BP_MAXPAIRS;   // tiles per launch
+  if (cap < 16) return 1017;
+  const size_t smem = (size_t)2 * (32 * R::LDZ + 32 * (128 + 8)) * sizeof(bf16_t);
+  static bool attr_done_dev[DJ_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[dj_current_device()];
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_dual_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)lstm_bwd_dual_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  const uint8_t* z = (const uint8_t*)Z;
+  const bf16_t *c = (const bf16_t*)C, *dh = (const bf16_t*)dH;
+  bf16_t* dz = (bf16_t*)dZ;
+  int left = ntiles & ~1;
+  while (left > 0) {
+    const int n = left < cap ? left : cap;
+    hipLaunchKernelGGL(cl_reset_kernel, dim3(BP_BYTES / (256 * 16)), dim3(256), 0, st,
+                       (uint4*)((unsigned char*)scratch + BP_OFF_CNT));
+    if (int rc = cluster_fault_hook(scratch, st)) return rc;
+    const dim3 grid((n / 2 + 7) / 8 * 16);
+    if (sigm)
+      hipLaunchKernelGGL((lstm_bwd_dual_kernel<true>), grid, dim3(256), smem, st, z, (const bf16_t*)UTpack, c, dh, dz, dbias,
+                         steps, dz_cts, ldz, (int*)scratch, n);
+    else
+      hipLaunchKernelGGL((lstm_bwd_dual_kernel<false>), grid, dim3(256), smem, st, z, (const bf16_t*)UTpack, c, dh, dz, dbias,
+                         steps, dz_cts, ldz, (int*)scratch, n);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
+    const int64_t rows = (int64_t)n * steps * 32;
+    z += rows * 4 * H;
+    c += rows * H;
+    dh += rows * H;
+    dz += rows * ldz;
+    left -= n;
+  }
+  if (ntiles & 1)      // the odd last tile: per-tile kernel on the same buffers (dz_cts counts from the buffer's start)
+    return launch_bwd_x<bf16_t, 256, 0>(1, steps, z, UTpack, c, dh, dz, dz_cts_in, dbias, sigm, nullptr, 0, nullptr, 0, st);
+  return 0;
+}
+
 }  // namespace
 
 // fp32 H = 256 inference sweep of at most 8 tiles on clusters of 8 workgroups (lstm_fwd_cluster_f32_kernel).  Returns
@@ -2372,11 +2704,13 @@ int64_t dj_lstm_stash_row_bytes(int dtype, int H) { return (int64_t)4 * H * (dty
 int64_t dj_lstm_cluster_scratch_bytes_impl() { return (int64_t)CL_BYTES_ALL; }
 int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* UTpack, const void* C,
                        const void* dH, void* dZ, int64_t dz_cts, float* dbias, int sigm, const void* WTpack, int D, void* dX,
-                       int DP, void* cluster_scratch, hipStream_t st) {
+                       int DP, void* cluster_scratch, int bwd_mode, hipStream_t st) {
   if (ntiles <= 0 || steps <= 0) return 0;
-  // bf16 H = 256 (time axis): two workgroups per tile where the device holds the grid (lstm_bwd_pair_kernel)
+  // bf16 H = 256 (time axis): two workgroups per tile (lstm_bwd_pair_kernel), or two tiles per workgroup pair with the
+  // product of one folded into the gate math of the other (lstm_bwd_dual_kernel), where the device holds the grid
   if (cluster_scratch && dtype == DJ_BF16 && H == 256 && !WTpack) {
-    const int rc = launch_bwd_pair(ntiles, steps, Z, UTpack, C, dH, dZ, dz_cts, dbias, sigm, cluster_scratch, st);
+    const int rc = bwd_mode == 2 ? launch_bwd_dual(ntiles, steps, Z, UTpack, C, dH, dZ, dz_cts, dbias, sigm, cluster_scratch, st)
+                                 : launch_bwd_pair(ntiles, steps, Z, UTpack, C, dH, dZ, dz_cts, dbias, sigm, cluster_scratch, st);
     if (rc != 1017) return rc;
   }
   const int NQ = (D + 31) / 32;

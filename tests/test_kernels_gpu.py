@@ -304,11 +304,12 @@ def test_lstm_fwd_bwd(gpu_device, dtype, H, S, Ls, sigm):
         # the same sweep on PAIRS of workgroups (dj_lstm_bwd_pair: what the training step uses for the time axis): both
         # dZ layouts, against the per-tile kernel (same numbers up to the summation order of dz U^T) and the oracle
         cl = torch.zeros(lib.dj_lstm_cluster_scratch_bytes(), dtype=torch.uint8, device=gpu_device)
-        for cts_p in (0, cts):
+        for cts_p, entry in ((0, lib.dj_lstm_bwd_pair), (cts, lib.dj_lstm_bwd_pair), (0, lib.dj_lstm_bwd_dual),
+                             (cts, lib.dj_lstm_bwd_dual)):
             dZp = torch.zeros((4 * H // 256) * cts if cts_p else R * 4 * H, dtype=Zd.dtype, device=gpu_device)
             db3 = torch.zeros_like(db)
-            L.check(lib.dj_lstm_bwd_pair(DT[dtype], H, tiles, Ls, L.ptr(Gd), L.ptr(upb), L.ptr(Cd), L.ptr(dHd), L.ptr(dZp),
-                                         cts_p, L.ptr(db3), sigm, L.ptr(cl), _st()), "bwd pair")
+            L.check(entry(DT[dtype], H, tiles, Ls, L.ptr(Gd), L.ptr(upb), L.ptr(Cd), L.ptr(dHd), L.ptr(dZp),
+                          cts_p, L.ptr(db3), sigm, L.ptr(cl), _st()), "bwd pair / dual")
             torch.cuda.synchronize()
             assert lib.dj_lstm_cluster_faults(L.ptr(cl)) == 0
             if cts_p:
@@ -326,11 +327,13 @@ def test_lstm_fwd_bwd(gpu_device, dtype, H, S, Ls, sigm):
                                     L.ptr(db), sigm, L.ptr(cl), _st()) >= 1000
 
 
-@pytest.mark.parametrize("tiles,Ls", [(8, 4), (9, 1), (17, 33), (64, 6), (300, 3)])
-def test_lstm_bwd_pair_tile_counts(gpu_device, tiles, Ls):
-    """dj_lstm_bwd_pair against dj_lstm_bwd on the same (random) stash / cell states / upstream gradient: pair groups
-    that are full, partly filled and absent; a single step (no exchange at all); more tiles than one launch holds
-    (300 > 256: two launches); column-tile-major dZ.  The two kernels sum dz U^T in a different k order, so dz agrees
+@pytest.mark.parametrize("entry", ["dj_lstm_bwd_pair", "dj_lstm_bwd_dual"])
+@pytest.mark.parametrize("tiles,Ls", [(8, 4), (9, 1), (17, 33), (2, 2), (64, 6), (301, 3)])
+def test_lstm_bwd_pair_tile_counts(gpu_device, tiles, Ls, entry):
+    """dj_lstm_bwd_pair / dj_lstm_bwd_dual (two tiles per workgroup pair, interleaved) against dj_lstm_bwd on the same
+    (random) stash / cell states / upstream gradient: pair groups that are full, partly filled and absent; a single
+    step (no exchange at all); odd tile counts (the dual form hands its last tile to the per-tile kernel); more tiles
+    than one launch holds (301 > 256: two launches); column-tile-major dZ.  The two kernels sum dz U^T in a different k order, so dz agrees
     to bf16 rounding of nearly equal fp32 sums, not bit for bit."""
     L, lib = _lib()
     H, R = 256, tiles * Ls * 32
@@ -348,8 +351,8 @@ def test_lstm_bwd_pair_tile_counts(gpu_device, tiles, Ls):
         dZ = torch.zeros(4 * cts, dtype=torch.bfloat16, device=gpu_device)
         db = torch.zeros(4 * H, dtype=torch.float32, device=gpu_device)
         if pair:
-            L.check(lib.dj_lstm_bwd_pair(1, H, tiles, Ls, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ), cts,
-                                         L.ptr(db), 0, L.ptr(cl), _st()), "bwd pair")
+            L.check(getattr(lib, entry)(1, H, tiles, Ls, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ), cts,
+                                        L.ptr(db), 0, L.ptr(cl), _st()), entry)
         else:
             L.check(lib.dj_lstm_bwd(1, H, tiles, Ls, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ), cts, L.ptr(db),
                                     0, _st()), "bwd")

@@ -143,7 +143,7 @@ def test_train_step_bf16_scaled_widths(gpu_device):
     assert worst < BF16_GRAD_TOL, sorted(rows, key=lambda r: -r[1])[:6]
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16-bwd-pair"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "bf16-bwd-pair", "bf16-bwd-dual"])
 def test_train_step_production_kernels_vs_oracle(gpu_device, djenv, dtype):
     """The kernel selection of the bench shape, as ONE forward + BPTT step against the oracle, dropout on:
     B16 x T16 x N128 gives 64 time-axis sequence tiles, so bf16 runs the weight-stationary cluster kernel
@@ -151,8 +151,8 @@ def test_train_step_production_kernels_vs_oracle(gpu_device, djenv, dtype):
     forced onto its fused x*W / fused dX kernels.  fp32 at the north_star tolerance, bf16 at bf16 tolerance.
     "bf16-bwd-pair": the same step with the time-axis BPTT on workgroup pairs (DEEPJ_BWD_PAIR=1, opt-in)."""
     djenv.set("DEEPJ_FUSE_XW_MIN_TILES", "1")
-    if dtype == "bf16-bwd-pair":
-        djenv.set("DEEPJ_BWD_PAIR", "1")
+    if dtype in ("bf16-bwd-pair", "bf16-bwd-dual"):
+        djenv.set("DEEPJ_BWD_PAIR" if dtype.endswith("pair") else "DEEPJ_BWD_DUAL", "1")
         dtype = "bf16"
     B, T, seed, pin, pdr = 16, 16, 1234567, 0.2, 0.5
     ocfg, dcfg = _cfgs(time_steps=T, num_notes=128, dtype=dtype)

@@ -1,5 +1,5 @@
-"""Dev tool: the H = 256 BPTT sweep alone at the BASELINE shape (256 tiles x 128 steps): per-tile kernel vs workgroup
-pairs, HIP-event times, and how many pairs had both members on one compute unit (fault word 3 of the scratch).
+"""Dev tool: the H = 256 BPTT sweep alone at the BASELINE shape (256 tiles x 128 steps): per-tile kernel (0) vs workgroup
+pairs (1) vs two tiles per pair, interleaved (2), HIP-event times, and how many pairs had both members on one compute unit (fault word 3 of the scratch).
     DEEPJ_BWD_PAIR_FAR=0|1 python tools/bwd_pair_probe.py [tiles] [steps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,12 +25,14 @@ db = torch.zeros(4 * H, dtype=torch.float32, device=dev)
 cl = torch.zeros(lib.dj_lstm_cluster_scratch_bytes(), dtype=torch.uint8, device=dev)
 
 def run(pair):
-    if pair:
+    if pair == 2:
+        L.check(lib.dj_lstm_bwd_dual(1, H, tiles, steps, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ), cts, L.ptr(db), 0, L.ptr(cl), st), "dual")
+    elif pair:
         L.check(lib.dj_lstm_bwd_pair(1, H, tiles, steps, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ), cts, L.ptr(db), 0, L.ptr(cl), st), "pair")
     else:
         L.check(lib.dj_lstm_bwd(1, H, tiles, steps, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ), cts, L.ptr(db), 0, st), "bwd")
 
-for pair in (False, True, False, True):
+for pair in (0, 1, 2, 0, 1, 2):
     for _ in range(3):
         run(pair)
     torch.cuda.synchronize()
