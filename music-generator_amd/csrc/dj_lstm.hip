@@ -679,13 +679,18 @@ __device__ __forceinline__ void cl_load_x(ClXRegs<NR>& q, const bf16_t* xb, int 
       q.v[r][i] = ok ? v : make_uint4(0, 0, 0, 0);
     }
 }
+// Bound of every exchange wait, in shader-clock cycles: ~100 ms.  Hang protection only -- a healthy step meets in
+// microseconds.  (It was ~10 ms until a 1024-step step-wise generation run lost 6 waits on one test box in two
+// consecutive calls and none in the next two on other boxes, with byte-identical kernels: a member's workgroup can be
+// held up for milliseconds by things outside the process.)
+constexpr unsigned long long CL_WAIT_CYCLES = 200000000ull;
 // bounded wait of one wave for its cluster's counter (lane 0 polls); false = expired
 __device__ __forceinline__ bool cl_wait(int* cnt, int target, int lane) {
   int ok = 1;
   if (lane == 0) {
     const unsigned long long t0 = __builtin_readcyclecounter();
     while ((ok = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) == 0 &&
-           __builtin_readcyclecounter() - t0 < 20000000ull)       // ~10 ms: hang protection only
+           __builtin_readcyclecounter() - t0 < CL_WAIT_CYCLES)    // hang protection only
       __builtin_amdgcn_s_sleep(2);
   }
   return __builtin_amdgcn_readfirstlane(ok) != 0;
@@ -709,7 +714,7 @@ __device__ __forceinline__ int cl_wait_val(int* cnt, int target, int lane) {
   if (lane == 0) {
     const unsigned long long t0 = __builtin_readcyclecounter();
     while ((v = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target &&
-           __builtin_readcyclecounter() - t0 < 20000000ull)
+           __builtin_readcyclecounter() - t0 < CL_WAIT_CYCLES)
       __builtin_amdgcn_s_sleep(2);
     if (v < target) v = 0;
   }
@@ -1701,30 +1706,36 @@ __global__ __launch_bounds__((BwdCfg<T, H>::NT)) void lstm_bwd_kernel(const Stas
             dj_mfma(acc[0], a, ulw[kc * 64]);
           }
         }
-        // all blocks but the last refill the ring; the last block only drains it
-        constexpr int KMAIN = TAILPF ? R::NKCB - R::UNRB : R::NKCB;
+        // Blocks of UNRB chunks; every block but the last refills the ring PDB chunks ahead, the last one only where
+        // the stream still has chunks (none past NKCB: the clamped refills of the last block used to re-request chunk
+        // NKCB - 1 eight times per step and wave, 12 % of the streamed bytes).  The stream pointer and the A pointer
+        // advance once per block and every chunk sits at a compile-time offset from them: with a run-time chunk
+        // index hipcc computed a 64-bit address per fragment load (3-4 vector instructions per chunk) and issued the
+        // block's eight loads together behind its last MFMA.
+        constexpr int NBLK = (R::NKCB - KL) / R::UNRB;
+        const Frag* upk = up + KL * 64;
+        const T* apk = ap + KL * R::KC;
 #pragma unroll 1
-        for (int kc0 = KL; kc0 < KMAIN; kc0 += R::UNRB) {
+        for (int blk = 0; blk < NBLK - 1; ++blk) {
 #pragma unroll
           for (int u = 0; u < R::UNRB; ++u) {
-            const int kc = kc0 + u;
-            Frag a = dj_lds_frag(ap + kc * R::KC, h);
+            Frag a = dj_lds_frag(apk + u * R::KC, h);
 #pragma unroll
             for (int j = 0; j < R::NJ; ++j) dj_mfma(acc[j], a, bq[u % R::PDB][j]);
-            const int kn = (kc + R::PDB < R::NKCB) ? kc + R::PDB : R::NKCB - 1;
 #pragma unroll
-            for (int j = 0; j < R::NJ; ++j) bq[u % R::PDB][j] = up[(j * R::NKCB + kn) * 64];
+            for (int j = 0; j < R::NJ; ++j) bq[u % R::PDB][j] = upk[(j * R::NKCB + u + R::PDB) * 64];
           }
+          upk += R::UNRB * 64;
+          apk += R::UNRB * R::KC;
         }
-        if constexpr (TAILPF) {
-          static_assert(R::UNRB == R::PDB, "the drained block must be exactly the ring");
-          stash_prefetch(rb, t);       // every U^T fragment has been requested: the stash of step t-1 goes next
-          DJ_DH_LOAD(rb - 1);
 #pragma unroll
-          for (int u = 0; u < R::UNRB; ++u) {
-            Frag a = dj_lds_frag(ap + (KMAIN + u) * R::KC, h);
+        for (int u = 0; u < R::UNRB; ++u) {
+          Frag a = dj_lds_frag(apk + u * R::KC, h);
 #pragma unroll
-            for (int j = 0; j < R::NJ; ++j) dj_mfma(acc[j], a, bq[u % R::PDB][j]);
+          for (int j = 0; j < R::NJ; ++j) dj_mfma(acc[j], a, bq[u % R::PDB][j]);
+          if (u + R::PDB < R::UNRB) {
+#pragma unroll
+            for (int j = 0; j < R::NJ; ++j) bq[u % R::PDB][j] = upk[(j * R::NKCB + u + R::PDB) * 64];
           }
         }
       }

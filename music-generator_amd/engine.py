@@ -175,13 +175,22 @@ class Engine:
             self.loss[1:].zero_()
         return m
 
+    def cluster_fault_words(self):
+        """(expired waits, clusters spread over several XCDs) recorded in this engine's workspace, without resetting
+        them (dj_workspace_cluster_fault_words); synchronises."""
+        words = (C.c_int32 * 2)()
+        with torch.cuda.device(self.device):
+            rc = self.lib.dj_workspace_cluster_fault_words(C.byref(self.c), self.ws_ptr, self.ws_bytes, words)
+        return (int(words[0]), int(words[1])) if rc == 0 else (-1, -1)
+
     def raise_on_cluster_faults(self, what):
+        words = self.cluster_fault_words()
         n = self.cluster_faults()
         if n:
             raise _lib.DeepJError(
-                "%s: %d cluster faults in the recurrent forward kernel (device shared with other kernels, or "
-                "workgroups not dealt round-robin over the XCDs); the results are NaN.  Set DEEPJ_CLUSTER=0 to use "
-                "the per-tile kernel." % (what, n))
+                "%s: %d cluster faults in the recurrent forward kernel (%d expired waits: device shared with other "
+                "kernels; %d clusters whose workgroups were not dealt round-robin over the XCDs); the results are NaN.  "
+                "Set DEEPJ_CLUSTER=0 to use the per-tile kernel." % (what, n, words[0], words[1]))
 
     # -- shapes
     def _shapes(self):

@@ -101,6 +101,7 @@ GEN_CHUNK = 4 * NOTES_PER_BAR
 # "Sampling parity"); otherwise the rolls are certified up to `first_near_tie_step`.
 # `max_temperature` / `silent_steps`: the heating schedule of end_time() as the run saw it (host MusicGeneration state).
 last_run_stats = {"draws": 0, "near_ties": 0, "first_near_tie_step": -1, "max_temperature": 1.0, "silent_steps": 0}
+repeated_steps = 0      # step-wise steps computed twice because of a cluster fault (process total; 0 in a healthy run)
 
 
 def _note_schedule(pieces):
@@ -139,10 +140,20 @@ def _fused_step(shared, engine, pieces):
     notes, beat, style = process_inputs([g.build_time_inputs() for g in pieces])
     u_dev = torch.as_tensor(_draw_ahead(2 * NUM_NOTES * len(pieces)), dtype=torch.float64).to(be.device)
     temps = be.tensor(np.array([g.temperature for g in pieces], np.float32))
-    nxt, used = engine.generate_step(shared.params, be.tensor(notes), be.tensor(beat), be.tensor(style), u_dev, temps)
+    args = (shared.params, be.tensor(notes), be.tensor(beat), be.tensor(style), u_dev, temps)
+    nxt, used = engine.generate_step(*args)
     nxt = be.numpy(nxt)
     used = used.cpu().numpy()
-    if hasattr(engine, "raise_on_cluster_faults"):        # NaN-poisoned rows would be sampled as silence
+    if hasattr(engine, "cluster_faults") and engine.cluster_faults():
+        # NaN-poisoned rows would be sampled as silence: never used.  The step has no device-side state (windows,
+        # temperatures and uniforms are its inputs), so it is simply computed again, once; a second fault raises.
+        print("[deepj] generation: cluster fault in a time step (an exchange wait expired); repeating the step",
+              flush=True)
+        global repeated_steps
+        repeated_steps += 1
+        nxt, used = engine.generate_step(*args)
+        nxt = be.numpy(nxt)
+        used = used.cpu().numpy()
         engine.raise_on_cluster_faults("generation")
     np.random.random_sample(int(used[0]))
     last_run_stats["draws"] += int(used[0])
