@@ -473,37 +473,49 @@ def main():
     B, T, N = args.batch, args.time_steps, args.notes
     pin, pdr = args.dropout or (0.2, 0.5)                # model.py:128 defaults
     cfg = DeepJConfig(num_notes=N, time_steps=T, dtype=args.dtype)
-    eng = Engine(cfg, B, T, device=dev, input_dropout=pin, dropout=pdr)
-    P = torch.from_numpy(init_params_numpy(cfg, seed=1234)).to(dev)     # replicated weights
-    G = torch.zeros_like(P)
-    opt = Nadam(P.numel(), dev)
+    lib = _lib.load()
     notes, chosen, beat, style, target = [torch.from_numpy(a).to(dev)
                                           for a in synthetic_batch(N, T, B, seed=rank)]
-    lib = _lib.load()
-    step = make_step(eng, opt, P, G, (notes, chosen, beat, style, target), world, rank, dist)
+    fallback_faults = 0
+    for attempt in (0, 1):
+        # attempt 1 only after cluster faults in attempt 0 (an exchange wait of the weight-stationary forward sweep
+        # expired: the device was not this job's alone): the same run on the per-tile kernels, as Model.fit falls back
+        eng = Engine(cfg, B, T, device=dev, input_dropout=pin, dropout=pdr,
+                     kernel_flags=_lib.KF_NO_CLUSTER if attempt else 0)
+        P = torch.from_numpy(init_params_numpy(cfg, seed=1234)).to(dev)     # replicated weights
+        G = torch.zeros_like(P)
+        opt = Nadam(P.numel(), dev)
+        step = make_step(eng, opt, P, G, (notes, chosen, beat, style, target), world, rank, dist)
 
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    if not args.no_profile:
-        lib.dj_profile_enable(1)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    final_loss = float(loss.cpu()[0])
-    faults = eng.cluster_faults()
-    if world > 1:
-        f = torch.tensor([float(faults)], dtype=torch.float64, device=dev)
-        dist.all_reduce(f)
-        faults = int(f.cpu()[0])
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if not args.no_profile:
+            lib.dj_profile_enable(1)         # (also clears the categories of a first attempt)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss = step(args.warmup + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        final_loss = float(loss.cpu()[0])
+        faults = eng.cluster_faults()
+        if world > 1:
+            f = torch.tensor([float(faults)], dtype=torch.float64, device=dev)
+            dist.all_reduce(f)
+            faults = int(f.cpu()[0])
+        if not faults or attempt == 1:
+            break
+        fallback_faults = faults
+        if rank == 0:
+            print(f"[bench] {faults} cluster faults in the timed run: repeating it on the per-tile kernels "
+                  "(DJ_KF_NO_CLUSTER)", file=sys.stderr, flush=True)
+        del eng, step
     if faults or not np.isfinite(final_loss):
         raise SystemExit(f"invalid run: {faults} cluster faults, final loss {final_loss} -- no number is reported "
                          "(DEEPJ_CLUSTER=0 selects the per-tile kernel)")
@@ -576,7 +588,9 @@ def main():
                                    f"Nadam; random-init weights",
                        "global_batch": B * world, "seq_len": T, "num_notes": N, "parallelism": f"dp{world}",
                        **({"rehearsal": f"backend {backend}, all ranks on one device: not a measurement"}
-                          if (backend != "nccl" or os.environ.get("DEEPJ_BENCH_ONE_DEVICE") == "1") else {})},
+                          if (backend != "nccl" or os.environ.get("DEEPJ_BENCH_ONE_DEVICE") == "1") else {}),
+                       **({"kernels": f"per-tile forward kernels (DJ_KF_NO_CLUSTER) after {fallback_faults} cluster "
+                                      "faults in a first timed run"} if fallback_faults else {})},
             "model_tflops_per_s": round(flops_step * world * args.steps / elapsed / 1e12, 2),
             "final_loss": round(final_loss, 5),
             "roofline": roof, "kernel_ms_per_step": kernels, "kernel_rates": roof_all,
