@@ -270,3 +270,50 @@ def test_cluster_fault_repeats_the_step_on_the_per_tile_kernel(monkeypatch, caps
     with pytest.raises(RuntimeError, match="cluster faults"):
         model.train_on_batch(x, y)
     assert all(np.array_equal(a, b) for a, b in zip(before, model.get_weights()))     # nothing was applied
+
+
+def test_stepwise_generation_repeats_a_faulted_step_once():
+    """generate._fused_step: a time step whose device call reports a cluster fault (NaN-poisoned rows would be sampled
+    as silence) is computed again, once -- it has no device-side state -- and a second fault raises.  Fake engine on
+    the CPU: the host logic only."""
+    import types
+    import torch
+    from music_generator_amd import generate as Gn
+    from music_generator_amd.constants import NUM_NOTES
+    from music_generator_amd.dataset import compute_genre
+
+    class FakeEngine:
+        def __init__(self, faults):
+            self.faults, self.calls = list(faults), 0
+
+        def generate_step(self, params, notes, beat, style, u, temps):
+            self.calls += 1
+            g = notes.shape[0]
+            nxt = torch.zeros(g, NUM_NOTES, 3)
+            nxt[:, 5, 0] = float(self.calls)          # which call produced the notes that are used
+            return nxt, torch.tensor([g * NUM_NOTES + g, 0], dtype=torch.int32)
+
+        def cluster_faults(self):
+            return self.faults.pop(0) if self.faults else 0
+
+        def raise_on_cluster_faults(self, what):
+            if self.cluster_faults():
+                raise RuntimeError("cluster faults in " + what)
+
+    be = types.SimpleNamespace(device=torch.device("cpu"), tensor=lambda a: torch.as_tensor(np.asarray(a, np.float32)),
+                               numpy=lambda t: t.numpy())
+    shared = types.SimpleNamespace(backend=be, params=None)
+    pieces = [Gn.MusicGeneration(compute_genre(i)) for i in range(2)]
+    before = Gn.repeated_steps
+    np.random.seed(1)
+    eng = FakeEngine([0])                                   # healthy: one call
+    Gn._fused_step(shared, eng, pieces)
+    assert eng.calls == 1 and pieces[0].next_note[5, 0] == 1.0 and Gn.repeated_steps == before
+    eng = FakeEngine([3, 0])                                # one fault: the step is repeated, the second result is used
+    pos = np.random.get_state()[2]
+    Gn._fused_step(shared, eng, pieces)
+    assert eng.calls == 2 and pieces[0].next_note[5, 0] == 2.0 and Gn.repeated_steps == before + 1
+    assert np.random.get_state()[2] != pos                  # the draws were consumed once, after the clean result
+    eng = FakeEngine([1, 1])                                # the repeat faults too: never silent
+    with pytest.raises(RuntimeError):
+        Gn._fused_step(shared, eng, pieces)
