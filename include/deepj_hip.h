@@ -111,9 +111,13 @@ int32_t dj_train_fwd_bwd_acc(const dj_config* cfg, const float* params, float* g
  * full_batch in dj_nadam_step, loss = mean of the calls' losses for equal sizes) the result is the gradient of ONE step
  * on the full batch -- the scaled model's batch of 128 in two halves through one workspace (tests: against the oracle at
  * the full batch).  bins_full == NULL (then full_batch = batch_offset = 0) is dj_train_fwd_bwd_acc.  Code 1211: bad
- * offsets. */
+ * offsets.  dj_pitch_bins' own batch_offset is 0 for a whole batch; a data-parallel rank that holds samples
+ * [batch_offset, batch_offset + cfg->batch) of the GLOBAL batch computes its part of the table with it (the input
+ * dropout mask is the global batch's), the parts are all-gathered along the sample axis and every rank then runs
+ * dj_train_fwd_bwd_mb against the global table: N ranks = one step of the reference on the global batch, exactly
+ * (Model.fit with DEEPJ_DDP_EXACT=1). */
 int32_t dj_pitch_bins(const dj_config* cfg_full, const float* notes_full, float* bins_full, uint64_t seed, int32_t train,
-                      void* stream);
+                      int32_t batch_offset, void* stream);
 int32_t dj_train_fwd_bwd_mb(const dj_config* cfg, const float* params, float* grads, const float* notes,
                             const float* chosen, const float* beat, const float* style, const float* target, float* out,
                             float* loss, void* workspace, int64_t workspace_bytes, uint64_t seed, int32_t accumulate,

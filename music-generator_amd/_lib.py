@@ -50,7 +50,7 @@ _SIGS = {
                                      C.c_uint64, C.c_int32, _P]),
     "dj_train_fwd_bwd_mb": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64,
                                         C.c_uint64, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
-    "dj_pitch_bins": (C.c_int32, [C.POINTER(DjConfig), _P, _P, C.c_uint64, C.c_int32, _P]),
+    "dj_pitch_bins": (C.c_int32, [C.POINTER(DjConfig), _P, _P, C.c_uint64, C.c_int32, C.c_int32, _P]),
     "dj_nadam_step": (C.c_int32, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_float, C.c_float,
                                   C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "dj_predict": (C.c_int32, [C.POINTER(DjConfig), _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),

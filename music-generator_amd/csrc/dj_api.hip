@@ -643,11 +643,16 @@ int32_t dj_train_fwd_bwd_acc(const dj_config* cfg, const float* params, float* g
 }
 
 // pitch_bins table of a whole batch (model.py:43-45): bins[i, b, t] = sum_k dropped_notes[b, t, i + 12 k, 0]
-int32_t dj_pitch_bins(const dj_config* cfg, const float* notes, float* bins, uint64_t seed, int32_t train, void* stream) {
+int32_t dj_pitch_bins(const dj_config* cfg, const float* notes, float* bins, uint64_t seed, int32_t train,
+                      int32_t batch_offset, void* stream) {
   Plan p;
   RUN(make_plan(cfg, p));
   if (!notes || !bins) return 1210;
-  return dj_launch_bins(notes, bins, p.B, p.T, p.N, p.c.octave, mkdrop(seed, DJ_SITE_NOTES, p.c.input_dropout, train != 0),
+  if (batch_offset < 0) return 1211;
+  // the input-dropout mask of these samples is the one of rows batch_offset * T * N ... of the batch they belong to
+  return dj_launch_bins(notes, bins, p.B, p.T, p.N, p.c.octave,
+                        mkdrop(seed, DJ_SITE_NOTES, p.c.input_dropout, train != 0,
+                               (uint32_t)((int64_t)batch_offset * p.T * p.N)),
                         (hipStream_t)stream);
 }
 

@@ -201,16 +201,18 @@ class Engine:
         if tuple(t.shape) != tuple(shape):
             raise ValueError(f"{what}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
 
-    def pitch_bins(self, notes_full, seed=0, train=True):
+    def pitch_bins(self, notes_full, seed=0, train=True, batch_offset=0):
         """pitch_bins table [octave, B_full, T] of a WHOLE batch (model.py:43-45; dj_pitch_bins): what the micro-batches
-        of that batch read through train_fwd_bwd(..., full_batch=, batch_offset=, bins_full=)."""
+        of that batch read through train_fwd_bwd(..., full_batch=, batch_offset=, bins_full=).  batch_offset: these
+        samples are rows batch_offset... of a larger (global) batch -- a data-parallel rank's part of the table."""
         bfull, T = int(notes_full.shape[0]), self.time_steps
         self._check(notes_full, (bfull, T, self.cfg.num_notes, self.cfg.note_units), "notes_full")
         cfull = self.cfg.cstruct(bfull, T, self.c.input_dropout, self.c.dropout, self.c.kernel_flags)
         bins = torch.empty((self.cfg.octave, bfull, T), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.dj_pitch_bins(C.byref(cfull), _lib.ptr(notes_full), _lib.ptr(bins),
-                                              C.c_uint64(int(seed) & (2 ** 64 - 1)), 1 if train else 0, _stream_ptr()),
+                                              C.c_uint64(int(seed) & (2 ** 64 - 1)), 1 if train else 0,
+                                              int(batch_offset), _stream_ptr()),
                        "dj_pitch_bins")
         return bins
 

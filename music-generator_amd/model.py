@@ -349,11 +349,19 @@ class TrainableModel(Model):
         return self._train_step([np.asarray(a) for a in x],
                                 np.asarray(y[0] if isinstance(y, (list, tuple)) else y) if y is not None else None)
 
-    def _train_step(self, x, target, on_device=False, weight=None, total_weight=None):
+    def _train_step(self, x, target, on_device=False, weight=None, total_weight=None, shard=None):
         """x = [notes, chosen, beat, style] (+ target) as host arrays, or as device fp32 tensors when
         `on_device` (fit() with a device-resident data set).  weight: this rank's share of the global batch
         (default: its sample count; 0 for a rank that only keeps the collective pattern alive);
-        total_weight: the global batch size when the caller knows it (fit does), else it is all-reduced."""
+        total_weight: the global batch size when the caller knows it (fit does), else it is all-reduced;
+        shard = (first sample of this rank's shard within the global batch, shard stride): fit's contiguous shards.
+
+        Data parallel, DEEPJ_DDP_EXACT=1: the step is the reference's step on the GLOBAL batch, exactly.  By default
+        each rank evaluates the reference on its own shard (the pitch_bins reshape, model.py:43-49, couples the
+        samples of a batch, and the dropout masks are indexed by batch rows); in exact mode every rank computes its
+        part of the global pitch_bins table (dj_pitch_bins with its batch offset), the parts are all-gathered -- one
+        small extra collective per step, [octave, shard, T] floats per rank -- and the shard runs against the global
+        table with the global batch's dropout masks of its rows (dj_train_fwd_bwd_mb; one seed for all ranks)."""
         s, be = self._s, self._s.backend
         notes, chosen, beat, style = x
         if target is None:
@@ -377,21 +385,42 @@ class TrainableModel(Model):
         dist = self._dist()
         rank = dist.get_rank() if dist else 0
         world = dist.get_world_size() if dist else 1
-        seed = (s.seed * 1000003 + s.step * world + rank) & 0xFFFFFFFF
+        exact = dist is not None and os.environ.get("DEEPJ_DDP_EXACT") == "1"
+        seed = (s.seed * 1000003 + s.step * (1 if exact else world) + (0 if exact else rank)) & 0xFFFFFFFF
         t = [notes, chosen, beat, style, target] if on_device else [be.tensor(a) for a in (notes, chosen, beat, style, target)]
         weight = float(B) if weight is None else float(weight)
 
+        def global_bins(eng):
+            """(global batch size, this shard's first sample in it, pitch_bins table of the global batch)."""
+            import torch
+            b0, per = shard if shard is not None else (rank * B, B)          # train_on_batch: equal shards, rank order
+            total = int(total_weight) if total_weight is not None else world * B
+            part = eng.pitch_bins(t[0].contiguous(), seed=seed, batch_offset=b0)          # [octave, B, T]
+            pad = torch.zeros((part.shape[0], per, part.shape[2]), dtype=part.dtype, device=part.device)
+            if weight > 0:
+                pad[:, :B] = part                       # (a weight-0 rank holds a stand-in sample: nothing to add)
+            parts_ = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(parts_, pad)
+            return total, b0, torch.cat(parts_, dim=1)[:, :total].contiguous()
+
         def fwd_bwd():
             eng = s.engine(B // parts, T, train=True)
+            if exact:
+                full, off, bins = global_bins(eng)
+            elif parts > 1:
+                full, off, bins = B, 0, eng.pitch_bins(t[0].contiguous(), seed=seed)
             if parts == 1:
-                loss = eng.train_fwd_bwd(s.params, s.grads, *t, seed=seed)
+                if exact:
+                    loss = eng.train_fwd_bwd(s.params, s.grads, *t, seed=seed, full_batch=full, batch_offset=off,
+                                             bins_full=bins)
+                else:
+                    loss = eng.train_fwd_bwd(s.params, s.grads, *t, seed=seed)
             else:
                 k, loss = B // parts, None
-                bins = eng.pitch_bins(t[0].contiguous(), seed=seed)
                 for i in range(parts):
                     mb = [x_[i * k:(i + 1) * k].contiguous() for x_ in t]
-                    li = eng.train_fwd_bwd(s.params, s.grads, *mb, seed=seed, accumulate=i > 0, full_batch=B,
-                                           batch_offset=i * k, bins_full=bins)
+                    li = eng.train_fwd_bwd(s.params, s.grads, *mb, seed=seed, accumulate=i > 0, full_batch=full,
+                                           batch_offset=off + i * k, bins_full=bins)
                     loss = li.clone() if loss is None else loss + li     # [sum of means, faults so far (cumulative)]
                     if loss.numel() > 1:
                         loss[1] = li[1]
@@ -436,7 +465,7 @@ class TrainableModel(Model):
             if hasattr(eng, "take_async_faults"):
                 eng.take_async_faults(local_faults)                            # reset the device-side census
             s.add_kernel_flags(KF_NO_CLUSTER)
-            return self._train_step(x, target, on_device, weight, total_weight)
+            return self._train_step(x, target, on_device, weight, total_weight, shard)
         if loss_value != loss_value:
             raise FloatingPointError("training loss is NaN at step %d" % s.step)
         s.optimizer.step(s.params, s.grads, scale)
@@ -498,20 +527,23 @@ class TrainableModel(Model):
             for bi in range(nb):
                 ids = index[bi * batch_size:(bi + 1) * batch_size]
                 _call(callbacks, "on_batch_begin", bi, {"batch": bi, "size": len(ids)})
-                weight = None
+                weight, shard = None, None
                 if world > 1:
                     per = (len(ids) + world - 1) // world
                     mine = ids[rank * per:(rank + 1) * per]
                     weight = float(len(mine))
+                    shard = (rank * per if len(mine) else 0, per)     # first sample of the shard in the batch, shard stride
                     if len(mine) == 0:                    # keep the collective pattern identical: a sample with
                         mine = ids[:1]                    # weight 0 adds nothing to the gradient or the loss
                 else:
                     mine = ids
                 if resident is not None:
                     dev = be.take(resident, mine)
-                    loss = self._train_step(dev[:4], dev[4], on_device=True, weight=weight, total_weight=len(ids))
+                    loss = self._train_step(dev[:4], dev[4], on_device=True, weight=weight, total_weight=len(ids),
+                                            shard=shard)
                 else:
-                    loss = self._train_step([a[mine] for a in x], target[mine], weight=weight, total_weight=len(ids))
+                    loss = self._train_step([a[mine] for a in x], target[mine], weight=weight, total_weight=len(ids),
+                                            shard=shard)
                 tot += loss * len(ids)
                 seen += len(ids)
                 _call(callbacks, "on_batch_end", bi, {"batch": bi, "size": len(ids), "loss": loss})

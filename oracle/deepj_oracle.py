@@ -236,6 +236,21 @@ def pitch_bins(cfg: OracleConfig, x: torch.Tensor) -> torch.Tensor:
     return tiled.reshape(B, T, N, 1)
 
 
+def pitch_bins_table(cfg: OracleConfig, x: torch.Tensor) -> torch.Tensor:
+    """The [octave, B, T] table of model.py:45 (before the tile and the raw reshape) of the (dropped-out) notes x."""
+    return torch.stack([x[:, :, i::cfg.octave, 0].sum(dim=2) for i in range(cfg.octave)], dim=0)
+
+
+def pitch_bins_of_shard(cfg: OracleConfig, table: torch.Tensor, b0: int, B: int, N: int) -> torch.Tensor:
+    """The pitch_bins feature [B,T,N,1] of samples [b0, b0 + B) of the batch whose table [octave, B_full, T] is given:
+    rows b0.. of what pitch_bins() returns on the whole batch (tile, flatten, keep B_full*T*N, reshape: model.py:46-47).
+    Checker utility for evaluations that see a shard at a time (micro-batches, data-parallel ranks)."""
+    O_, B_full, T = table.shape
+    reps = -(-N // O_)
+    full = table.repeat(reps, 1, 1).reshape(-1)[: B_full * T * N].reshape(B_full, T, N, 1)
+    return full[b0:b0 + B]
+
+
 def pitch_bins_closed_form(cfg: OracleConfig, x: np.ndarray) -> np.ndarray:
     """Closed form of the same quirk, used by the HIP kernel:
     out[b,t,n] = bins[(f // (B*T)) % 12, (f % (B*T)) // T, f % T],  f = (b*T+t)*N+n."""
@@ -292,8 +307,9 @@ def style_embed(p, style_in):
     return style_in @ p["style/kernel"] + p["style/bias"]
 
 
-def time_axis(cfg, p, notes, beat, style, masks=None):
-    """model.py:51-89.  notes/beat are already input-dropped.  Returns [B,T,N,Ht]."""
+def time_axis(cfg, p, notes, beat, style, masks=None, bins=None):
+    """model.py:51-89.  notes/beat are already input-dropped.  Returns [B,T,N,Ht].  bins: the pitch_bins feature
+    [B,T,N,1] when these samples are a shard of a larger batch (pitch_bins_of_shard); None = computed from `notes`."""
     B, T, N, _ = notes.shape
     dt = notes.dtype
     octave = torch.tanh(conv_octave(p, notes))                        # model.py:56-57
@@ -303,7 +319,8 @@ def time_axis(cfg, p, notes, beat, style, masks=None):
     cls = torch.zeros(N, cfg.octave, dtype=dt)                        # model.py:32-41
     cls[torch.arange(N), torch.arange(N) % cfg.octave] = 1.0
     cls = cls.view(1, 1, N, cfg.octave).expand(B, T, N, cfg.octave)
-    bins = pitch_bins(cfg, notes)                                     # model.py:43-49
+    if bins is None:
+        bins = pitch_bins(cfg, notes)                                 # model.py:43-49
     beat_r = beat.unsqueeze(2).expand(B, T, N, beat.shape[-1])         # model.py:66
     x = torch.cat([pos, cls, bins, octave, beat_r], dim=3)            # model.py:61-67
     for l in range(cfg.time_axis_layers):                              # model.py:75-85
@@ -349,13 +366,13 @@ def to_torch(p: dict, dtype=torch.float32, requires_grad=False) -> dict:
     return out
 
 
-def forward(cfg, p, notes, chosen, beat, style_in, masks=None, return_time=False):
+def forward(cfg, p, notes, chosen, beat, style_in, masks=None, return_time=False, bins=None):
     """Training graph model.py:129-151: inputs [notes, chosen, beat, style]."""
     notes_d = _drop(notes, masks, "notes")                             # model.py:136
     beat_d = _drop(beat, masks, "beat")                                # model.py:137
     chosen_d = _drop(chosen, masks, "chosen")                          # model.py:138
     style = style_embed(p, style_in)
-    t_out = time_axis(cfg, p, notes_d, beat_d, style, masks)
+    t_out = time_axis(cfg, p, notes_d, beat_d, style, masks, bins)
     out = note_axis(cfg, p, t_out, chosen_d, style, masks)
     if return_time:
         return out, t_out
@@ -385,13 +402,13 @@ def primary_loss(y_true, y_pred):
     return (bce_note + bce_replay + mse).mean()
 
 
-def loss_and_grads(cfg, params_np: dict, batch, masks=None, dtype=torch.float32):
+def loss_and_grads(cfg, params_np: dict, batch, masks=None, dtype=torch.float32, bins=None):
     """One forward + BPTT (torch autograd over the restated graph).
     batch = (notes, chosen, beat, style_in, target) numpy arrays.
     Returns loss (float), out [B,T,N,3] numpy, grads dict of numpy."""
     p = to_torch(params_np, dtype, requires_grad=True)
     notes, chosen, beat, style_in, target = [torch.as_tensor(np.asarray(a)).to(dtype) for a in batch]
-    out = forward(cfg, p, notes, chosen, beat, style_in, masks)
+    out = forward(cfg, p, notes, chosen, beat, style_in, masks, bins=bins)
     loss = primary_loss(target, out)
     loss.backward()
     grads = {k: v.grad.detach().numpy() for k, v in p.items()}

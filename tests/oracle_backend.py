@@ -33,11 +33,36 @@ class _Engine:
     def _p(self, params):
         return O.unflatten_params(self.ocfg, params.numpy())
 
-    def train_fwd_bwd(self, params, grads, notes, chosen, beat, style, target, seed=0, out=None):
-        masks = O.make_masks(self.ocfg, self.B, seed, self.pin, self.pdr, T=self.T) if (self.pin or self.pdr) else None
+    def _masks(self, seed, b0, B):
+        """Dropout masks of samples [b0, b0 + B): rows of the masks of a batch of b0 + B samples (the counter hash
+        depends on the row index only)."""
+        if not (self.pin or self.pdr):
+            return None
+        m = O.make_masks(self.ocfg, b0 + B, seed, self.pin, self.pdr, T=self.T)
+        return {k: v[b0:b0 + B] for k, v in m.items()}
+
+    def pitch_bins(self, notes_full, seed=0, train=True, batch_offset=0):
+        x = torch.as_tensor(np.asarray(notes_full, np.float32))
+        m = self._masks(seed, batch_offset, x.shape[0]) if train else None
+        if m is not None and "notes" in m:
+            x = x * m["notes"]
+        return O.pitch_bins_table(self.ocfg, x)
+
+    def train_fwd_bwd(self, params, grads, notes, chosen, beat, style, target, seed=0, out=None, accumulate=False,
+                      full_batch=0, batch_offset=0, bins_full=None):
+        B = notes.shape[0]
+        if bins_full is None:
+            masks, bins = self._masks(seed, 0, B), None
+        else:          # a shard of a larger batch: that batch's masks and pitch_bins rows (dj_train_fwd_bwd_mb)
+            masks = self._masks(seed, batch_offset, B)
+            bins = O.pitch_bins_of_shard(self.ocfg, bins_full, batch_offset, B, self.ocfg.num_notes)
         loss, o, g = O.loss_and_grads(self.ocfg, self._p(params),
-                                      [t.numpy() for t in (notes, chosen, beat, style, target)], masks)
-        grads.copy_(torch.from_numpy(O.flatten_params(self.ocfg, g)))
+                                      [t.numpy() for t in (notes, chosen, beat, style, target)], masks, bins=bins)
+        gf = torch.from_numpy(O.flatten_params(self.ocfg, g))
+        if accumulate:
+            grads.add_(gf)
+        else:
+            grads.copy_(gf)
         faults = float(self.inject_faults.pop(0)) if self.inject_faults else 0.0
         self.loss = torch.tensor([float("nan") if faults else loss, faults], dtype=torch.float32)
         return self.loss

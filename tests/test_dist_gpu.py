@@ -199,3 +199,67 @@ def test_bench_two_rank_flow_on_one_gpu(gpu_device):
     assert d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2" and "rehearsal" in d["config"]
     assert d["value"] > 0 and abs(d["value"] - 2 * 64 * 128 * 128 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-3 * d["value"]
     assert np.isfinite(d["final_loss"]) and d["cpu_baseline"] is None and "scaled" not in d
+
+
+WORKER3 = r'''
+import json, os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from music_generator_amd.data import synthetic_batch
+from music_generator_amd.engine import DeepJConfig
+from music_generator_amd.model import build_models
+torch.cuda.set_device(0)
+world = int(sys.argv[2])
+if world > 1:
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", world_size=world, rank=int(sys.argv[1]))
+    try:
+        t = torch.ones(4, device="cuda:0"); dist.all_reduce(t); assert float(t[0]) == 2.0
+    except Exception as e:
+        print("RESULT " + json.dumps({{"skip": "gloo cannot all-reduce device tensors here: %s" % str(e)[:120]}}), flush=True)
+        sys.exit(0)
+B, T, N = 6, 5, 20                                       # N % 12 != 0 too; batches of 6 and (7th sample) 1
+cfg = DeepJConfig(num_notes=N, time_steps=T)             # fp32
+a = synthetic_batch(N, T, 7, seed=2)
+m = build_models(time_steps=T, config=cfg, seed=5)[0]    # dropout 0.2 / 0.5 on
+np.random.seed(0)
+hist = m.fit([a[0], a[1], a[2], a[3]], [a[4]], epochs=2, batch_size=B, verbose=0, shuffle=False)
+w = np.concatenate([v.ravel() for v in m.get_weights()])
+np.save(sys.argv[3], w)
+print("RESULT " + json.dumps({{"loss": hist.history["loss"]}}), flush=True)
+if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+'''
+
+
+def test_exact_data_parallel_equals_single_process_on_the_gpu(gpu_device, tmp_path):
+    """DEEPJ_DDP_EXACT=1 on the HIP kernels: two ranks (both on the one GPU, gloo as the collective) fit 7 samples at
+    global batch 6 -- shards of 3 + 3, then 1 + 0 -- and end at the weights ONE process reaches on the whole batches
+    with the same model seed: dj_pitch_bins with the rank's batch offset, the all-gathered global table,
+    dj_train_fwd_bwd_mb with the global batch's dropout masks (fp32; N = 20 exercises the N % 12 != 0 reshape)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / "worker3.py"
+    script.write_text(WORKER3.format(root=ROOT, port=port))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DEEPJ_DDP_EXACT="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DEEPJ_DIST_WORLD1"):
+        env.pop(k, None)
+    one = subprocess.run([sys.executable, str(script), "0", "1", str(tmp_path / "w_one.npy")], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert one.returncode == 0, (one.stdout[-1000:], one.stderr[-3000:])
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(tmp_path / ("w_r%d.npy" % r))], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, (so[-1000:], se[-3000:])
+    res = [json.loads([ln for ln in so.splitlines() if ln.startswith("RESULT ")][-1][7:]) for so, _ in outs]
+    if "skip" in res[0]:
+        pytest.skip(res[0]["skip"])
+    l_one = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])["loss"]
+    w1, wa, wb = (np.load(tmp_path / n) for n in ("w_one.npy", "w_r0.npy", "w_r1.npy"))
+    np.testing.assert_array_equal(wa, wb)
+    assert res[0]["loss"] == res[1]["loss"]
+    np.testing.assert_allclose(res[0]["loss"], l_one, rtol=1e-5)
+    np.testing.assert_allclose(wa, w1, rtol=1e-4, atol=2e-5)
