@@ -327,7 +327,8 @@ int32_t dj_dropout_mask(uint64_t seed, int32_t site, float p, int64_t rows, int3
  * the caller's stream around every launch, grouped by category.  dj_profile_read waits
  * for the category's events and returns the summed milliseconds and the scope count.
  * Process-global and not thread-safe: a measurement aid, not part of the data path. */
-int32_t dj_profile_enable(int32_t on);
+int32_t dj_profile_enable(int32_t on);   /* 0 = off, 1 = every category, 2 + c = category c only (2 events per launch
+                                          * cost ~0.2 ms per training step when every launch carries them); clears */
 int32_t dj_profile_category_count(void);
 const char* dj_profile_category_name(int32_t category);
 int32_t dj_profile_read(int32_t category, double* total_ms_host, int64_t* scopes_host);

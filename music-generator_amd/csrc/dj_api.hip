@@ -31,6 +31,7 @@ const char* const kProfNames[PC_COUNT] = {
 struct ProfRec { int cat; hipEvent_t a, b; };
 struct Prof {
   bool on = false;
+  int only = -1;          // >= 0: events around the launches of this category only (dj_profile_enable(2 + category))
   std::vector<ProfRec> recs;
   std::vector<hipEvent_t> pool;
   hipEvent_t get() {
@@ -40,7 +41,7 @@ struct Prof {
 } g_prof;
 struct ProfScope {
   bool act; hipStream_t st; hipEvent_t b;
-  ProfScope(int cat, hipStream_t s) : act(g_prof.on), st(s) {
+  ProfScope(int cat, hipStream_t s) : act(g_prof.on && (g_prof.only < 0 || g_prof.only == cat)), st(s) {
     if (!act) return;
     hipEvent_t a = g_prof.get(); b = g_prof.get();
     (void)hipEventRecord(a, st);
@@ -944,6 +945,7 @@ int32_t dj_profile_enable(int32_t on) {
   for (auto& r : g_prof.recs) { g_prof.pool.push_back(r.a); g_prof.pool.push_back(r.b); }
   g_prof.recs.clear();
   g_prof.on = on != 0;
+  g_prof.only = (on >= 2 && on - 2 < PC_COUNT) ? on - 2 : -1;
   return 0;
 }
 int32_t dj_profile_category_count(void) { return PC_COUNT; }
