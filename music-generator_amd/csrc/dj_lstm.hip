@@ -2575,8 +2575,7 @@ int launch_bwd_pair(int ntiles, int steps, const void* Z, const void* UTpack, co
                        (uint4*)((unsigned char*)scratch + BP_OFF_CNT));
     if (int rc = cluster_fault_hook(scratch, st)) return rc;
     const dim3 grid((n + 7) / 8 * 16);
-    static const int far = getenv("DEEPJ_BWD_PAIR_FAR") ? atoi(getenv("DEEPJ_BWD_PAIR_FAR")) : 0;
-    const int mate = far ? (int)grid.x / 2 : 8;
+    const int mate = 8;      // neighbours in dispatch order; (half the grid apart: all 256 pairs on ONE compute unit each, +5 %)
     if (sigm)
       hipLaunchKernelGGL((lstm_bwd_pair_kernel<true>), grid, dim3(256), smem, st, z, (const bf16_t*)UTpack, c, dh, dz, dbias,
                          steps, dz_cts, ldz, (int*)scratch, n, mate);

@@ -148,3 +148,13 @@ def test_pmc_traffic_from_rocprof_passes(tmp_path):
     assert got["lstm_bwd_note"] == 2 * 1024 * 500.0 + 1024 * 100.0
     assert bench.pmc_category("lstm_fwd_cluster_kernelILb0ELi16EE") == "lstm_fwd_time"
     assert bench.pmc_category("lstm_wgrad_bf16_kernel") == "gemm_dw" and bench.pmc_category(other) is None
+
+
+def test_dominant_category_prefers_a_sweep_within_five_percent():
+    """bench.dominant_category: the roofline names the largest category, but a recurrent sweep (one kernel, one shape)
+    within 5 % of it is preferred over the multi-shape GEMM categories, so that near-ties do not flip the line."""
+    import bench
+    keys = ["gemm_dw", "gemm_dx", "lstm_bwd_time", "lstm_fwd_time"]
+    assert bench.dominant_category({"gemm_dw": 2.85, "gemm_dx": 1.7, "lstm_bwd_time": 2.82, "lstm_fwd_time": 2.5}, keys) == "lstm_bwd_time"
+    assert bench.dominant_category({"gemm_dw": 3.5, "gemm_dx": 1.7, "lstm_bwd_time": 2.82, "lstm_fwd_time": 2.5}, keys) == "gemm_dw"
+    assert bench.dominant_category({"gemm_dw": 2.0, "gemm_dx": 1.7, "lstm_bwd_time": 2.82, "lstm_fwd_time": 2.9}, keys) == "lstm_fwd_time"

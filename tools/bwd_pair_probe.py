@@ -1,6 +1,6 @@
 """Dev tool: the H = 256 BPTT sweep alone at the BASELINE shape (256 tiles x 128 steps): per-tile kernel (0) vs workgroup
 pairs (1) vs two tiles per pair, interleaved (2), HIP-event times, and how many pairs had both members on one compute unit (fault word 3 of the scratch).
-    DEEPJ_BWD_PAIR_FAR=0|1 python tools/bwd_pair_probe.py [tiles] [steps]"""
+    python tools/bwd_pair_probe.py [tiles] [steps]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -43,4 +43,4 @@ for pair in (0, 1, 2, 0, 1, 2):
     e1.record()
     torch.cuda.synchronize()
     words = cl[16384:16384 + 16].view(torch.int32).cpu().tolist()
-    print(f"pair={pair} far={os.environ.get('DEEPJ_BWD_PAIR_FAR', '0')}: {e0.elapsed_time(e1) / 10:.3f} ms per launch; fault words {words[:3]}, same-CU pairs (cumulative) {words[3]}", flush=True)
+    print(f"pair={pair}: {e0.elapsed_time(e1) / 10:.3f} ms per launch; fault words {words[:3]}, same-CU pairs (cumulative) {words[3]}", flush=True)
