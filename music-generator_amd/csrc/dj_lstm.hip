@@ -24,7 +24,11 @@
 //    waves) from the dz tile it holds in LDS; its streamed-U^T build (H = 256) keeps the first 8 of a wave's
 //    64 k-chunks in the LDS the tiles leave free (BwdUlds);
 //  * lstm_fwd_cluster_kernel (bf16, H = 256, >= 64 tiles): 8 workgroups of one XCD keep the W and U slices of
-//    32 hidden units each in LDS for the whole sweep and exchange h slices through L2 once per step.
+//    32 hidden units each in LDS for the whole sweep and exchange h slices through L2 once per step;
+//  * lstm_bwd_pair_kernel / lstm_bwd_dual_kernel (bf16, H = 256; opt-in, DJ_KF_BWD_PAIR / DJ_KF_BWD_DUAL): the BPTT
+//    sweep with a tile's hidden units split over a pair of workgroups that exchange their halves of dz through the dZ
+//    output -- one tile per pair, or two tiles per pair with the product of one folded into the gate math of the
+//    other.  Correct, slower than lstm_bwd_kernel at the BASELINE shape.
 // The weight streams are bound by the CU's vector-memory path (64 B/clk), not by L2 or HBM: every fragment
 // that can live in registers or LDS instead is time won, and every loop bound in these kernels has to be a
 // compile-time constant (run-time variants of the same loops measured +0.4 ... +0.5 ms).
