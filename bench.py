@@ -108,6 +108,15 @@ def category_bytes(cfg, B, T, N, esize):
     return out
 
 
+def stash_bytes_per_note_step(cfg, esize=2):
+    """minimal BPTT stash per note-step if gates are kept -- sum over layers of 6H, plus the feature
+    row F and the 64 conv outputs, written once and read once: (sum 6H + F + 64) x esize x 2 = 19,064 B for the
+    reference model in bf16."""
+    F = 1 + cfg.octave + 1 + cfg.octave_units + cfg.notes_per_bar
+    elems = 6 * (cfg.time_axis_layers * cfg.time_axis_units + cfg.note_axis_layers * cfg.note_axis_units) + F + cfg.octave_units
+    return elems * esize * 2
+
+
 def launches_per_step(cfg):
     Lt, Ln = cfg.time_axis_layers, cfg.note_axis_layers
     F = 1 + cfg.octave + 1 + cfg.octave_units + cfg.notes_per_bar
@@ -276,7 +285,8 @@ def read_profile(lib, steps):
     return out
 
 
-def scaled_record(dtype, micro, steps, warmup, dropout, dev, rank, world, dist):
+def scaled_record(dtype, micro, steps, warmup, dropout, dev, rank, world, dist, force_collective=False, shape=None,
+                  return_params=False):
     """BASELINE configs[4]: 3 x 1024 units per axis, batch 128 x 256 steps x 128 notes per GPU.  The batch runs as
     `micro` equal micro-batches through one workspace with gradient accumulation and ONE optimizer step -- EXACTLY the
     step on the batch of 128 (dj_train_fwd_bwd_mb): the pitch_bins table is that of the whole batch (dj_pitch_bins, one
@@ -285,7 +295,7 @@ def scaled_record(dtype, micro, steps, warmup, dropout, dev, rank, world, dist):
     from music_generator_amd import _lib
     from music_generator_amd.data import synthetic_batch
     from music_generator_amd.engine import DeepJConfig, Engine, Nadam, init_params_numpy
-    B, T, N = 128, 256, 128
+    B, T, N = shape or (128, 256, 128)              # (tests rehearse the same function at a small shape)
     pin, pdr = dropout or (0.2, 0.5)
     cfg = DeepJConfig(num_notes=N, time_steps=T, dtype=dtype, time_axis_units=1024, note_axis_units=1024,
                       time_axis_layers=3, note_axis_layers=3)
@@ -304,8 +314,8 @@ def scaled_record(dtype, micro, steps, warmup, dropout, dev, rank, world, dist):
         for m in range(micro):
             loss = eng.train_fwd_bwd(P, G, *parts[m], seed=seed, accumulate=m > 0, full_batch=B, batch_offset=m * k,
                                      bins_full=bins)
-        if world > 1:
-            dist.all_reduce(G)
+        if world > 1 or force_collective:
+            dist.all_reduce(G)                           # 187.6 MB of fp32 gradient
         opt.step(P, G, grad_scale=1.0 / (micro * world))
         return loss
 
@@ -338,6 +348,8 @@ def scaled_record(dtype, micro, steps, warmup, dropout, dev, rank, world, dist):
     kernels = {k_: round(v_, 3) for k_, v_ in read_profile(lib, 1).items()}
     lib.dj_profile_enable(0)
     ws_gib = round(eng.ws_bytes / 2 ** 30, 1)
+    faults = eng.cluster_faults("scaled bench record")
+    params_out = P.cpu().numpy() if return_params else None
     del eng, P, G, opt, data, parts
     torch.cuda.empty_cache()
     if rank != 0:
@@ -363,7 +375,8 @@ def scaled_record(dtype, micro, steps, warmup, dropout, dev, rank, world, dist):
                      "unit": "TFLOP/s", "frac": round(dom_tf / PEAK_TFLOPS[dtype], 4), "traffic": None,
                      "whole_step_mfma_frac": round(tf / world / PEAK_TFLOPS[dtype], 4),
                      "flops_per_step": flops_step},
-        "kernel_ms_per_step": kernels, "kernel_tflops": rates, "cpu_baseline": None}
+        "kernel_ms_per_step": kernels, "kernel_tflops": rates, "cpu_baseline": None, "cluster_faults": faults,
+        **({"params": params_out} if return_params else {})}
 
 
 def scaled_bench(args, dev, rank, world, dist):
@@ -556,12 +569,16 @@ def main():
             break
         fallback_faults = faults
         if rank == 0:
-            print(f"[bench] {faults} cluster faults in the timed run: repeating it on the per-tile kernels "
+            from music_generator_amd.engine import describe_fault_report
+            what = describe_fault_report(eng.last_fault) if getattr(eng, "last_fault", None) else "reported by another rank"
+            print(f"[bench] {faults} cluster faults in the timed run ({what}): repeating it on the per-tile kernels "
                   "(DJ_KF_NO_CLUSTER)", file=sys.stderr, flush=True)
         del eng, step
     if faults or not np.isfinite(final_loss):
-        raise SystemExit(f"invalid run: {faults} cluster faults, final loss {final_loss} -- no number is reported "
-                         "(DEEPJ_CLUSTER=0 selects the per-tile kernel)")
+        from music_generator_amd.engine import describe_fault_report
+        what = describe_fault_report(eng.last_fault) if getattr(eng, "last_fault", None) else "no description"
+        raise SystemExit(f"invalid run: {faults} cluster faults ({what}), final loss {final_loss} -- no number is "
+                         "reported (DEEPJ_CLUSTER=0 selects the per-tile kernel)")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -602,6 +619,16 @@ def main():
         else:
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(tflops, 2), "peak": PEAK_TFLOPS[args.dtype],
                     "unit": "TFLOP/s", "frac": round(tflops / PEAK_TFLOPS[args.dtype], 4)}
+        # the whole step against both roofs, as SURVEY.md 8(d) defines them: train FLOPs per note-step (7,301,376 for the
+        # reference model) x note-steps/s per GPU / dense MFMA peak, and minimal-stash bytes per note-step (19,064 B) x
+        # note-steps/s per GPU / HBM peak
+        nsps = B * T * N * args.steps / elapsed
+        cf_ = category_flops(cfg, B, T, N)
+        flops_ns = 3 * (cf_["gemm_xw"] + cf_["lstm_fwd_time"] + cf_["lstm_fwd_note"]) / (B * T * N)
+        stash_ns = stash_bytes_per_note_step(cfg, 2 if args.dtype == "bf16" else 4)
+        roof.update({"whole_step_mfma_frac": round(flops_ns * nsps / (PEAK_TFLOPS[args.dtype] * 1e12), 4),
+                     "whole_step_stash_hbm_frac": round(stash_ns * nsps / (PEAK_HBM_GBS * 1e9), 4),
+                     "train_flops_per_note_step": int(flops_ns), "stash_bytes_per_note_step": stash_ns})
         roof.update({"traffic": traffic, "traffic_committed_pmc": committed, "traffic_source": tsrc,
                      "launches_per_step": lps[dom],
                      "avg_launch_ms": round(ms / lps[dom], 4), "bytes_per_launch": by[dom] / lps[dom],

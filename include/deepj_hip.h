@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DJ_ABI_VERSION 3
+#define DJ_ABI_VERSION 4
 #define DJ_DTYPE_F32 0  /* fp32 operands, v_mfma_f32_32x32x2_f32 (parity mode)            */
 #define DJ_DTYPE_BF16 1 /* bf16 operands/stash, fp32 accumulate + cell state (throughput) */
 
@@ -52,7 +52,7 @@ typedef struct dj_config {
 
 /* Kernel-selection flags (dj_config.kernel_flags: per engine; none changes results beyond summation order).  The
  * DEEPJ_* environment variables of the same meaning (DEEPJ_CLUSTER=0, DEEPJ_CLUSTER_PAIR=0, DEEPJ_CLUSTER_F32=0,
- * DEEPJ_CLUSTER_COOP=0, DEEPJ_FUSE_DX=0, DEEPJ_GEN_KSPLIT=0, DEEPJ_BWD_PAIR=1, DEEPJ_BWD_DUAL=1, DEEPJ_DEBUG_CLUSTER_FAULT=1,
+ * DEEPJ_CLUSTER_COOP=0, DEEPJ_FUSE_DX=0, DEEPJ_GEN_KSPLIT=0, DEEPJ_DEBUG_CLUSTER_FAULT=1, DEEPJ_DEBUG_CLUSTER_LATE=1,
  * DEEPJ_FUSE_XW_MIN_TILES=n)
  * are read ONCE, at the first call into the library, as process-wide defaults that are OR-ed with these bits; there
  * is no getenv on the launch path.  dj_env_reload() reads them again (tests that switch kernels inside one process).
@@ -66,8 +66,10 @@ typedef struct dj_config {
 #define DJ_KF_NO_FUSE_DX 16         /* dX = dz W^T always as a GEMM                                                    */
 #define DJ_KF_NO_GEN_KSPLIT 32      /* note sampler: one thread per gate column                                       */
 #define DJ_KF_DEBUG_CLUSTER_FAULT 64 /* cluster launches fail their placement check (fault-handling tests)            */
-#define DJ_KF_BWD_PAIR 128          /* opt-in: BPTT of the bf16 H = 256 layers on workgroup pairs (dj_lstm_bwd_pair)   */
-#define DJ_KF_BWD_DUAL 256          /* the same with two tiles per pair, interleaved (dj_lstm_bwd_dual)                */
+#define DJ_KF_DEBUG_CLUSTER_LATE 128 /* the last member of every cluster never arrives in round 0: every other wave's  */
+                                     /*   bound runs out, once (tests of the expiry path and its cost)                */
+/* (ABI 3 had two opt-in re-decompositions of the H = 256 BPTT sweep, DJ_KF_BWD_PAIR / _DUAL; they were slower and now
+ * live in tools/bwd_decompositions/, outside this library) */
 int32_t dj_env_reload(void);
 
 int32_t dj_abi_version(void);
@@ -276,23 +278,6 @@ int32_t dj_lstm_pack_wt(int32_t dtype, int32_t H, const float* W, int32_t D, voi
 int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack_bwd,
                        const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias,
                        int32_t recurrent_sigmoid, const void* wtpack, int32_t D, void* dX, int32_t DP, void* stream);
-/* The same sweep as dj_lstm_bwd (bf16, H = 256 only; code 1016 otherwise) with every tile split over a PAIR of
- * workgroups (dj_lstm.hip, lstm_bwd_pair_kernel): each member owns 128 hidden units -- its gate math, its half of dz, its
- * half of the U^T columns -- and the halves of dz_t meet through the dZ output itself (the partner reads it back from the
- * XCD's L2), so two workgroups of different tiles share a compute unit and their VALU / vector-memory phases interleave.
- * Needs the cluster scratch below (counter lines, fault words) and the device to itself (bounded waits; faults are
- * counted and poison the tile's gradients like the forward cluster's).  Opt-in for dj_train_fwd_bwd (DJ_KF_BWD_PAIR /
- * DEEPJ_BWD_PAIR=1; off whenever DJ_KF_NO_CLUSTER is set): at the BASELINE shape it measured 1.53-1.64 ms per launch
- * against 1.39-1.60 ms for dj_lstm_bwd -- with two workgroups streaming U^T on one compute unit the sweep stays bound by
- * the CU's vector-memory path.  Results equal dj_lstm_bwd's up to fp32 summation order. */
-int32_t dj_lstm_bwd_pair(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack_bwd,
-                         const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias,
-                         int32_t recurrent_sigmoid, void* cluster_scratch, void* stream);
-/* Two tiles per workgroup pair: a wave alternates between them, the product dz U^T of one tile folded into the gate
- * math of the other (lstm_bwd_dual_kernel).  Same arguments, requirements and fault handling as dj_lstm_bwd_pair. */
-int32_t dj_lstm_bwd_dual(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack_bwd,
-                         const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias,
-                         int32_t recurrent_sigmoid, void* cluster_scratch, void* stream);
 /* The bf16 H = 256 forward sweep (any tile count; in inference with <= 64 tiles both time-axis layers in one wavefront
  * launch, with <= 8 tiles four waves per tile) and the fp32 H = 256 inference sweep of <= 8 tiles (dj_predict /
  * dj_time_model_predict / dj_generate_* in the parity mode) run as weight-stationary clusters of 8 workgroups that meet
@@ -300,23 +285,38 @@ int32_t dj_lstm_bwd_dual(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps
  * slices) lives in a caller-owned scratch -- part of the workspace for the dj_train / dj_predict calls, one per
  * workspace and therefore per engine / stream; concurrent sweeps must not share one.  Two things are checked at run
  * time and can never produce a silent wrong answer or a hung device: a member that never arrives (grid not
- * co-resident, e.g. the device shared with another stream's kernels) lets the bounded wait expire; a cluster whose
+ * co-resident, e.g. the device shared with another stream's kernels) lets the bounded wait run out; a cluster whose
  * members report different hardware XCC ids (dispatch not round-robin over the XCDs, which the exchange through one
  * XCD's L2 relies on) is detected in round 0.  In both cases the affected tiles carry NaN from there on (so does the
- * loss) and the event is counted.  dj_lstm_cluster_faults / dj_workspace_cluster_faults return the number of events
- * recorded in that scratch / workspace since the previous call (synchronise the device; 0 in a healthy run, -1 on a
- * HIP error).  DJ_KF_NO_CLUSTER (DEEPJ_CLUSTER=0) selects the per-tile kernels instead (DJ_KF_NO_CLUSTER_PAIR / _COOP /
- * _F32 the individual forms); DJ_KF_DEBUG_CLUSTER_FAULT injects a placement fault (tests). */
+ * loss) and the event is counted.  The bound counts POLLS (2^17 of them, ~100 ms of actual polling), not elapsed
+ * time: time during which the whole queue is off the device (another process's time slice, a driver-side eviction)
+ * does not count against it.  The first wave whose bound runs out releases every other waiter of its cluster (a poison
+ * bit in the counter) and no poisoned wave waits again, so a faulted launch costs one bound, not one per step.
+ * dj_lstm_cluster_faults / dj_workspace_cluster_faults return the number of events recorded in that scratch / workspace
+ * since the previous call (they drain `stream`; 0 in a healthy run, -1 on a HIP error).  DJ_KF_NO_CLUSTER
+ * (DEEPJ_CLUSTER=0) selects the per-tile kernels instead (DJ_KF_NO_CLUSTER_PAIR / _COOP / _F32 the individual forms);
+ * DJ_KF_DEBUG_CLUSTER_FAULT injects a placement fault (tests). */
 int64_t dj_lstm_cluster_scratch_bytes(void);
-int32_t dj_lstm_cluster_faults(void* cluster_scratch);
-int32_t dj_workspace_cluster_faults(const dj_config* cfg, void* workspace, int64_t workspace_bytes);
-/* Diagnostics: the two counts separately, without resetting them -- words_host[0] = expired waits (a member never
- * arrived), words_host[1] = clusters whose members reported different XCC ids.  Synchronises. */
-int32_t dj_workspace_cluster_fault_words(const dj_config* cfg, void* workspace, int64_t workspace_bytes,
-                                         int32_t* words_host);
-/* The same census without a host round trip: a one-thread kernel on `stream` ADDS the count (as a float) to
- * out_dev[0] and resets the words -- put out_dev next to the loss and one device-to-host copy per training step
- * carries both (Model.fit reads [loss, faults] together before the optimizer step; the caller zeroes out_dev). */
+int32_t dj_lstm_cluster_faults(void* cluster_scratch, void* stream);
+int32_t dj_workspace_cluster_faults(const dj_config* cfg, void* workspace, int64_t workspace_bytes, void* stream);
+/* Diagnostics: the fault line of the workspace as it stands once `stream` has drained, without resetting anything --
+ * DJ_FAULT_REPORT_WORDS int32 (host):
+ *   [0] expired waits (waves whose bound ran out)   [1] workgroups whose cluster sat on several XCDs   [2] test hook
+ *   [4] waits that saw two consecutive polls > 2^20 shader cycles apart, [5] the longest poll-to-poll gap seen in units
+ *       of 1024 cycles -- the STALL CENSUS: cumulative over the life of the workspace, filled in healthy runs too; a
+ *       gap of milliseconds between two polls of a wave means the wave was off the device
+ *   [8] != 0: [9..17] describe the first expired wait since the last census: [9] kind << 24 | cluster << 12 |
+ *       member << 8 | wave (bit 28: the wait was for the producing layer's counter), [10] recurrence step (-1: round
+ *       0), [11] counter value seen last, [12] target, [13] polls made, [14..15] shader cycles between first and last
+ *       poll (lo, hi), [16] longest poll-to-poll gap in cycles, [17] hardware XCC id + 1. */
+#define DJ_FAULT_REPORT_WORDS 32
+int32_t dj_workspace_cluster_fault_report(const dj_config* cfg, void* workspace, int64_t workspace_bytes,
+                                          int32_t* words_host, void* stream);
+/* The same census without a host round trip: a one-thread kernel on `stream` ADDS (as floats) the event count to
+ * out_dev[0], the expired waits to out_dev[1] and the misplaced workgroups to out_dev[2], and resets the counts (not
+ * the description of the first expired wait) -- put out_dev next to the loss and one device-to-host copy per training
+ * step carries all of it (Model.fit reads [loss, faults, ...] together before the optimizer step; the caller zeroes
+ * out_dev). */
 int32_t dj_workspace_faults_async(const dj_config* cfg, void* workspace, int64_t workspace_bytes, float* out_dev,
                                   void* stream);
 /* mask[rows, cols] (fp32 0 or 1/(1-p)) of dropout site `site` -- exposes the counter

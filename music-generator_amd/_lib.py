@@ -22,7 +22,8 @@ class DjConfig(C.Structure):
 
 # dj_config.kernel_flags (include/deepj_hip.h DJ_KF_*)
 KF_NO_CLUSTER, KF_NO_CLUSTER_PAIR, KF_NO_CLUSTER_F32, KF_NO_CLUSTER_COOP = 1, 2, 4, 8
-KF_NO_FUSE_DX, KF_NO_GEN_KSPLIT, KF_DEBUG_CLUSTER_FAULT, KF_BWD_PAIR, KF_BWD_DUAL = 16, 32, 64, 128, 256
+KF_NO_FUSE_DX, KF_NO_GEN_KSPLIT, KF_DEBUG_CLUSTER_FAULT, KF_DEBUG_CLUSTER_LATE = 16, 32, 64, 128
+FAULT_REPORT_WORDS = 32                      # DJ_FAULT_REPORT_WORDS
 
 
 class DeepJError(RuntimeError):
@@ -37,7 +38,7 @@ _SIGS = {
     "dj_config_size": (C.c_int32, []),
     "dj_env_reload": (C.c_int32, []),
     "dj_style_embedding": (C.c_int32, [C.POINTER(DjConfig), _P, _P, C.c_int32, _P, _P]),
-    "dj_workspace_cluster_fault_words": (C.c_int32, [C.POINTER(DjConfig), _P, C.c_int64, C.POINTER(C.c_int32)]),
+    "dj_workspace_cluster_fault_report": (C.c_int32, [C.POINTER(DjConfig), _P, C.c_int64, C.POINTER(C.c_int32), _P]),
     "dj_workspace_faults_async": (C.c_int32, [C.POINTER(DjConfig), _P, C.c_int64, _P, _P]),
     "dj_param_count": (C.c_int64, [C.POINTER(DjConfig)]),
     "dj_param_info": (C.c_int32, [C.POINTER(DjConfig), C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64),
@@ -72,16 +73,12 @@ _SIGS = {
                                       _P, _P, C.c_int32, _P, _P]),
     "dj_lstm_bwd": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int32,
                                 _P]),
-    "dj_lstm_bwd_pair": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int32,
-                                     _P, _P]),
-    "dj_lstm_bwd_dual": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int32,
-                                     _P, _P]),
     "dj_lstm_bwd_dx": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int64, _P, C.c_int32,
                                    _P, C.c_int32, _P, C.c_int32, _P]),
     "dj_lstm_pack_wt": (C.c_int32, [C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),
     "dj_lstm_cluster_scratch_bytes": (C.c_int64, []),
-    "dj_lstm_cluster_faults": (C.c_int32, [_P]),
-    "dj_workspace_cluster_faults": (C.c_int32, [C.POINTER(DjConfig), _P, C.c_int64]),
+    "dj_lstm_cluster_faults": (C.c_int32, [_P, _P]),
+    "dj_workspace_cluster_faults": (C.c_int32, [C.POINTER(DjConfig), _P, C.c_int64, _P]),
     "dj_dropout_mask": (C.c_int32, [C.c_uint64, C.c_int32, C.c_float, C.c_int64, C.c_int32, _P, _P]),
     "dj_profile_enable": (C.c_int32, [C.c_int32]),
     "dj_profile_category_count": (C.c_int32, []),
@@ -119,7 +116,7 @@ def load():
             raise DeepJError(f"{LIB_PATH} does not export {name}")
         fn.restype = res
         fn.argtypes = args
-    if lib.dj_abi_version() != 3:
+    if lib.dj_abi_version() != 4:
         raise DeepJError("libdeepj_hip.so ABI version mismatch")
     if lib.dj_config_size() != C.sizeof(DjConfig):
         raise DeepJError("dj_config layout mismatch: library %d bytes, binding %d" % (lib.dj_config_size(), C.sizeof(DjConfig)))

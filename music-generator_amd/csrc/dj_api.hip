@@ -231,9 +231,8 @@ EnvDefaults read_env() {
   if (off("DEEPJ_CLUSTER_COOP")) d.flags |= DJ_KF_NO_CLUSTER_COOP;
   if (off("DEEPJ_FUSE_DX")) d.flags |= DJ_KF_NO_FUSE_DX;
   if (off("DEEPJ_GEN_KSPLIT")) d.flags |= DJ_KF_NO_GEN_KSPLIT;
-  if (on("DEEPJ_BWD_PAIR")) d.flags |= DJ_KF_BWD_PAIR;
-  if (on("DEEPJ_BWD_DUAL")) d.flags |= DJ_KF_BWD_DUAL;
   if (on("DEEPJ_DEBUG_CLUSTER_FAULT")) d.flags |= DJ_KF_DEBUG_CLUSTER_FAULT;
+  if (on("DEEPJ_DEBUG_CLUSTER_LATE")) d.flags |= DJ_KF_DEBUG_CLUSTER_LATE;
   if (const char* e = getenv("DEEPJ_FUSE_XW_MIN_TILES")) d.fuse_xw_min_tiles = atoll(e);
   return d;
 }
@@ -245,13 +244,6 @@ inline uint32_t kflags(const dj_config& c) { return (uint32_t)c.kernel_flags | e
 
 // the weight-stationary cluster kernels may be used by this plan (host side: cleared per engine after a cluster fault)
 inline bool cluster_enabled(const dj_config& c) { return !(kflags(c) & DJ_KF_NO_CLUSTER); }
-// BPTT of the H = 256 layers on pairs of workgroups (opt-in: measured 3-5 % slower than the per-tile kernel, DESIGN.md
-// section 8 round 3): same co-residency / placement requirements as the forward cluster, so the cluster-fault fallback
-// (DJ_KF_NO_CLUSTER) switches it off too
-inline int bwd_pair_mode(const dj_config& c) {
-  if (kflags(c) & DJ_KF_NO_CLUSTER) return 0;
-  return (kflags(c) & DJ_KF_BWD_DUAL) ? 2 : (kflags(c) & DJ_KF_BWD_PAIR) ? 1 : 0;
-}
 
 // Fuse x*W into the recurrent kernel when its extra L2 weight stream (D x 4H) is no larger than
 // twice the recurrent one (H x 4H); wider inputs (note layer 0: D = 259 vs H = 128) are cheaper as
@@ -329,7 +321,7 @@ int lstm_layer_fwd(const Ctx& c, const LstmP& L, int64_t tiles, int steps, int64
     RUN(dj_launch_lstm_fwd_fused(dt, L.H, (int)tiles, steps, c.at(wX), L.DP, dj_lstm_fused_nkx(dt, L.H, L.D), c.at(wWt),
                                  c.P + L.b, c.train ? c.at(wZ) : nullptr, c.at(wUf), c.at(wH),
                                  c.train ? c.at(wC) : nullptr, c.p.c.recurrent_sigmoid,
-                                 cluster_enabled(c.p.c) ? c.at(c.p.w_cluster) : nullptr, c.st));
+                                 cluster_enabled(c.p.c) ? c.at(c.p.w_cluster) : nullptr, kflags(c.p.c), c.st));
     return 0;
   }
   if (!rec_persistent(L.H)) {        // per-step path: z row-major in the operand dtype, in place in the stash buffer
@@ -356,7 +348,7 @@ int lstm_layer_fwd(const Ctx& c, const LstmP& L, int64_t tiles, int steps, int64
   if (!c.train && dt == DJ_F32 && L.H == 256 && tiles <= 8 && cluster_enabled(c.p.c) &&
       !(kflags(c.p.c) & DJ_KF_NO_CLUSTER_F32)) {
     const int rc = dj_launch_lstm_fwd_cluster_f32((int)tiles, steps, c.at(wZx), c.at(wUf), c.at(wH),
-                                                  c.p.c.recurrent_sigmoid, c.at(c.p.w_cluster), c.st);
+                                                  c.p.c.recurrent_sigmoid, c.at(c.p.w_cluster), kflags(c.p.c), c.st);
     if (rc != 1017) return rc;
   }
   RUN(dj_launch_lstm_fwd(dt, L.H, (int)tiles, steps, c.at(wZx), c.train ? c.at(wZ) : nullptr, c.at(wUf), c.at(wH),
@@ -400,7 +392,7 @@ int time_axis_forward(const Ctx& c, const float* notes, const float* beat) {
     const int rc = dj_launch_lstm_fwd_cluster_pair(
         (int)p.tilesT, p.T, c.at(p.w_X_t[0]), p.tl[0].DP, c.at(p.w_Wt_t[0]), c.P + p.tl[0].b, c.at(p.w_Uf_t[0]),
         c.at(p.w_X_t[1]), c.at(p.w_Wt_t[1]), c.P + p.tl[1].b, c.at(p.w_Uf_t[1]), c.at(p.w_H_t[1]),
-        c.at<float>(p.w_sp_t[1]), p.tl[1].D, p.N, p.B, p.c.recurrent_sigmoid, c.at(p.w_cluster), c.st);
+        c.at<float>(p.w_sp_t[1]), p.tl[1].D, p.N, p.B, p.c.recurrent_sigmoid, c.at(p.w_cluster), kflags(p.c), c.st);
     if (rc != 1017) return rc;          // 1017: the device cannot hold both halves -- layer by layer below
   }
   for (int l = 0; l < p.Lt; ++l) {
@@ -483,8 +475,7 @@ int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int st
     ProfScope ps(is_note ? PC_LSTM_BWD_NOTE : PC_LSTM_BWD_TIME, c.st);
     if (rec_persistent(L.H)) {
       RUN(dj_launch_lstm_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUb), c.at(wC), c.at(wdH), c.at(wdZ), cts, G + L.b,
-                             c.p.c.recurrent_sigmoid, fdx ? c.at(wWp) : nullptr, L.D, fdx ? c.at(wdX) : nullptr, L.DP,
-                             (L.H == 256 && bwd_pair_mode(c.p.c)) ? c.at(c.p.w_cluster) : nullptr, bwd_pair_mode(c.p.c), c.st));
+                             c.p.c.recurrent_sigmoid, fdx ? c.at(wWp) : nullptr, L.D, fdx ? c.at(wdX) : nullptr, L.DP, c.st));
     } else {
       const void* Uc = dt == DJ_F32 ? (const void*)(c.P + L.U) : (const void*)c.at(wUb);
       RUN(dj_launch_lstm_step_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), Uc, c.at(wC), c.at(wdH), c.at(wdZ), G + L.b,
@@ -528,18 +519,20 @@ int check_ws(const Plan& p, void* ws, int64_t bytes) {
   return 0;
 }
 
-// one kernel: fault words of the cluster scratch added to out[0] as a float, words reset (dj_workspace_faults_async)
+// one kernel: fault counts of the cluster scratch added to out[0..2] as floats (total, expired waits, misplaced), counts
+// reset; the description of the first expired wait stays until the host takes it (dj_workspace_faults_async)
 __global__ void faults_to_float_kernel(int* fault_words, float* out) {
   if (threadIdx.x == 0) {
-    const int n = fault_words[0] + fault_words[1];
-    if (n) { out[0] += (float)n; fault_words[0] = 0; fault_words[1] = 0; }
+    const int e = fault_words[0], m = fault_words[1];
+    if (e | m) {
+      out[0] += (float)(e + m); out[1] += (float)e; out[2] += (float)m;
+      fault_words[0] = 0; fault_words[1] = 0;
+    }
   }
 }
 
 }  // namespace
 
-// process-level switch defaults for the kernel translation units (dj_lstm.hip, dj_gen.hip)
-uint32_t dj_env_flags() { return env_defaults().flags; }
 
 // =============================================================================== C ABI
 extern "C" {
@@ -841,7 +834,7 @@ int32_t dj_generate_step(const dj_config* cfg, const float* params, const float*
   return dj_launch_generate_notes(p.c.dtype, p.B, p.T, p.N, p.Ht, p.Hn, p.Ln, p.S, p.SU, params, offs,
                                   c.at(p.w_H_t[p.Lt - 1]), style_win + (int64_t)(p.T - 1) * p.S, (int64_t)p.T * p.S,
                                   c.at<float>(p.w_dX_n), uniforms, temperature, next_notes, draws_used, nullptr,
-                                  nullptr, p.c.recurrent_sigmoid, 0, c.st);
+                                  nullptr, p.c.recurrent_sigmoid, 0, kflags(p.c), c.st);
 }
 
 int32_t dj_gen_state_size(void) { return dj_gen_state_bytes(); }
@@ -883,7 +876,7 @@ int generate_resident(const dj_config* cfg, const float* params, void* state, fl
   RUN(dj_launch_generate_notes(p.c.dtype, p.B, p.T, p.N, p.Ht, p.Hn, p.Ln, p.S, p.SU, params, offs,
                                c.at(p.w_H_t[p.Lt - 1]), style_win + (int64_t)(p.T - 1) * p.S, (int64_t)p.T * p.S,
                                c.at<float>(p.w_dX_n), uniform_pool, nullptr, nullptr, nullptr, state, results,
-                               p.c.recurrent_sigmoid, static_ready ? 1 : 0, c.st));
+                               p.c.recurrent_sigmoid, static_ready ? 1 : 0, kflags(p.c), c.st));
   return dj_launch_gen_advance(state, results, notes_src, notes_dst, beat_src, beat_dst, p.B, p.T, p.N, p.NB, c.st);
 }
 }  // namespace
@@ -932,7 +925,7 @@ int32_t dj_lstm_fwd_fused(int32_t dtype, int32_t H, int32_t ntiles, int32_t step
   if (D > DP) return 1232;
   return dj_launch_lstm_fwd_fused(dtype, H, ntiles, steps, X, DP, dj_lstm_fused_nkx(dtype, H, D), wpack, bias, stash,
                                   upack_fwd, Hout, Cout, sigm, (env_defaults().flags & DJ_KF_NO_CLUSTER) ? nullptr : cluster_scratch,
-                                  (hipStream_t)stream);
+                                  env_defaults().flags, (hipStream_t)stream);
 }
 int64_t dj_lstm_cluster_scratch_bytes(void) { return dj_lstm_cluster_scratch_bytes_impl(); }
 int64_t dj_lstm_stash_bytes(int32_t dtype, int32_t H, int64_t rows) {
@@ -1000,43 +993,33 @@ int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, con
                     const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias, int32_t sigm,
                     void* stream) {
   return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dz_tile_stride, dbias, sigm, nullptr, 0, nullptr,
-                            0, nullptr, 0, (hipStream_t)stream);
-}
-int32_t dj_lstm_bwd_pair(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack,
-                         const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias, int32_t sigm,
-                         void* cluster_scratch, void* stream) {
-  if (!cluster_scratch || dtype != DJ_BF16 || H != 256) return 1016;
-  return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dz_tile_stride, dbias, sigm, nullptr, 0, nullptr,
-                            0, cluster_scratch, 1, (hipStream_t)stream);
-}
-int32_t dj_lstm_bwd_dual(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack,
-                         const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias, int32_t sigm,
-                         void* cluster_scratch, void* stream) {
-  if (!cluster_scratch || dtype != DJ_BF16 || H != 256) return 1016;
-  return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dz_tile_stride, dbias, sigm, nullptr, 0, nullptr,
-                            0, cluster_scratch, 2, (hipStream_t)stream);
+                            0, (hipStream_t)stream);
 }
 int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack,
                        const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias, int32_t sigm,
                        const void* wtpack, int32_t D, void* dX, int32_t DP, void* stream) {
   if (!wtpack) return 1013;
   return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dz_tile_stride, dbias, sigm, wtpack, D, dX, DP,
-                            nullptr, 0, (hipStream_t)stream);
+                            (hipStream_t)stream);
 }
-int32_t dj_lstm_cluster_faults(void* cluster_scratch) { return dj_lstm_cluster_faults_impl(cluster_scratch); }
-int32_t dj_workspace_cluster_faults(const dj_config* cfg, void* ws, int64_t ws_bytes) {
+int32_t dj_lstm_cluster_faults(void* cluster_scratch, void* stream) {
+  return dj_lstm_cluster_faults_impl(cluster_scratch, (hipStream_t)stream);
+}
+int32_t dj_workspace_cluster_faults(const dj_config* cfg, void* ws, int64_t ws_bytes, void* stream) {
   Plan p;
   if (make_plan(cfg, p) || check_ws(p, ws, ws_bytes)) return -1;
   if (!(p.Ht == 256 || p.Hn == 256)) return 0;
-  return dj_lstm_cluster_faults_impl((char*)ws + p.w_cluster);
+  return dj_lstm_cluster_faults_impl((char*)ws + p.w_cluster, (hipStream_t)stream);
 }
-int32_t dj_workspace_cluster_fault_words(const dj_config* cfg, void* ws, int64_t ws_bytes, int32_t* words_host) {
+int32_t dj_workspace_cluster_fault_report(const dj_config* cfg, void* ws, int64_t ws_bytes, int32_t* words_host,
+                                          void* stream) {
   Plan p;
-  if (!words_host || make_plan(cfg, p) || check_ws(p, ws, ws_bytes)) return 1210;
-  words_host[0] = words_host[1] = 0;
+  RUN(make_plan(cfg, p));
+  RUN(check_ws(p, ws, ws_bytes));
+  if (!words_host) return 1210;
+  memset(words_host, 0, DJ_FAULT_REPORT_WORDS * sizeof(int32_t));
   if (!(p.Ht == 256 || p.Hn == 256)) return 0;
-  return (int)hipMemcpy(words_host, dj_lstm_cluster_fault_words((char*)ws + p.w_cluster), 2 * sizeof(int32_t),
-                        hipMemcpyDeviceToHost);
+  return dj_lstm_cluster_fault_line((char*)ws + p.w_cluster, words_host, (hipStream_t)stream);
 }
 int32_t dj_lstm_pack_wt(int32_t dtype, int32_t H, const float* W, int32_t D, void* out, void* stream) {
   return dj_launch_lstm_pack_wt(dtype, H, W, D, out, (hipStream_t)stream);

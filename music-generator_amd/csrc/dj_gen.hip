@@ -587,7 +587,7 @@ int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int
                              int64_t style_stride,
                              float* scratch, const double* uniforms, const float* temperature, float* next_notes,
                              int* draws_used, void* state, float* results, int sigm, int static_ready,
-                             hipStream_t st) {
+                             uint32_t kf, hipStream_t st) {
   if (G < 1 || G > GEN_MAXG || Ln < 1 || Ln > 4 || 4 * Hn > 1024 || (Hn % 32) || Ht + 3 > 512 || SU > 64 || S > 64) return 1300;
   GenArgs a;
   a.G = G; a.N = N; a.Hn = Hn; a.Ht = Ht; a.Ln = Ln; a.S = S; a.SU = SU; a.T = T; a.P = P;
@@ -614,7 +614,7 @@ int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int
   const size_t smem = ((size_t)3 * Ln * G * Hn + (size_t)G * 4 * Hn + (size_t)G * Hn + 3 * Hn + 4 + (size_t)G * N * 3 + 9 * G + 8) *
                           sizeof(float) + (size_t)2 * N * G * sizeof(double) + 16;
   if (smem > 64 * 1024) return 1301;
-  const bool ks_off = (dj_env_flags() & DJ_KF_NO_GEN_KSPLIT) != 0;
+  const bool ks_off = (kf & DJ_KF_NO_GEN_KSPLIT) != 0;
   if (!ks_off && G <= 4 && 4 * Hn <= 512 && smem + (size_t)3 * G * 4 * Hn * sizeof(float) <= 64 * 1024) {
     const size_t smem_ks = smem + (size_t)3 * G * 4 * Hn * sizeof(float);      // zp is 4 x the size of zb
     if (sigm)

@@ -3,8 +3,8 @@
 #include "dj_common.h"
 #include "../../include/deepj_hip.h"      // DJ_KF_* kernel-selection flags
 
-// DEEPJ_* environment switches as read once at load / dj_env_reload() (dj_api.hip): OR of DJ_KF_* bits
-uint32_t dj_env_flags();
+// `kf` arguments below: the effective DJ_KF_* bits of the call (dj_config.kernel_flags OR-ed with the DEEPJ_* process
+// defaults read once at load / dj_env_reload(): dj_api.hip kflags)
 
 struct FeatArgs {
   const float* notes;   // [B,T,N,3]
@@ -92,12 +92,9 @@ int64_t dj_lstm_stash_row_bytes(int dtype, int H);
 // WTpack/D/dX/DP: optional fused input gradient dX = dz W^T (WTpack from dj_launch_lstm_pack_wt; null = off;
 // available where dj_lstm_bwd_has_dx says so)
 // dz_cts: layout of the dZ output, as for dj_launch_lstm_wgrad (0 = row-major [rows, 4H])
-// cluster_scratch (optional; dj_lstm_cluster_scratch_bytes_impl() bytes, as for the forward cluster): bf16 H = 256 sweeps
-// then run on pairs of workgroups where the device holds the grid -- bwd_mode 1: one tile per pair
-// (lstm_bwd_pair_kernel), 2: two tiles per pair, product and gate math interleaved (lstm_bwd_dual_kernel)
 int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* UTpack, const void* C,
                        const void* dH, void* dZ, int64_t dz_cts, float* dbias, int sigm, const void* WTpack, int D, void* dX,
-                       int DP, void* cluster_scratch, int bwd_mode, hipStream_t st);
+                       int DP, hipStream_t st);
 int dj_lstm_bwd_has_dx(int dtype, int H, int D);
 int dj_launch_lstm_pack_wt(int dtype, int H, const float* W, int D, void* out, hipStream_t st);
 int dj_lstm_fused_nkx(int dtype, int H, int D);
@@ -105,20 +102,23 @@ int dj_launch_lstm_pack_w(int dtype, int H, const float* W, int D, int NKX, void
 // cluster_scratch: dj_lstm_cluster_scratch_bytes_impl() bytes, 128-byte aligned, owned by the caller's workspace
 // (null = per-tile kernel only)
 int dj_launch_lstm_fwd_cluster_f32(int ntiles, int steps, const void* Zx, const void* Upack, void* Hout, int sigm,
-                                   void* scratch, hipStream_t st);
+                                   void* scratch, uint32_t kf, hipStream_t st);
 int dj_launch_lstm_fwd_cluster_pair(int ntiles, int steps, const void* X0, int DP0, const void* W0pack, const float* b0,
                                     const void* U0pack, void* X1, const void* W1pack, const float* b1, const void* U1pack,
                                     void* H1, const float* sp1, int sp_D, int n_seq, int n_b, int sigm, void* scratch,
-                                    hipStream_t st);
+                                    uint32_t kf, hipStream_t st);
 int dj_launch_lstm_fwd_fused(int dtype, int H, int ntiles, int steps, const void* X, int DP, int NKX,
                              const void* Wpack, const float* bias, void* Zst, const void* Upack, void* Hout,
-                             void* Cout, int sigm, void* cluster_scratch, hipStream_t st);
+                             void* Cout, int sigm, void* cluster_scratch, uint32_t kf, hipStream_t st);
 int64_t dj_lstm_cluster_scratch_bytes_impl();
 // expired waits + misplaced clusters recorded in that scratch since the last call (0 in a healthy run; the affected
-// tiles carry NaN), -1 on a HIP error; synchronises
-int dj_lstm_cluster_faults_impl(void* cluster_scratch);
-// device address of the two fault words inside a cluster scratch
+// tiles carry NaN), -1 on a HIP error; drains `st` (asynchronous copy on the caller's stream + synchronise: a blocking
+// copy on the null stream does not order against a non-blocking stream)
+int dj_lstm_cluster_faults_impl(void* cluster_scratch, hipStream_t st);
+// device address of the fault line inside a cluster scratch (32 ints; layout in dj_lstm.hip, "bounded exchange waits")
 void* dj_lstm_cluster_fault_words(void* cluster_scratch);
+// copy of that line as it stands once `st` has drained; resets nothing
+int dj_lstm_cluster_fault_line(void* cluster_scratch, int32_t* words_host, hipStream_t st);
 // dj_step.hip -- generic-H path (one GEMM + gate launch per recurrence step)
 int64_t dj_lstm_step_scratch_floats(int H, int64_t ntiles);
 int dj_launch_lstm_step_fwd(int dtype, int H, int ntiles, int steps, void* Z, const void* Ut, void* Hs, void* Cs,
@@ -155,7 +155,7 @@ int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int
                              const int64_t* offs /* [6 + 5*Ln] */, const void* Htime, const float* style_last,
                              int64_t style_stride, float* scratch, const double* uniforms, const float* temperature,
                              float* next_notes, int* draws_used, void* state, float* results, int sigm,
-                             int static_ready, hipStream_t st);
+                             int static_ready, uint32_t kf, hipStream_t st);
 int dj_launch_gen_advance(void* state, const float* results, const float* nsrc, float* ndst, const float* bsrc,
                           float* bdst, int G, int T, int N, int NB, hipStream_t st);
 int dj_gen_state_bytes();

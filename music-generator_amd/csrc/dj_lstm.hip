@@ -25,10 +25,8 @@
 //    64 k-chunks in the LDS the tiles leave free (BwdUlds);
 //  * lstm_fwd_cluster_kernel (bf16, H = 256, >= 64 tiles): 8 workgroups of one XCD keep the W and U slices of
 //    32 hidden units each in LDS for the whole sweep and exchange h slices through L2 once per step;
-//  * lstm_bwd_pair_kernel / lstm_bwd_dual_kernel (bf16, H = 256; opt-in, DJ_KF_BWD_PAIR / DJ_KF_BWD_DUAL): the BPTT
-//    sweep with a tile's hidden units split over a pair of workgroups that exchange their halves of dz through the dZ
-//    output -- one tile per pair, or two tiles per pair with the product of one folded into the gate math of the
-//    other.  Correct, slower than lstm_bwd_kernel at the BASELINE shape.
+//  * (two re-decompositions of the H = 256 BPTT sweep over PAIRS of workgroups were built in round 3, are correct and
+//    slower than lstm_bwd_kernel: they live in tools/bwd_decompositions/, not in this library)
 // The weight streams are bound by the CU's vector-memory path (64 B/clk), not by L2 or HBM: every fragment
 // that can live in registers or LDS instead is time won, and every loop bound in these kernels has to be a
 // compile-time constant (run-time variants of the same loops measured +0.4 ... +0.5 ms).
@@ -648,8 +646,9 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
 // engine / stream -- never shared between concurrent sweeps):
 //     [0, 16 KiB)     per cluster two 128-byte lines: line 0 = the step counter, line 1 = the members' XCC ids
 //                     (zeroed by cl_reset_kernel in front of every launch)
-//     [16 KiB, +128)  fault words: [0] expired waits, [1] clusters whose members sat on different XCDs (sticky
-//                     until dj_lstm_cluster_faults reads them)
+//     [16 KiB, +128)  fault line: [0] expired waits, [1] workgroups of clusters whose members sat on different XCDs
+//                     (both sticky until the census reads them), stall census, description of the first expired
+//                     wait ("bounded exchange waits" below)
 //     [.., +8 MiB)    hx: [tile][step parity][k-chunk][lane] x 16 bytes
 // Coherence: the members of a cluster must run on ONE XCD, whose L2 is then the coherence point for their h slices
 // (stores acknowledged before the counter moves, exchange loads bypass L1 with sc1).  Round-robin dispatch puts
@@ -683,21 +682,87 @@ __device__ __forceinline__ void cl_load_x(ClXRegs<NR>& q, const bf16_t* xb, int 
       q.v[r][i] = ok ? v : make_uint4(0, 0, 0, 0);
     }
 }
-// Bound of every exchange wait, in shader-clock cycles: ~100 ms.  Hang protection only -- a healthy step meets in
-// microseconds.  (It was ~10 ms until a 1024-step step-wise generation run lost 6 waits on one test box in two
-// consecutive calls and none in the next two on other boxes, with byte-identical kernels: a member's workgroup can be
-// held up for milliseconds by things outside the process.)
-constexpr unsigned long long CL_WAIT_CYCLES = 200000000ull;
-// bounded wait of one wave for its cluster's counter (lane 0 polls); false = expired
-__device__ __forceinline__ bool cl_wait(int* cnt, int target, int lane) {
-  int ok = 1;
-  if (lane == 0) {
-    const unsigned long long t0 = __builtin_readcyclecounter();
-    while ((ok = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) == 0 &&
-           __builtin_readcyclecounter() - t0 < CL_WAIT_CYCLES)    // hang protection only
-      __builtin_amdgcn_s_sleep(2);
+// ---- bounded exchange waits.
+// Fault line of a cluster scratch (32 ints at CL_OFF_FAULT; dj_lstm_cluster_fault_words):
+//   [0] expired waits (waves whose bound ran out)        [1] workgroups of clusters spread over several XCDs
+//   [2] test hook (DJ_KF_DEBUG_CLUSTER_FAULT)
+//   [4] waits that saw two consecutive polls more than CL_GAP_STALL cycles apart   } stall census: cumulative, never
+//   [5] the longest poll-to-poll gap seen, in units of 1024 shader cycles          } reset by the fault census
+//   [8] 1 = words 9..20 describe the FIRST expired wait since the host last took the census:
+//       [9] who (kind << 24 | cluster << 12 | member << 8 | wave; kind 1 = bf16 sweep, 2 = cooperative body, 3 = fp32,
+//       5 / 6 = pair / two-tile BPTT experiments (tools/); bit 28 = the wait was for the PRODUCING layer's counter),
+//       [10] step, [11] counter value seen last, [12] target, [13] polls made, [14..15] shader cycles from the first poll
+//       to the last (64 bit), [16] longest poll-to-poll gap in cycles (saturating), [17] hardware XCC id + 1
+// THE BOUND COUNTS POLLS, NOT TIME.  Until round 4 a wait expired once 20 M (then 200 M) shader cycles had passed since
+// its first poll.  That clock keeps running while the wave does not: when the whole queue is taken off the device for a
+// while (wave save / restore around another process's time slice, an eviction of the process's queues by the driver)
+// every waiter comes back to a poll that still shows the old count -- the late member was off the device too -- next to
+// a clock that says the bound is long gone, and all of them "expire" together although nobody is late relative to anybody
+// else (a 1024-step generation test lost 6 waits at once on one box that way).  A poll
+// is only counted when the wave executes it, so the bound below is ~100 ms of ACTUAL polling (each poll is a load
+// from L2 past the L1, 0.5 - 1 us, plus 128 cycles of sleep) whatever happens to the queue in between.
+// STICKY: the first wave of a cluster whose bound does run out (grid not co-resident: a member never arrives) sets
+// CL_POISON in the cluster's counter, which satisfies every later target at once; a wave that sees the bit -- or fails
+// its placement check -- is `dead`: its tile carries NaN from there on and it does not wait again (it keeps storing and
+// arriving, so no partner stalls on it).  A faulted launch therefore costs ONE bound, not one per remaining step.
+constexpr int CL_POISON = 1 << 30;
+constexpr unsigned CL_WAIT_POLLS = 1u << 17;
+constexpr unsigned CL_GAP_NOTE = 1u << 17, CL_GAP_STALL = 1u << 20;   // ~60 us / ~0.5 ms at 2.1 GHz
+enum { CLF_EXPIRED = 0, CLF_MISPLACED = 1, CLF_HOOK = 2, CLF_STALLS = 4, CLF_MAXGAP = 5, CLF_DIAG = 8, CLF_WORDS = 32 };
+constexpr int CLW_GATE = 1 << 28;
+__device__ __forceinline__ int cl_who(int kind, int cid, int member, int wave) {
+  return kind << 24 | (cid & 0xfff) << 12 | (member & 15) << 8 | (wave & 255);
+}
+// wave-uniform bounded wait for *cnt >= target (every lane polls the same word: one request); returns the value seen
+// (CL_POISON set: some wave of the cluster has given up), or -1 = this wave's bound ran out (counted, described)
+__device__ __forceinline__ int cl_wait(int* cnt, int target, int* fault, int who, int t, int lane) {
+  int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  if (v >= target) return v;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  unsigned last = (unsigned)t0, maxgap = 0, polls = 0;
+#pragma nounroll
+  do {
+    __builtin_amdgcn_s_sleep(2);
+    v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const unsigned now = (unsigned)__builtin_readcyclecounter();
+    const unsigned gap = now - last;
+    last = now;
+    maxgap = gap > maxgap ? gap : maxgap;
+  } while (v < target && ++polls < CL_WAIT_POLLS);     // the last poll is always looked at before giving up
+  if (maxgap > CL_GAP_NOTE && lane == 0) {             // stall census (rare: a healthy poll returns within microseconds)
+    atomicMax(fault + CLF_MAXGAP, (int)(maxgap >> 10));
+    if (maxgap > CL_GAP_STALL) atomicAdd(fault + CLF_STALLS, 1);
   }
-  return __builtin_amdgcn_readfirstlane(ok) != 0;
+  if (v >= target) return v;
+  if (lane == 0) {
+    atomicAdd(fault + CLF_EXPIRED, 1);
+    if (atomicCAS(fault + CLF_DIAG, 0, 1) == 0) {
+      const unsigned long long el = __builtin_readcyclecounter() - t0;
+      fault[CLF_DIAG + 1] = who;
+      fault[CLF_DIAG + 2] = t;
+      fault[CLF_DIAG + 3] = v;
+      fault[CLF_DIAG + 4] = target;
+      fault[CLF_DIAG + 5] = (int)polls;
+      fault[CLF_DIAG + 6] = (int)(unsigned)el;
+      fault[CLF_DIAG + 7] = (int)(unsigned)(el >> 32);
+      fault[CLF_DIAG + 8] = (int)maxgap;
+      fault[CLF_DIAG + 9] = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15) + 1;
+    }
+  }
+  return -1;
+}
+// One exchange wait of a wave under the sticky protocol above.  true = the wave's tile has to be poisoned NOW (its own
+// bound ran out, or another wave of the cluster had given up); a dead wave returns at once.  `seen` (optional) receives
+// the counter value (with CL_POISON once dead: every later target counts as met).
+__device__ __forceinline__ bool cl_wait_step(int* cnt, int target, int* fault, int who, int t, int lane, bool& dead,
+                                             int* seen = nullptr) {
+  if (dead) return false;
+  const int v = cl_wait(cnt, target, fault, who, t, lane);
+  if (seen) *seen = v < 0 ? CL_POISON : v;
+  if (v >= 0 && !(v & CL_POISON)) return false;
+  if (v < 0 && lane == 0) __hip_atomic_fetch_or(cnt, CL_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  dead = true;
+  return true;
 }
 // Wavefront pairing (inference, two stacked layers in ONE launch; lstm_fwd_cluster_pair_kernel): the blocks of the second
 // half of the grid run the upper layer one to three steps behind the lower one.  The lower layer (`sp_out` set) writes,
@@ -712,18 +777,6 @@ struct ClPair {
   int* gate;                // upper layer: counter line of the producing cluster; null = X is ready at launch
   int role;                 // 0 / 1: half of the grid (cluster ids and hx slots of the halves are disjoint)
 };
-// bounded wait that returns the counter value it saw (0 = expired)
-__device__ __forceinline__ int cl_wait_val(int* cnt, int target, int lane) {
-  int v = 0;
-  if (lane == 0) {
-    const unsigned long long t0 = __builtin_readcyclecounter();
-    while ((v = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target &&
-           __builtin_readcyclecounter() - t0 < CL_WAIT_CYCLES)
-      __builtin_amdgcn_s_sleep(2);
-    if (v < target) v = 0;
-  }
-  return __builtin_amdgcn_readfirstlane(v);
-}
 template <bool SIGM, int NKX>
 __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__ X, int DP,
                                                       const bf16_t* __restrict__ Wpack, const float* __restrict__ bias,
@@ -783,16 +836,23 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int hook = __hip_atomic_load(fault + CLF_HOOK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tests only
+  if (tid == 0 && !((hook & 2) && s == CL_M - 1)) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // placement check: once all members have arrived, their XCC ids must be this workgroup's own
+  const int who = cl_who(1, cid, s, w);
+  bool dead = false;                                       // wave-uniform: the tile is poisoned, no more waits (cl_wait_step)
   {
-    bool ok = cl_wait(cnt, ARRIVALS, lane);
-    int other = my_xcc;
-    if (ok && lane < CL_M) other = __hip_atomic_load(xccs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // fault[2]: test hook (DEEPJ_DEBUG_CLUSTER_FAULT): the launch behaves as if its clusters were spread over XCDs
-    const bool same = __all(other == my_xcc) && __hip_atomic_load(fault + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-    if (!ok || !same) {
-      if (lane == 0 && w == 0) atomicAdd(fault + (ok ? 1 : 0), 1);
+    bool bad = cl_wait_step(cnt, ARRIVALS, fault, who, -1, lane, dead);
+    if (!bad) {
+      int other = my_xcc;
+      if (lane < CL_M) other = __hip_atomic_load(xccs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // hook bit 0 (DEEPJ_DEBUG_CLUSTER_FAULT): the launch behaves as if its clusters were spread over XCDs
+      if (!__all(other == my_xcc) || (hook & 1)) {
+        if (lane == 0 && w == 0) atomicAdd(fault + CLF_MISPLACED, 1);
+        dead = bad = true;
+      }
+    }
+    if (bad) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) c[r] = __builtin_nanf("");
     }
@@ -801,13 +861,18 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
   // upper layer of a pair: the producing cluster (same tile, lower half of the grid) must sit on this XCD too
   int* gate = pr.gate ? cl + 2 * lcid * CL_CNT_STRIDE : nullptr;
   int seen = 0;                                            // last value of the producer's counter this wave saw
-  if (gate && active) {
-    seen = cl_wait_val(gate, ARRIVALS * 3, lane);          // rows of step 0 are out once the producer has closed step 1
-    int other = my_xcc;
-    if (seen && lane < CL_M) other = __hip_atomic_load(gate + CL_CNT_STRIDE + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool same = __all(other == my_xcc);
-    if (!seen || !same) {
-      if (lane == 0) atomicAdd(fault + (seen ? 1 : 0), 1);
+  if (gate && active && !dead) {
+    // rows of step 0 are out once the producer has closed step 1
+    bool bad = cl_wait_step(gate, ARRIVALS * 3, fault, who | CLW_GATE, -1, lane, dead, &seen);
+    if (!bad) {
+      int other = my_xcc;
+      if (lane < CL_M) other = __hip_atomic_load(gate + CL_CNT_STRIDE + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!__all(other == my_xcc)) {
+        if (lane == 0) atomicAdd(fault + CLF_MISPLACED, 1);
+        dead = bad = true;
+      }
+    }
+    if (bad) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) c[r] = __builtin_nanf("");
     }
@@ -873,22 +938,16 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
     const T* xnext = X + ((tile * steps + (t + 1 < steps ? t + 1 : t)) * 32 + xr8) * DP + xc * 8;
     // ---- h_{t-1} U: needs the slices of all members
     {
-      if (!cl_wait(cnt, ARRIVALS * (t + 1), lane)) {
-        // a member never arrived (grid not co-resident): never a silent wrong answer -- count it and poison the
-        // cell state, so every later h of this tile, and the loss, is NaN
-        if (lane == 0) atomicAdd(fault, 1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c[r] = __builtin_nanf("");
-      }
+      // a member that never arrives (grid not co-resident) is never a silent wrong answer: the wait is bounded and
+      // counted (cl_wait), and the cell state is poisoned, so every later h of this tile, and the loss, is NaN
+      bool bad = cl_wait_step(cnt, ARRIVALS * (t + 1), fault, who, t, lane, dead);
       // upper layer of a pair: x_{t+1} (requested below) exists once the producer has closed step t + 2; the counter
       // is polled only when the last value seen does not cover it (the producer is faster and runs away)
-      if (gate && t + 1 < steps && seen < ARRIVALS * (t + 4)) {
-        seen = cl_wait_val(gate, ARRIVALS * (t + 4), lane);
-        if (!seen) {
-          if (lane == 0) atomicAdd(fault, 1);
+      if (gate && t + 1 < steps && seen < ARRIVALS * (t + 4))
+        bad |= cl_wait_step(gate, ARRIVALS * (t + 4), fault, who | CLW_GATE, t, lane, dead, &seen);
+      if (bad) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) c[r] = __builtin_nanf("");
-        }
+        for (int r = 0; r < 16; ++r) c[r] = __builtin_nanf("");
       }
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
@@ -1045,28 +1104,39 @@ __device__ __forceinline__ void lstm_fwd_cluster_coop_body(const bf16_t* __restr
   if (tid == 0) __hip_atomic_store(xccs + s, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int hook = __hip_atomic_load(fault + CLF_HOOK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tests only
+  if (tid == 0 && !((hook & 2) && s == CL_M - 1)) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int who = cl_who(2, cid, s, w);
+  bool dead = false;                                       // wave-uniform: poisoned, no more waits (cl_wait_step)
   {
-    bool ok = cl_wait(cnt, ARRIVALS, lane);
-    int other = my_xcc;
-    if (ok && lane < CL_M) other = __hip_atomic_load(xccs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // fault[2]: test hook (DEEPJ_DEBUG_CLUSTER_FAULT): the launch behaves as if its clusters were spread over XCDs
-    const bool same = __all(other == my_xcc) && __hip_atomic_load(fault + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-    if (!ok || !same) {
-      if (lane == 0 && w == 0) atomicAdd(fault + (ok ? 1 : 0), 1);
+    bool bad = cl_wait_step(cnt, ARRIVALS, fault, who, -1, lane, dead);
+    if (!bad) {
+      int other = my_xcc;
+      if (lane < CL_M) other = __hip_atomic_load(xccs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // hook bit 0 (DEEPJ_DEBUG_CLUSTER_FAULT): the launch behaves as if its clusters were spread over XCDs
+      if (!__all(other == my_xcc) || (hook & 1)) {
+        if (lane == 0 && w == 0) atomicAdd(fault + CLF_MISPLACED, 1);
+        dead = bad = true;
+      }
+    }
+    if (bad) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) c4[e] = __builtin_nanf("");
     }
   }
   int* gate = pr.gate ? cl + 2 * lcid * CL_CNT_STRIDE : nullptr;
   int seen = 0;
-  if (gate && live && gwave) {
-    seen = cl_wait_val(gate, ARRIVALS * 3, lane);
-    int other = my_xcc;
-    if (seen && lane < CL_M) other = __hip_atomic_load(gate + CL_CNT_STRIDE + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool same = __all(other == my_xcc);
-    if (!seen || !same) {
-      if (lane == 0 && w == 0) atomicAdd(fault + (seen ? 1 : 0), 1);
+  if (gate && live && gwave && !dead) {
+    bool bad = cl_wait_step(gate, ARRIVALS * 3, fault, who | CLW_GATE, -1, lane, dead, &seen);
+    if (!bad) {
+      int other = my_xcc;
+      if (lane < CL_M) other = __hip_atomic_load(gate + CL_CNT_STRIDE + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!__all(other == my_xcc)) {
+        if (lane == 0 && w == 0) atomicAdd(fault + CLF_MISPLACED, 1);
+        dead = bad = true;
+      }
+    }
+    if (bad) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) c4[e] = __builtin_nanf("");
     }
@@ -1126,18 +1196,12 @@ __device__ __forceinline__ void lstm_fwd_cluster_coop_body(const bf16_t* __restr
     const T* xnext = X + ((tile * steps + (t + 1 < steps ? t + 1 : t)) * 32 + xr8) * DP + xc * 8;
     // ---- h_{t-1} U of gate w
     {
-      if (!cl_wait(cnt, ARRIVALS * (t + 1), lane)) {
-        if (lane == 0 && w == 0) atomicAdd(fault, 1);
+      bool bad = cl_wait_step(cnt, ARRIVALS * (t + 1), fault, who, t, lane, dead);
+      if (gate && t + 1 < steps && seen < ARRIVALS * (t + 4))
+        bad |= cl_wait_step(gate, ARRIVALS * (t + 4), fault, who | CLW_GATE, t, lane, dead, &seen);
+      if (bad) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) c4[e] = __builtin_nanf("");
-      }
-      if (gate && t + 1 < steps && seen < ARRIVALS * (t + 4)) {
-        seen = cl_wait_val(gate, ARRIVALS * (t + 4), lane);
-        if (!seen) {
-          if (lane == 0 && w == 0) atomicAdd(fault, 1);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) c4[e] = __builtin_nanf("");
-        }
       }
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
@@ -1262,14 +1326,21 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_f32_kernel(const float* 
   if (tid == 0) __hip_atomic_store(xccs + s, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int hook = __hip_atomic_load(fault + CLF_HOOK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tests only
+  if (tid == 0 && !((hook & 2) && s == CL_M - 1)) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int who = cl_who(3, cid, s, w);
+  bool dead = false;                                       // wave-uniform: poisoned, no more waits (cl_wait_step)
   {
-    bool ok = cl_wait(cnt, ARRIVALS, lane);
-    int other = my_xcc;
-    if (ok && lane < CL_M) other = __hip_atomic_load(xccs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool same = __all(other == my_xcc) && __hip_atomic_load(fault + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-    if (!ok || !same) {
-      if (lane == 0 && w == 0) atomicAdd(fault + (ok ? 1 : 0), 1);
+    bool bad = cl_wait_step(cnt, ARRIVALS, fault, who, -1, lane, dead);
+    if (!bad) {
+      int other = my_xcc;
+      if (lane < CL_M) other = __hip_atomic_load(xccs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!__all(other == my_xcc) || (hook & 1)) {
+        if (lane == 0 && w == 0) atomicAdd(fault + CLF_MISPLACED, 1);
+        dead = bad = true;
+      }
+    }
+    if (bad) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) c4[e] = __builtin_nanf("");
     }
@@ -1293,8 +1364,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_f32_kernel(const float* 
     for (int i = 0; i < 4; ++i) {
       acc[4 * i] = zx[i].x; acc[4 * i + 1] = zx[i].y; acc[4 * i + 2] = zx[i].z; acc[4 * i + 3] = zx[i].w;
     }
-    if (!cl_wait(cnt, ARRIVALS * (t + 1), lane)) {
-      if (lane == 0 && w == 0) atomicAdd(fault, 1);
+    if (cl_wait_step(cnt, ARRIVALS * (t + 1), fault, who, t, lane, dead)) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) c4[e] = __builtin_nanf("");
     }
@@ -1765,533 +1835,6 @@ __global__ __launch_bounds__((BwdCfg<T, H>::NT)) void lstm_bwd_kernel(const Stas
 
 #undef DJ_DH_LOAD
 
-// ---------------------------------------------------------------- backward, two workgroups per tile (bf16, H = 256)
-// The per-tile kernel above holds a compute unit with ONE tile whose step is a strict chain: gate math (VALU: ~900
-// vector instructions per wave, two waves per SIMD) -> dz tile -> dz U^T (512 KB of U^T fragments through the CU's
-// vector-memory path) -> next gate math.  While one phase runs the other pipe idles, and with 256 tiles for 256 compute
-// units there is no second tile to fill it.  Here a tile is split over a PAIR of workgroups of four waves (blocks b and
-// b + 8: one XCD under round-robin dispatch, verified like the forward cluster's placement): member `part` owns hidden
-// units [128 part, 128 part + 128) -- its gate math, its half of dz, its half of the U^T columns (256 KB per step) --
-// so every compute unit hosts TWO workgroups of different tiles whose phases interleave.  Per step a member
-//   1. computes dz of its units (lane-local, as above) into the LDS tile and stores it to dZ -- the kernel's output IS
-//      the exchange: the partner reads it back from the XCD's L2 (sc1 loads), nothing extra is written;
-//   2. waits for its own stores (vmcnt), every wave then arrives on the pair's counter line (8 arrivals per round);
-//   3. multiplies the OWN half of the k range (its dz columns are already in LDS) -- the partner's stores and
-//      arrivals travel meanwhile;
-//   4. waits for the partner's round, fetches the partner's half of dz_t (32 KB) into the LDS tile, multiplies it.
-// Waits are bounded and counted like the forward cluster's (fault words of the same scratch; the tile's cell gradient is
-// poisoned with NaN, the host repeats the step on the per-tile kernel).  The k order differs from the per-tile kernel
-// (own half first), so results agree to fp32 summation order, not bit for bit.
-constexpr int BP_MAXPAIRS = 256;
-constexpr int BP_ARR = 8;                                  // arrivals per round: 2 members x 4 waves
-constexpr size_t BP_OFF_CNT = CL_BYTES;                    // behind the forward cluster's region: one 128-byte line per
-constexpr size_t BP_BYTES = (size_t)BP_MAXPAIRS * 128;     //   pair, [0] = counter, [8 + part] = XCC ids
-constexpr size_t CL_BYTES_ALL = CL_BYTES + BP_BYTES;
-
-template <bool SIGM>
-__global__ __launch_bounds__(256, 2) void lstm_bwd_pair_kernel(const uint8_t* __restrict__ Z,
-                                                               const bf16_t* __restrict__ UTpack,
-                                                               const bf16_t* __restrict__ C,
-                                                               const bf16_t* __restrict__ dH, bf16_t* __restrict__ dZ,
-                                                               float* __restrict__ dbias, int steps, int64_t dz_cts,
-                                                               int ldz, int* __restrict__ cl, int ntiles, int mate) {
-  using T = bf16_t;
-  constexpr int H = 256, HP = 128;
-  using R = RecCfg<T, H>;
-  using Frag = typename DjFrag<T>::type;
-  constexpr int LDP = HP + R::EPL;                         // row stride of the dH staging tile (own 128 columns)
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* dzs = (T*)smem_raw;                                   // [32][LDZ]: dz_t, all 4H columns
-  T* dhs = dzs + 32 * R::LDZ;                              // [32][LDP]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
-  // pair (b, b + mate): `mate` is 8 (neighbours in dispatch order) or half the grid; a multiple of 8 either way, so
-  // both members sit on one XCD under round-robin dispatch
-  const int bidx = (int)blockIdx.x;
-  int part, pid;
-  if (mate == 8) {
-    part = (bidx >> 3) & 1;
-    pid = (bidx & 7) + 8 * (bidx >> 4);
-  } else {
-    part = bidx >= mate;
-    pid = bidx - part * mate;
-  }
-  if (pid >= ntiles) return;                               // both members of a pair without a tile leave
-  const int64_t tile = pid;
-  const int wb = 4 * part + w;                             // this wave's 32-unit block
-  int* cnt = (int*)((unsigned char*)cl + BP_OFF_CNT) + pid * 32;
-  int* xccs = cnt + 8;
-  int* fault = cl + CL_CNT_INTS;
-
-  float dcc[16], dbs[4];
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    dcc[r] = 0.f;
-    acc[r] = 0.f;
-  }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) dbs[g] = 0.f;
-
-  // round 0: publish the XCD this member runs on, meet the partner, compare
-  const int my_xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15) + 1;   // HW_REG_XCC_ID[3:0]
-  const int my_cu = (int)((__builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11))) & 255) + 1;   // HW_REG_HW_ID[15:8]: cu, sh, se
-  if (tid == 0) {
-    __hip_atomic_store(xccs + part, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(xccs + 2 + part, my_cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  {
-    const bool ok = cl_wait(cnt, BP_ARR, lane);
-    int other = my_xcc;
-    if (ok && lane < 2) other = __hip_atomic_load(xccs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // statistic (fault word 3, not a fault): pairs whose members share a compute unit -- they run in lockstep on one
-    // tile and gain nothing from each other
-    if (ok && tid == 0 && part == 0 &&
-        __hip_atomic_load(xccs + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_cu)
-      atomicAdd(fault + 3, 1);
-    const bool same = __all(other == my_xcc) && __hip_atomic_load(fault + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-    if (!ok || !same) {
-      if (lane == 0 && w == 0) atomicAdd(fault + (ok ? 1 : 0), 1);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dcc[r] = __builtin_nanf("");
-    }
-  }
-
-  // fragment streams and LDS views of the two halves of the k range (k = gate * 256 + unit): half `part` is this
-  // member's own, the other the partner's; 8 k-chunks per gate and half
-  const Frag* up = (const Frag*)UTpack + (int64_t)wb * R::NKCB * 64 + lane;
-  const Frag* up_own = up + 8 * part * 64;
-  const Frag* up_oth = up + 8 * (1 - part) * 64;
-  const T* ap_own = dzs + l31 * R::LDZ + HP * part;
-  const T* ap_oth = dzs + l31 * R::LDZ + HP * (1 - part);
-  auto zaddr = [&](int64_t rb, int g) { return Z + ((rb * R::NCB + (g * H + wb * 32) / 32) * 64 + lane) * 16; };
-  auto caddr = [&](int64_t rb) { return C + ((rb * R::NCBH + wb) * 64 + lane) * 16; };
-  // dH_t, own 128 columns: 32 rows x 16 vectors of 16 bytes = 2 per thread (named scalars: see the kernel above)
-  auto dh_ld = [&](int64_t rb, int i) {
-    const int v = tid + 256 * i, row = v >> 4, cv = (v & 15) * 8;
-    return *(const uint4*)(dH + (rb * 32 + row) * H + HP * part + cv);
-  };
-  auto dh_st = [&](int i, uint4 val) {
-    const int v = tid + 256 * i, row = v >> 4, cv = (v & 15) * 8;
-    *(uint4*)(dhs + row * LDP + cv) = val;
-  };
-  // half a dz tile between LDS and dZ: 32 rows x 4 gates x 256 bytes = 8 vectors of 16 bytes per thread; one column
-  // tile (gate) per pass, 4 rows x 256 bytes per wave instruction
-  auto dz_off = [&](int i, int half, int& lds_off) {
-    const int g = i >> 1, v2 = tid + 256 * (i & 1), row = v2 >> 4, cv = (v2 & 15) * 8 + HP * half;
-    lds_off = row * R::LDZ + g * H + cv;
-    return (int64_t)g * dz_cts + (int64_t)row * ldz + cv;
-  };
-  // dz_t U^T in two halves of 32 k-chunks -- the own half of the k range, then the partner's -- each through a ring of
-  // RD fragments.  Chunk i of a half: gate i / 8, chunk i % 8 of that half's 8 per gate.  Rolled loops of RD (fully
-  // unrolled, hipcc hoists every fragment load and spills).
-  constexpr int RD = 8;
-  auto choff = [](int i) { return (16 * (i / 8) + i % 8) * 64; };
-  auto ring_fill = [&](Frag (&bq)[RD], const Frag* ub) {
-#pragma unroll
-    for (int p = 0; p < RD; ++p) bq[p] = ub[choff(p)];
-  };
-  // consume chunks [RD * it, RD * it + RD) of the half at (ab), refill with the RD chunks that follow in the stream
-  auto prod_turn = [&](Frag (&bq)[RD], const T* ab, int it, const Frag* refill) {
-#pragma unroll
-    for (int u = 0; u < RD; ++u) {
-      const int i = u;            // chunk within the turn; (RD * it) enters through the pointers
-      Frag a = dj_lds_frag(ab + 256 * (i / 8) + 16 * (i % 8), h);
-      dj_mfma(acc, a, bq[u]);
-      if (refill) bq[u] = refill[choff(u)];
-      if ((u & 3) == 3) asm volatile("" ::: "memory");     // keeps the refills where they are written (register budget)
-    }
-    (void)it;
-  };
-
-  Frag16<T> cnext, cprev;
-  GateDec<T, SIGM> gd;
-  uint4 dh0 = dh_ld(tile * steps + steps - 1, 0), dh1 = dh_ld(tile * steps + steps - 1, 1);
-  cnext.load(caddr(tile * steps + steps - 1));
-
-  for (int t = steps - 1; t >= 0; --t) {
-    const int64_t rb = tile * steps + t;
-    dh_st(0, dh0);
-    dh_st(1, dh1);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) gd.load(g, zaddr(rb, g));
-    if (t > 0) {
-      cprev.load(caddr(rb - 1));
-      dh0 = dh_ld(rb - 1, 0);
-      dh1 = dh_ld(rb - 1, 1);
-    }
-    lds_barrier();     // dH_t staged; every wave has left the previous step's product (its reads of the dz tile)
-    float dhv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dhv[r] = dj_to_f32(dhs[dj_crow(r, lane) * LDP + w * 32 + l31]) + acc[r];
-    {
-      const int u = wb * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = dj_crow(r, lane);
-        float ig, fg, gg, og, di, df, dO;
-        gd.get(r, ig, fg, gg, og, di, df, dO);
-        const float ct = cnext.get(r);
-        const float cp = (t > 0) ? cprev.get(r) : 0.f;
-        const float dh = dhv[r];
-        const float tc = dj_tanh(ct);
-        const float dzo = dh * tc * dO;
-        const float dc = dcc[r] + dh * og * (1.f - tc * tc);
-        const float dzi = dc * gg * di;
-        const float dzf = dc * cp * df;
-        const float dzg = dc * ig * (1.f - gg * gg);
-        dcc[r] = dc * fg;
-        T* dp = dzs + row * R::LDZ + u;
-        dj_lds_put2(dp, dp + H, dzi, dzf);
-        dj_lds_put2(dp + 2 * H, dp + 3 * H, dzg, dzo);
-        dbs[0] += dzi;
-        dbs[1] += dzf;
-        dbs[2] += dzg;
-        dbs[3] += dzo;
-      }
-      if (t > 0) cnext.copy_from(cprev);
-    }
-    lds_barrier();     // this member's half of dz_t is complete in LDS
-    bf16_t* dzg_ = dZ + rb * 32 * ldz;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int lo;
-      const int64_t go = dz_off(i, part, lo);
-      *(uint4*)(dzg_ + go) = *(const uint4*)(dzs + lo);
-    }
-    if (t > 0) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      // the stores above are the exchange: once acknowledged (they are in the XCD's L2), this wave arrives
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      Frag bq[RD];
-      // opaque per step (as loop invariants hipcc keeps all 64 fragment addresses in registers and spills them);
-      // through an offset, so that the pointers keep their address space (global_load, not flat_load)
-      int64_t uoff = 0;
-      asm volatile("" : "+v"(uoff));
-      const Frag *uo = up_own + uoff, *ut = up_oth + uoff;
-      ring_fill(bq, uo);
-      constexpr int NTURN = 32 / RD, GPT = RD / 8;         // turns per half, gates per turn
-#pragma unroll 1
-      for (int it = 0; it + 1 < NTURN; ++it) prod_turn(bq, ap_own + 256 * GPT * it, it, uo + 16 * GPT * (it + 1) * 64);
-      prod_turn(bq, ap_own + 256 * GPT * (NTURN - 1), NTURN - 1, nullptr);
-      // the partner half's first fragments travel during the exchange.  (Requested from inside the own half's last
-      // turn instead -- one continuous stream -- the sweep was 4 % slower; a ring of 16 was 6 % slower: with two
-      // workgroups streaming on one compute unit the fragment stream is bound by the CU's vector-memory path, not by
-      // bytes in flight.)
-      ring_fill(bq, ut);
-      if (!cl_wait(cnt, BP_ARR * (steps - t + 1), lane)) {
-        if (lane == 0) atomicAdd(fault, 1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dcc[r] = __builtin_nanf("");
-      }
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("" ::: "memory");
-      uint4 pz[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        int lo;
-        const int64_t go = dz_off(i, 1 - part, lo);
-        pz[i] = ld_sc1((const uint4*)(dzg_ + go));
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        int lo;
-        dz_off(i, 1 - part, lo);
-        *(uint4*)(dzs + lo) = pz[i];
-      }
-      lds_barrier();   // the partner's half of dz_t is in LDS
-#pragma unroll 1
-      for (int it = 0; it + 1 < NTURN; ++it) prod_turn(bq, ap_oth + 256 * GPT * it, it, ut + 16 * GPT * (it + 1) * 64);
-      prod_turn(bq, ap_oth + 256 * GPT * (NTURN - 1), NTURN - 1, nullptr);
-    }
-  }
-  if (dbias) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float v = dbs[g];
-      v += __shfl_xor(v, 32);
-      if (h == 0) atomicAdd(dbias + g * H + wb * 32 + l31, v);
-    }
-  }
-}
-
-// ---------------------------------------------------------------- backward, TWO tiles on a pair of workgroups (bf16, H = 256)
-// The pair kernel above showed that two independent workgroups per compute unit do not interleave by themselves.  Here
-// the interleave is written into ONE instruction stream: a pair of workgroups (blocks b, b + 8; four waves each, ONE
-// per SIMD, so the whole VGPR + AGPR file is theirs) owns TWO sequence tiles, A and B; member `part` owns hidden units
-// [128 part, +128) of both, wave w the 32-unit block 4 part + w.  A wave alternates between the tiles:
-//     slot A(t):  gate math of A at step t  (VALU)   ||  dz_B(t+1) U^T  (MFMA + the U^T fragment stream)
-//     slot B(t):  gate math of B at step t           ||  dz_A(t) U^T
-// four k-chunks of the other tile's product behind each of the 16 gate-math elements, so the MFMAs and their
-// fragment loads run in the shadow of the gate math's vector instructions instead of after them.  The product's own
-// half of the k range comes first (the member's own dz columns, written one slot earlier); the partner's half of that
-// dz tile is fetched from L2 in the middle of the slot (element 8) -- the partner stored it half a slot ago, so the
-// exchange latency is off the chain -- and multiplied behind elements 8..15.  The U^T fragments are ONE endless stream
-// (own half, partner half, own half, ...: the same 64 chunks every slot, both tiles share the wave's slice) through a
-// ring that never drains.  Exchange, placement check and fault handling as in lstm_bwd_pair_kernel (counter line of
-// the pair: [0] tile A, [1] tile B).
-template <bool SIGM>
-__global__ __launch_bounds__(256) void lstm_bwd_dual_kernel(const uint8_t* __restrict__ Z, const bf16_t* __restrict__ UTpack,
-                                                            const bf16_t* __restrict__ C, const bf16_t* __restrict__ dH,
-                                                            bf16_t* __restrict__ dZ, float* __restrict__ dbias, int steps,
-                                                            int64_t dz_cts, int ldz, int* __restrict__ cl, int ntiles) {
-  using T = bf16_t;
-  constexpr int H = 256, HP = 128;
-  using R = RecCfg<T, H>;
-  using Frag = typename DjFrag<T>::type;
-  constexpr int LDP = HP + R::EPL;
-  constexpr int TILE_EL = 32 * R::LDZ + 32 * LDP;          // LDS elements per tile: dz tile [32][LDZ] + dH staging [32][LDP]
-  constexpr int RD = 16;                                   // U^T ring: 4 waves x 16 KB in flight per compute unit
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* const lds = (T*)smem_raw;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, l31 = lane & 31;
-  const int bidx = (int)blockIdx.x, part = (bidx >> 3) & 1, pid = (bidx & 7) + 8 * (bidx >> 4);
-  if (2 * pid >= ntiles) return;                           // ntiles is even: both tiles of a pair exist or neither
-  const int64_t tile0 = 2 * pid;
-  const int wb = 4 * part + w;
-  int* line = (int*)((unsigned char*)cl + BP_OFF_CNT) + pid * 32;
-  int* xccs = line + 8;
-  int* fault = cl + CL_CNT_INTS;
-
-  float dcc[2][16], dbs[4];
-  f32x16 acc[2];
-#pragma unroll
-  for (int x = 0; x < 2; ++x)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      dcc[x][r] = 0.f;
-      acc[x][r] = 0.f;
-    }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) dbs[g] = 0.f;
-
-  // round 0 (on tile A's counter): publish the XCD, meet the partner, compare
-  const int my_xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15) + 1;
-  if (tid == 0) __hip_atomic_store(xccs + part, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0) __hip_atomic_fetch_add(line, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  {
-    const bool ok = cl_wait(line, BP_ARR, lane);
-    int other = my_xcc;
-    if (ok && lane < 2) other = __hip_atomic_load(xccs + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool same = __all(other == my_xcc) && __hip_atomic_load(fault + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-    if (!ok || !same) {
-      if (lane == 0 && w == 0) atomicAdd(fault + (ok ? 1 : 0), 1);
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dcc[x][r] = __builtin_nanf("");
-    }
-  }
-
-  const Frag* up = (const Frag*)UTpack + (int64_t)wb * R::NKCB * 64 + lane;
-  const Frag* up_own = up + 8 * part * 64;
-  const Frag* up_oth = up + 8 * (1 - part) * 64;
-  auto choff = [](int i) { return (16 * (i / 8) + i % 8) * 64; };      // chunk i of a half: gate i / 8, chunk i % 8
-  auto zaddr = [&](int64_t rb, int g) { return Z + ((rb * R::NCB + (g * H + wb * 32) / 32) * 64 + lane) * 16; };
-  auto caddr = [&](int64_t rb) { return C + ((rb * R::NCBH + wb) * 64 + lane) * 16; };
-  auto dh_ld = [&](int64_t rb, int i) {
-    const int v = tid + 256 * i, row = v >> 4, cv = (v & 15) * 8;
-    return *(const uint4*)(dH + (rb * 32 + row) * H + HP * part + cv);
-  };
-  auto dz_off = [&](int i, int half, int& lds_off) {
-    const int g = i >> 1, v2 = tid + 256 * (i & 1), row = v2 >> 4, cv = (v2 & 15) * 8 + HP * half;
-    lds_off = row * R::LDZ + g * H + cv;
-    return (int64_t)g * dz_cts + (int64_t)row * ldz + cv;
-  };
-
-  Frag16<T> cnext[2], cprev[2];
-  GateDec<T, SIGM> gd[2];
-  uint4 dhr[2][2];
-  Frag bq[RD];
-#pragma unroll
-  for (int p = 0; p < RD; ++p) bq[p] = up_own[choff(p)];
-
-  // one slot: gate math of tile X at step t, with the product dz_Y(ty) U^T of the other tile folded in (do_p)
-  // (do_p is a compile-time flag: with a run-time branch around every product group hipcc's wait-count bookkeeping
-  // loses the order of the ring's loads across the joins and waits for nearly all of them before every MFMA)
-  auto slot = [&](auto xc, auto pc, int t) {
-    constexpr int X = decltype(xc)::value, Y = 1 - X;
-    constexpr bool do_p = decltype(pc)::value;
-    T* const dzx = lds + X * TILE_EL;
-    T* const dzy = lds + Y * TILE_EL;
-    const T* const dhx = dzx + 32 * R::LDZ;
-    T* const dhy = dzy + 32 * R::LDZ;
-    const int64_t rbx = (tile0 + X) * steps + t;
-    const int ty = X == 0 ? t + 1 : t;                     // slot A(t) carries P_B(t+1), slot B(t) carries P_A(t)
-    const int64_t rby = (tile0 + Y) * steps + ty;
-    const int tn = X == 0 ? t : t - 1;                     // the next gate slot is G_Y(tn)
-    // its stash is requested in the MIDDLE of this slot, once the exchange's loads have landed: vector memory returns
-    // in order, so HBM loads issued at the top of the slot held up every ring fragment behind them (the first eight
-    // elements took 6.7 k cycles against 3.9 k for the second eight), and in front of the exchange they held up its
-    // counter poll (4.4 k).  Here only the ring refills issued after them can be delayed, and those are not needed
-    // for four elements.
-    auto prefetch_next = [&]() {
-      if (tn >= 0) {
-        const int64_t rbn = (tile0 + Y) * steps + tn;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) gd[Y].load(g, zaddr(rbn, g));
-        cprev[Y].load(caddr(tn > 0 ? rbn - 1 : rbn));
-        dhr[Y][0] = dh_ld(rbn, 0);
-        dhr[Y][1] = dh_ld(rbn, 1);
-      }
-    };
-    float dhv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dhv[r] = dj_to_f32(dhx[dj_crow(r, lane) * LDP + w * 32 + l31]) + acc[X][r];
-    if constexpr (do_p) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[Y][r] = 0.f;
-    }
-    const T* ap_own = dzy + l31 * R::LDZ + HP * part;
-    const T* ap_oth = dzy + l31 * R::LDZ + HP * (1 - part);
-    // opaque per slot (as loop invariants hipcc keeps all 64 fragment addresses in registers) -- through an OFFSET:
-    // a laundered pointer loses its address space and every fragment load becomes a flat_load, which hipcc can only
-    // wait for with vmcnt(0) lgkmcnt(0), i.e. each group of products waited for the refills issued just before it
-    int64_t uoff = 0;
-    asm volatile("" : "+v"(uoff));
-    const Frag *uo = up_own + uoff, *ut = up_oth + uoff;
-    const int u = wb * 32 + l31;
-    Frag an[4];
-    auto afrag_read = [&](int rr) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int pos = 4 * rr + j, i = pos & 31;
-        an[j] = dj_lds_frag((pos < 32 ? ap_own : ap_oth) + 256 * (i / 8) + 16 * (i % 8), h);
-      }
-    };
-    if constexpr (do_p) afrag_read(0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (r == 8) {
-        if constexpr (!do_p) prefetch_next();
-        if constexpr (do_p) {
-          // the partner's half of dz_Y(ty): stored half a slot ago, fetched into the LDS tile now
-          const int target = BP_ARR * ((steps - ty) + (Y == 0 ? 1 : 0));
-          if (!cl_wait(line + Y, target, lane)) {
-            if (lane == 0) atomicAdd(fault, 1);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) dcc[Y][q] = __builtin_nanf("");
-          }
-          __builtin_amdgcn_wave_barrier();
-          asm volatile("" ::: "memory");
-          const bf16_t* gsrc = dZ + rby * 32 * ldz;
-          uint4 pz[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            int lo;
-            const int64_t go = dz_off(i, 1 - part, lo);
-            pz[i] = ld_sc1((const uint4*)(gsrc + go));
-          }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            int lo;
-            dz_off(i, 1 - part, lo);
-            *(uint4*)(dzy + lo) = pz[i];
-          }
-          asm volatile("" ::: "memory");
-          prefetch_next();
-        }
-        lds_barrier();       // the partner's half of dz_Y is in LDS (every wave passes here, product or not)
-        if constexpr (do_p) afrag_read(8);
-      }
-      {
-        const int row = dj_crow(r, lane);
-        float ig, fg, gg, og, di, df, dO;
-        gd[X].get(r, ig, fg, gg, og, di, df, dO);
-        const float ct = cnext[X].get(r);
-        const float cp = (t > 0) ? cprev[X].get(r) : 0.f;
-        const float dh = dhv[r];
-        const float tc = dj_tanh(ct);
-        const float dzo = dh * tc * dO;
-        const float dc = dcc[X][r] + dh * og * (1.f - tc * tc);
-        const float dzi = dc * gg * di;
-        const float dzf = dc * cp * df;
-        const float dzg = dc * ig * (1.f - gg * gg);
-        dcc[X][r] = dc * fg;
-        T* dp = dzx + row * R::LDZ + u;
-        dj_lds_put2(dp, dp + H, dzi, dzf);
-        dj_lds_put2(dp + 2 * H, dp + 3 * H, dzg, dzo);
-        dbs[0] += dzi;
-        dbs[1] += dzf;
-        dbs[2] += dzg;
-        dbs[3] += dzo;
-      }
-      if constexpr (do_p) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int pos = 4 * r + j;                                   // 0..31 own half, 32..63 the partner's
-          dj_mfma(acc[Y], an[j], bq[pos % RD]);
-          const int pn = (pos + RD) & 63, in = pn & 31;                // the stream repeats every slot
-          bq[pos % RD] = (pn < 32 ? uo : ut)[choff(in)];
-        }
-        // the A fragments of the next group are read a whole element ahead (read right in front of their MFMAs they
-        // cost an LDS round trip per pair); the partner half's first group (element 8) is read behind the mid barrier
-        if (r != 7 && r != 15) afrag_read(r + 1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (t > 0) cnext[X].copy_from(cprev[X]);
-    if (tn >= 0) {           // stage dH of the next gate slot
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int v = tid + 256 * i, row = v >> 4, cv = (v & 15) * 8;
-        *(uint4*)(dhy + row * LDP + cv) = dhr[Y][i];
-      }
-    }
-    lds_barrier();           // dz_X(t), own half, complete in LDS; dH staged; every wave has left this slot's LDS reads
-    bf16_t* gdst = dZ + rbx * 32 * ldz;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int lo;
-      const int64_t go = dz_off(i, part, lo);
-      *(uint4*)(gdst + go) = *(const uint4*)(dzx + lo);
-    }
-    if (t > 0) {             // the stores are the exchange: acknowledged, this wave arrives on tile X's counter
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(line + X, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
-
-  // prologue: the stash of G_A(steps - 1), its dH staged
-  {
-    const int64_t rb = tile0 * steps + steps - 1;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) gd[0].load(g, zaddr(rb, g));
-    cnext[0].load(caddr(rb));
-    cnext[1].load(caddr((tile0 + 1) * steps + steps - 1));
-    if (steps > 1) cprev[0].load(caddr(rb - 1));
-    T* const dh0 = lds + 32 * R::LDZ;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int v = tid + 256 * i, row = v >> 4, cv = (v & 15) * 8;
-      *(uint4*)(dh0 + row * LDP + cv) = dh_ld(rb, i);
-    }
-    lds_barrier();
-  }
-  // slot A(t) carries the product of B at t + 1, slot B(t) that of A at t: the first and the last slot have none
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  slot(I0{}, std::false_type{}, steps - 1);
-  for (int t = steps - 1; t > 0; --t) {
-    slot(I1{}, std::true_type{}, t);
-    slot(I0{}, std::true_type{}, t - 1);
-  }
-  slot(I1{}, std::false_type{}, 0);
-  if (dbias) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float v = dbs[g];
-      v += __shfl_xor(v, 32);
-      if (h == 0) atomicAdd(dbias + g * H + wb * 32 + l31, v);
-    }
-  }
-}
 
 template <typename T, int H> int launch_pack(const float* U, void* fwd, void* bwd, hipStream_t st) {
   int n = H * 4 * H;
@@ -2467,44 +2010,50 @@ int cluster_cus() {
 // kernel edges do not have that problem.
 __global__ void cl_reset_kernel(uint4* p) { p[blockIdx.x * 256 + threadIdx.x] = make_uint4(0, 0, 0, 0); }
 int cluster_reset(void* scratch, hipStream_t st) {
-  static_assert(CL_OFF_FAULT % (256 * 16) == 0 && BP_BYTES % (256 * 16) == 0 && BP_OFF_CNT % 128 == 0, "reset grid");
+  static_assert(CL_OFF_FAULT % (256 * 16) == 0, "reset grid");
   hipLaunchKernelGGL(cl_reset_kernel, dim3(CL_OFF_FAULT / (256 * 16)), dim3(256), 0, st, (uint4*)scratch);
   return (int)hipGetLastError();
 }
-// Test hook: with DEEPJ_DEBUG_CLUSTER_FAULT set, the next launches fail their placement check (word 2 of the fault
-// line), so that the host-side handling (fallback in fit, errors in predict / generation) can be exercised on hardware.
-int cluster_fault_hook(void* scratch, hipStream_t st) {
+// Test hooks (word 2 of the fault line), so that the fault handling can be exercised on hardware, deterministically:
+// DJ_KF_DEBUG_CLUSTER_FAULT (bit 0 of the word): the next launches fail their placement check (fallback in fit, errors
+// in predict / generation); DJ_KF_DEBUG_CLUSTER_LATE (bit 1): the last member of every cluster never arrives in round 0,
+// so every other wave's bound really runs out -- once (poison bit, sticky), which the launch duration shows.
+__global__ void cl_hook_kernel(int* f, int v) { f[CLF_HOOK] = v; }
+int cluster_fault_hook(void* scratch, uint32_t kf, hipStream_t st) {
   static void* armed[16] = {};                        // scratches whose hook word is set (a handful of engines at most)
-  const bool want = (dj_env_flags() & DJ_KF_DEBUG_CLUSTER_FAULT) != 0;
+  static int armed_v[16] = {};
+  const int want = ((kf & DJ_KF_DEBUG_CLUSTER_FAULT) ? 1 : 0) | ((kf & DJ_KF_DEBUG_CLUSTER_LATE) ? 2 : 0);
   int slot = -1, free_slot = -1;
   for (int i = 0; i < 16; ++i) {
     if (armed[i] == scratch) slot = i;
     if (!armed[i] && free_slot < 0) free_slot = i;
   }
-  if (want && slot < 0) {
-    if (free_slot < 0) return 1018;
-    if (hipMemsetAsync((char*)scratch + CL_OFF_FAULT + 8, 1, 4, st) != hipSuccess) return 1018;
-    armed[free_slot] = scratch;
-  } else if (!want && slot >= 0) {
-    if (hipMemsetAsync((char*)scratch + CL_OFF_FAULT + 8, 0, 4, st) != hipSuccess) return 1018;
-    armed[slot] = nullptr;
-  }
+  if (slot < 0 && !want) return 0;
+  if (slot >= 0 && armed_v[slot] == want) return 0;
+  if (slot < 0) slot = free_slot;
+  if (slot < 0) return 1018;
+  hipLaunchKernelGGL(cl_hook_kernel, dim3(1), dim3(1), 0, st, (int*)((char*)scratch + CL_OFF_FAULT), want);
+  if (hipGetLastError() != hipSuccess) return 1018;
+  armed[slot] = want ? scratch : nullptr;
+  armed_v[slot] = want;
   return 0;
 }
 int launch_fwd_cluster(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
-                       void* Zst, const void* Upack, void* Hout, void* Cout, int sigm, void* scratch, hipStream_t st) {
+                       void* Zst, const void* Upack, void* Hout, void* Cout, int sigm, void* scratch, uint32_t kf,
+                       hipStream_t st) {
   using R = RecCfg<bf16_t, 256>;
   if (ntiles < 1 || ntiles > 256 || NKX * R::KC > 256 || DP > 256 || DP % 8 || !scratch || ((uintptr_t)scratch & 127))
     return 1016;
   const size_t smem = (size_t)(4 * NKX * 64 + 4 * R::NKC * 64) * 16 + (size_t)8 * 4096;
   // counters and XCC ids of every cluster start at zero in every launch (cl_reset_kernel: a kernel node under graph capture)
   if (int rc = cluster_reset(scratch, st)) return rc;
-  if (int rc = cluster_fault_hook(scratch, st)) return rc;
+  if (int rc = cluster_fault_hook(scratch, kf, st)) return rc;
   return sigm ? launch_fwd_cluster_s<true>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st)
               : launch_fwd_cluster_s<false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st);
 }
 
-int launch_fwd_cluster_pair(int ntiles, int steps, const ClPairArgs& a, int sigm, void* scratch, hipStream_t st) {
+int launch_fwd_cluster_pair(int ntiles, int steps, const ClPairArgs& a, int sigm, void* scratch, uint32_t kf,
+                            hipStream_t st) {
   using R = RecCfg<bf16_t, 256>;
   if (ntiles < 1 || ntiles > 64 || a.DP0 > 128 || a.DP0 % 8 || !scratch || ((uintptr_t)scratch & 127) || a.sp_D < 256)
     return 1016;
@@ -2522,9 +2071,9 @@ int launch_fwd_cluster_pair(int ntiles, int steps, const ClPairArgs& a, int sigm
     attr_done = true;
   }
   if (int rc = cluster_reset(scratch, st)) return rc;
-  if (int rc = cluster_fault_hook(scratch, st)) return rc;
+  if (int rc = cluster_fault_hook(scratch, kf, st)) return rc;
   // at most one tile per cluster (8 clusters per layer): the cooperative body, four waves per tile
-  const bool coop_off = (dj_env_flags() & DJ_KF_NO_CLUSTER_COOP) != 0;
+  const bool coop_off = (kf & DJ_KF_NO_CLUSTER_COOP) != 0;
   const bool coop = ntiles <= 8 && !coop_off;
 #define DJ_PAIR_LAUNCH(S, C_) \
   hipLaunchKernelGGL((lstm_fwd_cluster_pair_kernel<S, C_>), dim3(128), dim3(512), smem, st, a, steps, (int*)scratch, ntiles)
@@ -2537,127 +2086,13 @@ int launch_fwd_cluster_pair(int ntiles, int steps, const ClPairArgs& a, int sigm
   return (int)hipGetLastError();
 }
 
-// BPTT of a bf16 H = 256 layer on pairs of workgroups (lstm_bwd_pair_kernel): at most 256 tiles per launch, two
-// workgroups per compute unit, the whole grid co-resident.  Returns 1017 when the device cannot hold it (the caller then
-// uses the per-tile kernel).
-int bwd_pair_blocks_per_cu() {
-  static int bpc[DJ_MAX_DEVICES] = {};
-  const int dev = dj_current_device();
-  if (!bpc[dev]) {
-    const size_t smem = (size_t)(32 * RecCfg<bf16_t, 256>::LDZ + 32 * (128 + 8)) * sizeof(bf16_t);
-    const void* fns[2] = {(const void*)lstm_bwd_pair_kernel<false>, (const void*)lstm_bwd_pair_kernel<true>};
-    int least = 1 << 30;
-    for (const void* fn : fns) {
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return 0;
-      int n = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, smem) != hipSuccess) return 0;
-      least = n < least ? n : least;
-    }
-    bpc[dev] = least > 0 ? least : -1;
-  }
-  return bpc[dev] > 0 ? bpc[dev] : 0;
-}
-int launch_bwd_pair(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
-                    int64_t dz_cts_in, float* dbias, int sigm, void* scratch, hipStream_t st) {
-  using R = RecCfg<bf16_t, 256>;
-  constexpr int H = 256;
-  if (!scratch || ((uintptr_t)scratch & 127)) return 1016;
-  const int64_t dz_cts = dz_cts_in ? dz_cts_in : 256;
-  const int ldz = dz_cts_in ? 256 : 4 * H;
-  if (dz_cts_in && dz_cts_in < (int64_t)ntiles * steps * 32 * 256) return 1018;
-  const int64_t slots = (int64_t)cluster_cus() * bwd_pair_blocks_per_cu() / 2;       // pairs the device holds at once
-  const int cap = (int)(slots < BP_MAXPAIRS ? slots / 8 * 8 : BP_MAXPAIRS);
-  if (cap < 8) return 1017;
-  const size_t smem = (size_t)(32 * R::LDZ + 32 * (128 + 8)) * sizeof(bf16_t);
-  const uint8_t* z = (const uint8_t*)Z;
-  const bf16_t *c = (const bf16_t*)C, *dh = (const bf16_t*)dH;
-  bf16_t* dz = (bf16_t*)dZ;
-  while (ntiles > 0) {
-    const int n = ntiles < cap ? ntiles : cap;
-    // counter lines of the pairs start at zero in every launch (a kernel, not a memset node: cluster_reset above)
-    hipLaunchKernelGGL(cl_reset_kernel, dim3(BP_BYTES / (256 * 16)), dim3(256), 0, st,
-                       (uint4*)((unsigned char*)scratch + BP_OFF_CNT));
-    if (int rc = cluster_fault_hook(scratch, st)) return rc;
-    const dim3 grid((n + 7) / 8 * 16);
-    const int mate = 8;      // neighbours in dispatch order; (half the grid apart: all 256 pairs on ONE compute unit each, +5 %)
-    if (sigm)
-      hipLaunchKernelGGL((lstm_bwd_pair_kernel<true>), grid, dim3(256), smem, st, z, (const bf16_t*)UTpack, c, dh, dz, dbias,
-                         steps, dz_cts, ldz, (int*)scratch, n, mate);
-    else
-      hipLaunchKernelGGL((lstm_bwd_pair_kernel<false>), grid, dim3(256), smem, st, z, (const bf16_t*)UTpack, c, dh, dz, dbias,
-                         steps, dz_cts, ldz, (int*)scratch, n, mate);
-    if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
-    const int64_t rows = (int64_t)n * steps * 32;
-    z += rows * 4 * H;
-    c += rows * H;
-    dh += rows * H;
-    dz += rows * ldz;
-    ntiles -= n;
-  }
-  return 0;
-}
-
-// BPTT of a bf16 H = 256 layer with two tiles per workgroup pair (lstm_bwd_dual_kernel): one workgroup per compute unit
-// (150 KB of LDS), at most `compute units` tiles per launch, an even number of them (an odd last tile takes the
-// per-tile kernel).  Returns 1017 when the device cannot hold a group of 16 workgroups.
-template <typename T, int H, int DX>
-int launch_bwd_x(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
-                 int64_t dz_cts_in, float* dbias, int sigm, const void* WTpack, int NQ, void* dX, int DP, hipStream_t st);
-int launch_bwd_dual(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
-                    int64_t dz_cts_in, float* dbias, int sigm, void* scratch, hipStream_t st) {
-  using R = RecCfg<bf16_t, 256>;
-  constexpr int H = 256;
-  if (!scratch || ((uintptr_t)scratch & 127)) return 1016;
-  const int64_t dz_cts = dz_cts_in ? dz_cts_in : 256;
-  const int ldz = dz_cts_in ? 256 : 4 * H;
-  if (dz_cts_in && dz_cts_in < (int64_t)ntiles * steps * 32 * 256) return 1018;
-  const int cap = cluster_cus() / 16 * 16 < 2 * BP_MAXPAIRS ? cluster_cus() / 16 * 16 : 2 * BP_MAXPAIRS;   // tiles per launch
-  if (cap < 16) return 1017;
-  const size_t smem = (size_t)2 * (32 * R::LDZ + 32 * (128 + 8)) * sizeof(bf16_t);
-  static bool attr_done_dev[DJ_MAX_DEVICES] = {};
-  bool& attr_done = attr_done_dev[dj_current_device()];
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd_dual_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)lstm_bwd_dual_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
-  const uint8_t* z = (const uint8_t*)Z;
-  const bf16_t *c = (const bf16_t*)C, *dh = (const bf16_t*)dH;
-  bf16_t* dz = (bf16_t*)dZ;
-  int left = ntiles & ~1;
-  while (left > 0) {
-    const int n = left < cap ? left : cap;
-    hipLaunchKernelGGL(cl_reset_kernel, dim3(BP_BYTES / (256 * 16)), dim3(256), 0, st,
-                       (uint4*)((unsigned char*)scratch + BP_OFF_CNT));
-    if (int rc = cluster_fault_hook(scratch, st)) return rc;
-    const dim3 grid((n / 2 + 7) / 8 * 16);
-    if (sigm)
-      hipLaunchKernelGGL((lstm_bwd_dual_kernel<true>), grid, dim3(256), smem, st, z, (const bf16_t*)UTpack, c, dh, dz, dbias,
-                         steps, dz_cts, ldz, (int*)scratch, n);
-    else
-      hipLaunchKernelGGL((lstm_bwd_dual_kernel<false>), grid, dim3(256), smem, st, z, (const bf16_t*)UTpack, c, dh, dz, dbias,
-                         steps, dz_cts, ldz, (int*)scratch, n);
-    if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
-    const int64_t rows = (int64_t)n * steps * 32;
-    z += rows * 4 * H;
-    c += rows * H;
-    dh += rows * H;
-    dz += rows * ldz;
-    left -= n;
-  }
-  if (ntiles & 1)      // the odd last tile: per-tile kernel on the same buffers (dz_cts counts from the buffer's start)
-    return launch_bwd_x<bf16_t, 256, 0>(1, steps, z, UTpack, c, dh, dz, dz_cts_in, dbias, sigm, nullptr, 0, nullptr, 0, st);
-  return 0;
-}
 
 }  // namespace
 
 // fp32 H = 256 inference sweep of at most 8 tiles on clusters of 8 workgroups (lstm_fwd_cluster_f32_kernel).  Returns
 // 1017 when the device cannot hold the grid (the caller then uses the per-tile kernel).
 int dj_launch_lstm_fwd_cluster_f32(int ntiles, int steps, const void* Zx, const void* Upack, void* Hout, int sigm,
-                                   void* scratch, hipStream_t st) {
+                                   void* scratch, uint32_t kf, hipStream_t st) {
   using R = RecCfg<float, 256>;
   if (ntiles < 1 || ntiles > 8 || !scratch || ((uintptr_t)scratch & 127)) return 1016;
   if (cluster_cus() < 64) return 1017;
@@ -2674,7 +2109,7 @@ int dj_launch_lstm_fwd_cluster_f32(int ntiles, int steps, const void* Zx, const 
     attr_done = true;
   }
   if (int rc = cluster_reset(scratch, st)) return rc;
-  if (int rc = cluster_fault_hook(scratch, st)) return rc;
+  if (int rc = cluster_fault_hook(scratch, kf, st)) return rc;
   if (sigm)
     hipLaunchKernelGGL((lstm_fwd_cluster_f32_kernel<true>), dim3(64), dim3(512), smem, st, (const float*)Zx,
                        (const float*)Upack, (float*)Hout, steps, (int*)scratch, ntiles);
@@ -2690,12 +2125,12 @@ int dj_launch_lstm_fwd_cluster_f32(int ntiles, int steps, const void* Zx, const 
 int dj_launch_lstm_fwd_cluster_pair(int ntiles, int steps, const void* X0, int DP0, const void* W0pack, const float* b0,
                                     const void* U0pack, void* X1, const void* W1pack, const float* b1, const void* U1pack,
                                     void* H1, const float* sp1, int sp_D, int n_seq, int n_b, int sigm, void* scratch,
-                                    hipStream_t st) {
+                                    uint32_t kf, hipStream_t st) {
   ClPairArgs a;
   a.X0 = (const bf16_t*)X0; a.DP0 = DP0; a.W0 = (const bf16_t*)W0pack; a.b0 = b0; a.U0 = (const bf16_t*)U0pack;
   a.X1 = (bf16_t*)X1; a.W1 = (const bf16_t*)W1pack; a.b1 = b1; a.U1 = (const bf16_t*)U1pack; a.H1 = (bf16_t*)H1;
   a.sp1 = sp1; a.sp_D = sp_D; a.n_seq = n_seq; a.n_b = n_b;
-  return launch_fwd_cluster_pair(ntiles, steps, a, sigm, scratch, st);
+  return launch_fwd_cluster_pair(ntiles, steps, a, sigm, scratch, kf, st);
 }
 
 #define DJ_DISPATCH_TH(FN, ...)                                     \
@@ -2715,18 +2150,11 @@ int dj_launch_lstm_fwd(int dtype, int H, int ntiles, int steps, const void* Zx, 
 }
 // bytes per row of the gate stash of a layer with H units (fragment-tiled; GateEnc above)
 int64_t dj_lstm_stash_row_bytes(int dtype, int H) { return (int64_t)4 * H * (dtype == DJ_F32 ? 4 : 1); }
-int64_t dj_lstm_cluster_scratch_bytes_impl() { return (int64_t)CL_BYTES_ALL; }
+int64_t dj_lstm_cluster_scratch_bytes_impl() { return (int64_t)CL_BYTES; }
 int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* UTpack, const void* C,
                        const void* dH, void* dZ, int64_t dz_cts, float* dbias, int sigm, const void* WTpack, int D, void* dX,
-                       int DP, void* cluster_scratch, int bwd_mode, hipStream_t st) {
+                       int DP, hipStream_t st) {
   if (ntiles <= 0 || steps <= 0) return 0;
-  // bf16 H = 256 (time axis): two workgroups per tile (lstm_bwd_pair_kernel), or two tiles per workgroup pair with the
-  // product of one folded into the gate math of the other (lstm_bwd_dual_kernel), where the device holds the grid
-  if (cluster_scratch && dtype == DJ_BF16 && H == 256 && !WTpack) {
-    const int rc = bwd_mode == 2 ? launch_bwd_dual(ntiles, steps, Z, UTpack, C, dH, dZ, dz_cts, dbias, sigm, cluster_scratch, st)
-                                 : launch_bwd_pair(ntiles, steps, Z, UTpack, C, dH, dZ, dz_cts, dbias, sigm, cluster_scratch, st);
-    if (rc != 1017) return rc;
-  }
   const int NQ = (D + 31) / 32;
   if (WTpack && (!dX || D < 1 || DP < 8 || (DP % 8) || NQ * 32 < DP)) return 1013;
   DJ_DISPATCH_TH(launch_bwd, ntiles, steps, Z, UTpack, C, dH, dZ, dz_cts, dbias, sigm, WTpack, NQ, dX, DP, st)
@@ -2758,18 +2186,33 @@ int dj_launch_lstm_pack_w(int dtype, int H, const float* W, int D, int NKX, void
   DJ_DISPATCH_TH(launch_pack_w, W, D, NKX, out, st)
 }
 void* dj_lstm_cluster_fault_words(void* scratch) { return (char*)scratch + CL_OFF_FAULT; }
-int dj_lstm_cluster_faults_impl(void* scratch) {
+namespace {
+// census taken: counts and the description of the first expired wait start again; the stall census (words 4, 5) stays
+__global__ void cl_fault_clear_kernel(int* f) {
+  const int i = threadIdx.x;
+  if (i == CLF_EXPIRED || i == CLF_MISPLACED || (i >= CLF_DIAG && i < CLF_WORDS)) f[i] = 0;
+}
+}  // namespace
+// the whole fault line (CLF_WORDS ints, layout at "bounded exchange waits") as it stands once `st` has drained
+int dj_lstm_cluster_fault_line(void* scratch, int32_t* words_host, hipStream_t st) {
+  if (!scratch || !words_host) return 1016;
+  if (hipError_t e = hipMemcpyAsync(words_host, (char*)scratch + CL_OFF_FAULT, CLF_WORDS * sizeof(int32_t),
+                                    hipMemcpyDeviceToHost, st); e != hipSuccess) return (int)e;
+  return (int)hipStreamSynchronize(st);
+}
+int dj_lstm_cluster_faults_impl(void* scratch, hipStream_t st) {
   if (!scratch) return 0;
-  int n[2] = {0, 0};
-  const int zero[2] = {0, 0};
-  char* f = (char*)scratch + CL_OFF_FAULT;
-  if (hipMemcpy(n, f, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  if ((n[0] || n[1]) && hipMemcpy(f, zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) return -1;
-  return n[0] + n[1];
+  int32_t w[CLF_WORDS];
+  if (dj_lstm_cluster_fault_line(scratch, w, st)) return -1;
+  if (w[CLF_EXPIRED] || w[CLF_MISPLACED] || w[CLF_DIAG]) {
+    hipLaunchKernelGGL(cl_fault_clear_kernel, dim3(1), dim3(64), 0, st, (int*)((char*)scratch + CL_OFF_FAULT));
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+  }
+  return w[CLF_EXPIRED] + w[CLF_MISPLACED];
 }
 int dj_launch_lstm_fwd_fused(int dtype, int H, int ntiles, int steps, const void* X, int DP, int NKX,
                              const void* Wpack, const float* bias, void* Zst, const void* Upack, void* Hout,
-                             void* Cout, int sigm, void* cluster_scratch, hipStream_t st) {
+                             void* Cout, int sigm, void* cluster_scratch, uint32_t kf, hipStream_t st) {
   if (ntiles <= 0 || steps <= 0) return 0;
   // weight-stationary cluster kernel (bf16, H = 256), in launches whose whole grid is co-resident (at most one
   // workgroup per compute unit, groups of 64 blocks = 8 clusters of 8 members); any tile count: a sweep of few tiles
@@ -2779,7 +2222,7 @@ int dj_launch_lstm_fwd_fused(int dtype, int H, int ntiles, int steps, const void
     if (cap >= 64) {
       while (ntiles > 0) {
         const int n = ntiles < cap ? ntiles : cap;
-        const int rc = launch_fwd_cluster(n, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, sigm, cluster_scratch, st);
+        const int rc = launch_fwd_cluster(n, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, sigm, cluster_scratch, kf, st);
         if (rc) return rc;
         const int64_t rows = (int64_t)n * steps * 32;      // all five buffers are tile-major
         X = (const bf16_t*)X + rows * DP;

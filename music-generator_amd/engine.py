@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -122,6 +123,48 @@ def _stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Every observation of cluster faults by the host, on any path (census after predict / generation, the [loss, faults]
+# read-back of a training step): process-wide, empty in a healthy run.  The GPU tests fail on any entry that a test did
+# not inject (tests/conftest.py), so a recurrence on the driver's box cannot hide behind a fallback.
+FAULT_LOG: list = []
+_LIVE = weakref.WeakSet()          # engines alive in this process (census of their stall words at the end of a test)
+
+_WAIT_KINDS = {1: "bf16 sweep", 2: "bf16 cooperative body", 3: "fp32 inference sweep", 5: "pair BPTT (tools)",
+               6: "two-tile BPTT (tools)"}
+
+
+def decode_fault_report(words):
+    """dj_workspace_cluster_fault_report words -> dict (include/deepj_hip.h DJ_FAULT_REPORT_WORDS)."""
+    w = [int(v) for v in words]
+    rep = {"expired": w[0], "misplaced": w[1], "hook": w[2], "stalled_waits": w[4], "max_poll_gap_cycles": w[5] << 10,
+           "first_expired": None}
+    if w[8]:
+        who = w[9] & 0xFFFFFFFF
+        rep["first_expired"] = {
+            "kernel": _WAIT_KINDS.get((who >> 24) & 15, "kind %d" % ((who >> 24) & 15)),
+            "producer_counter": bool(who & (1 << 28)), "cluster": (who >> 12) & 0xFFF, "member": (who >> 8) & 15,
+            "wave": who & 255, "step": w[10], "counter_seen": w[11], "target": w[12], "polls": w[13],
+            "elapsed_cycles": (w[14] & 0xFFFFFFFF) | ((w[15] & 0xFFFFFFFF) << 32),
+            "max_poll_gap_cycles": w[16] & 0xFFFFFFFF, "xcc": w[17] - 1}
+    return rep
+
+
+def describe_fault_report(rep):
+    txt = "%d expired waits (a member of a cluster never arrived: device shared with other kernels), %d workgroups of " \
+          "clusters that were not dealt round-robin over the XCDs" % (rep["expired"], rep["misplaced"])
+    f = rep.get("first_expired")
+    if f:
+        txt += ("; first expired wait: %s, cluster %d member %d wave %d (XCC %d) at step %d%s: counter %d of %d after "
+                "%d polls / %d shader cycles, longest gap between two polls %d cycles"
+                % (f["kernel"], f["cluster"], f["member"], f["wave"], f["xcc"], f["step"],
+                   " on the producing layer's counter" if f["producer_counter"] else "", f["counter_seen"], f["target"],
+                   f["polls"], f["elapsed_cycles"], f["max_poll_gap_cycles"]))
+    if rep.get("stalled_waits"):
+        txt += "; stall census of this workspace: %d waits with polls > 2^20 cycles apart, longest gap %d cycles" % (
+            rep["stalled_waits"], rep["max_poll_gap_cycles"])
+    return txt
+
+
 class Engine:
     """One (config, batch, time_steps) instance = one workspace in HBM."""
 
@@ -147,8 +190,11 @@ class Engine:
             self.ws_ptr = C.c_void_p(self.ws.data_ptr() + pad)
             _lib.check(self.lib.dj_workspace_init(C.byref(self.c), self.ws_ptr, nbytes, _stream_ptr()),
                        "dj_workspace_init")
-        # [mean loss, cluster faults of the call]: one device-to-host copy serves both (dj_workspace_faults_async)
-        self.loss = torch.zeros(2, dtype=torch.float32, device=self.device)
+        # [mean loss, cluster faults of the call, of which expired waits, misplaced]: one device-to-host copy serves
+        # all of it (dj_workspace_faults_async)
+        self.loss = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.last_fault = None                           # the newest FAULT_LOG entry of this engine
+        _LIVE.add(self)
 
     def set_kernel_flags(self, flags: int):
         """Per-engine kernel selection (DJ_KF_*); e.g. KF_NO_CLUSTER after a cluster fault.  Affects later calls of
@@ -157,40 +203,55 @@ class Engine:
             self.c.kernel_flags = int(flags)
             self.flags_epoch += 1
 
-    def cluster_faults(self) -> int:
-        """Events recorded by the weight-stationary cluster forward kernel in THIS engine's workspace since the last
-        call (expired waits, clusters spread over several XCDs; include/deepj_hip.h dj_lstm_cluster_faults).  Zero
-        in a healthy run; non-zero means the affected tiles -- and the loss -- are NaN.  Synchronises the device."""
+    def cluster_fault_report(self):
+        """The fault line of this engine's workspace, decoded (decode_fault_report): counts, stall census, description of
+        the first expired wait.  Resets nothing; drains the current stream."""
+        words = (C.c_int32 * _lib.FAULT_REPORT_WORDS)()
         with torch.cuda.device(self.device):
-            n = int(self.lib.dj_workspace_cluster_faults(C.byref(self.c), self.ws_ptr, self.ws_bytes))
+            _lib.check(self.lib.dj_workspace_cluster_fault_report(C.byref(self.c), self.ws_ptr, self.ws_bytes, words,
+                                                                  _stream_ptr()), "dj_workspace_cluster_fault_report")
+        return decode_fault_report(words)
+
+    def _log_faults(self, what, rep, n):
+        entry = dict(rep, what=what, events=int(n), kernel_flags=int(self.c.kernel_flags), batch=self.batch,
+                     time_steps=self.time_steps, dtype=self.cfg.dtype)
+        self.last_fault = entry
+        FAULT_LOG.append(entry)
+
+    def cluster_faults(self, what="census") -> int:
+        """Events recorded by the weight-stationary cluster kernels in THIS engine's workspace since the last
+        call (expired waits, clusters spread over several XCDs; include/deepj_hip.h dj_lstm_cluster_faults).  Zero
+        in a healthy run; non-zero means the affected tiles -- and the loss -- are NaN, and the observation is
+        appended to FAULT_LOG with the description of the first expired wait.  Drains the current stream."""
+        rep = self.cluster_fault_report()
+        with torch.cuda.device(self.device):
+            n = int(self.lib.dj_workspace_cluster_faults(C.byref(self.c), self.ws_ptr, self.ws_bytes, _stream_ptr()))
         if n < 0:
             raise _lib.DeepJError("dj_workspace_cluster_faults failed")
-        return n + self.take_async_faults()
+        if n:
+            self._log_faults(what, rep, n)
+        return n + self.take_async_faults(what=what)
 
-    def take_async_faults(self, value=None) -> int:
-        """Faults that train_fwd_bwd calls have added to loss[1] (dj_workspace_faults_async) since the last take;
+    def take_async_faults(self, value=None, what="training step") -> int:
+        """Faults that train_fwd_bwd calls have added to loss[1:4] (dj_workspace_faults_async) since the last take;
         `value`: the number if the caller has already read loss[1] with the loss."""
         m = int(self.loss[1].item()) if value is None else int(value)
         if m:
+            host = self.loss.cpu().numpy()
+            rep = self.cluster_fault_report()            # the async census leaves the first wait's description in place
+            rep["expired"], rep["misplaced"] = int(host[2]), int(host[3])
             self.loss[1:].zero_()
+            with torch.cuda.device(self.device):         # ... until the host takes it here
+                self.lib.dj_workspace_cluster_faults(C.byref(self.c), self.ws_ptr, self.ws_bytes, _stream_ptr())
+            self._log_faults(what, rep, m)
         return m
 
-    def cluster_fault_words(self):
-        """(expired waits, clusters spread over several XCDs) recorded in this engine's workspace, without resetting
-        them (dj_workspace_cluster_fault_words); synchronises."""
-        words = (C.c_int32 * 2)()
-        with torch.cuda.device(self.device):
-            rc = self.lib.dj_workspace_cluster_fault_words(C.byref(self.c), self.ws_ptr, self.ws_bytes, words)
-        return (int(words[0]), int(words[1])) if rc == 0 else (-1, -1)
-
     def raise_on_cluster_faults(self, what):
-        words = self.cluster_fault_words()
-        n = self.cluster_faults()
+        n = self.cluster_faults(what)
         if n:
             raise _lib.DeepJError(
-                "%s: %d cluster faults in the recurrent forward kernel (%d expired waits: device shared with other "
-                "kernels; %d clusters whose workgroups were not dealt round-robin over the XCDs); the results are NaN.  "
-                "Set DEEPJ_CLUSTER=0 to use the per-tile kernel." % (what, n, words[0], words[1]))
+                "%s: %d cluster faults in the recurrent forward kernel (%s); the results are NaN.  "
+                "Set DEEPJ_CLUSTER=0 to use the per-tile kernel." % (what, n, describe_fault_report(self.last_fault)))
 
     # -- shapes
     def _shapes(self):

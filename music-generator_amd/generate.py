@@ -101,7 +101,7 @@ GEN_CHUNK = 4 * NOTES_PER_BAR
 # "Sampling parity"); otherwise the rolls are certified up to `first_near_tie_step`.
 # `max_temperature` / `silent_steps`: the heating schedule of end_time() as the run saw it (host MusicGeneration state).
 last_run_stats = {"draws": 0, "near_ties": 0, "first_near_tie_step": -1, "max_temperature": 1.0, "silent_steps": 0}
-repeated_steps = 0      # step-wise steps computed twice because of a cluster fault (process total; 0 in a healthy run)
+repeated_steps = 0      # step-wise steps computed twice because of a cluster fault (DEEPJ_GENERATE_RETRY=1 only)
 
 
 def _note_schedule(pieces):
@@ -144,16 +144,20 @@ def _fused_step(shared, engine, pieces):
     nxt, used = engine.generate_step(*args)
     nxt = be.numpy(nxt)
     used = used.cpu().numpy()
-    if hasattr(engine, "cluster_faults") and engine.cluster_faults():
-        # NaN-poisoned rows would be sampled as silence: never used.  The step has no device-side state (windows,
-        # temperatures and uniforms are its inputs), so it is simply computed again, once; a second fault raises.
-        print("[deepj] generation: cluster fault in a time step (an exchange wait expired); repeating the step",
-              flush=True)
-        global repeated_steps
-        repeated_steps += 1
-        nxt, used = engine.generate_step(*args)
-        nxt = be.numpy(nxt)
-        used = used.cpu().numpy()
+    if hasattr(engine, "raise_on_cluster_faults"):
+        # NaN-poisoned rows would be sampled as silence: never used.  A cluster fault RAISES, with the description of
+        # the first expired wait (engine.describe_fault_report).  Until round 4 the step was silently computed again
+        # once; that hid a fault instead of explaining it and is now opt-in hang protection (DEEPJ_GENERATE_RETRY=1:
+        # the step has no device-side state -- windows, temperatures and uniforms are its inputs -- so it can be
+        # repeated; every repeat is printed, counted in `repeated_steps` and recorded in engine.FAULT_LOG).
+        if os.environ.get("DEEPJ_GENERATE_RETRY") == "1" and engine.cluster_faults("generation (step repeated)"):
+            print("[deepj] generation: cluster fault in a time step; repeating the step (DEEPJ_GENERATE_RETRY=1)",
+                  flush=True)
+            global repeated_steps
+            repeated_steps += 1
+            nxt, used = engine.generate_step(*args)
+            nxt = be.numpy(nxt)
+            used = used.cpu().numpy()
         engine.raise_on_cluster_faults("generation")
     np.random.random_sample(int(used[0]))
     last_run_stats["draws"] += int(used[0])

@@ -421,9 +421,9 @@ class TrainableModel(Model):
                     mb = [x_[i * k:(i + 1) * k].contiguous() for x_ in t]
                     li = eng.train_fwd_bwd(s.params, s.grads, *mb, seed=seed, accumulate=i > 0, full_batch=full,
                                            batch_offset=off + i * k, bins_full=bins)
-                    loss = li.clone() if loss is None else loss + li     # [sum of means, faults so far (cumulative)]
+                    loss = li.clone() if loss is None else loss + li     # [sum of means, faults so far (cumulative), ..]
                     if loss.numel() > 1:
-                        loss[1] = li[1]
+                        loss[1:] = li[1:]
                 loss[:1] /= parts                                # equal parts: mean of the micro-batch means
                 s.grads.mul_(1.0 / parts)
             return eng, loss
@@ -460,10 +460,15 @@ class TrainableModel(Model):
             from ._lib import KF_NO_CLUSTER
             if s.kernel_flags & KF_NO_CLUSTER:
                 raise RuntimeError("cluster faults reported with the cluster kernel disabled")
-            print("[deepj] rank %d: %d cluster faults in the recurrent forward kernel: falling back to the per-tile "
-                  "kernel for this model (DJ_KF_NO_CLUSTER) and repeating the step" % (rank, int(faults)), flush=True)
             if hasattr(eng, "take_async_faults"):
-                eng.take_async_faults(local_faults)                            # reset the device-side census
+                eng.take_async_faults(local_faults)       # reset the device-side census; the event goes to engine.FAULT_LOG
+            what = ""
+            if getattr(eng, "last_fault", None) and hasattr(eng, "cluster_fault_report"):
+                from .engine import describe_fault_report
+                what = " (this rank: %s)" % describe_fault_report(eng.last_fault)
+            print("[deepj] rank %d: %d cluster faults in the recurrent forward kernel%s: falling back to the per-tile "
+                  "kernel for this model (DJ_KF_NO_CLUSTER) and repeating the step" % (rank, int(faults), what),
+                  flush=True)
             s.add_kernel_flags(KF_NO_CLUSTER)
             return self._train_step(x, target, on_device, weight, total_weight, shard)
         if loss_value != loss_value:

@@ -11,6 +11,7 @@ for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "fault_injection: the test injects cluster faults on purpose (census not asserted)")
     # the CPU oracle is torch-CPU: give it the cores this process may really use (affinity mask capped by the cgroup
     # quota).  os.cpu_count() on a GPU box is the whole host: 8x oversubscription made oracle steps 10x slower.
     try:
@@ -61,3 +62,78 @@ def djenv(monkeypatch):
     yield env
     monkeypatch.undo()
     env._reload()
+
+
+# ---- cluster-exchange census.  The weight-stationary cluster kernels count expired waits
+# and misplaced clusters and every host path that sees a count records it in engine.FAULT_LOG; training falls back to
+# the per-tile kernels and goes on, so a green test would not by itself say the waits held.  Every GPU test that does
+# not inject faults on purpose (marker `fault_injection`) therefore FAILS if, while it ran, the host observed a fault,
+# step-wise generation repeated a step, or a live engine holds fault counts nobody read.  The stall census (the longest
+# gap between two polls of any exchange wait: a wave that was off the device) is collected from every engine and
+# printed at the end of the session -- evidence about the box even when nothing expired.
+_CENSUS = {"engines": 0, "stalled_waits": 0, "max_poll_gap_cycles": 0, "faults_in_injection_tests": 0, "worst": None}
+
+
+def _census_live_engines():
+    from music_generator_amd import engine as E
+    unread = []
+    for eng in list(E._LIVE):
+        try:
+            rep = eng.cluster_fault_report()
+        except Exception:
+            continue
+        _CENSUS["engines"] += 1
+        _CENSUS["stalled_waits"] = max(_CENSUS["stalled_waits"], rep["stalled_waits"])
+        if rep["max_poll_gap_cycles"] > _CENSUS["max_poll_gap_cycles"]:
+            _CENSUS["max_poll_gap_cycles"] = rep["max_poll_gap_cycles"]
+        if rep["expired"] or rep["misplaced"]:
+            unread.append(E.describe_fault_report(rep))
+    return unread
+
+
+@pytest.fixture(autouse=True)
+def cluster_fault_census(request):
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import torch
+    if not torch.cuda.is_available():
+        yield
+        return
+    from music_generator_amd import engine as E
+    from music_generator_amd import generate as Gn
+    n0, r0 = len(E.FAULT_LOG), Gn.repeated_steps
+    yield
+    unread = _census_live_engines()
+    new = E.FAULT_LOG[n0:]
+    if request.node.get_closest_marker("fault_injection") is not None:
+        _CENSUS["faults_in_injection_tests"] += len(new)
+        for eng in list(E._LIVE):                      # leave no injected count behind for the next test
+            try:
+                eng.cluster_faults("after an injection test")
+            except Exception:
+                pass
+        del E.FAULT_LOG[n0:]
+        return
+    if new:
+        _CENSUS["worst"] = new[0]
+    assert not new, "cluster faults observed during the test: " + "; ".join(
+        "%s: %s" % (e["what"], E.describe_fault_report(e)) for e in new)
+    assert Gn.repeated_steps == r0, "step-wise generation repeated %d steps" % (Gn.repeated_steps - r0)
+    assert not unread, "fault counts left unread in a live engine: " + "; ".join(unread)
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not _CENSUS["engines"]:
+        return
+    line = ("cluster exchange census: %d engine readings, waits with polls > 2^20 cycles apart: %d, longest gap between "
+            "two polls of a wait: %d shader cycles (~%.0f us at 2.1 GHz), faults in injection tests: %d, faults elsewhere: %s"
+            % (_CENSUS["engines"], _CENSUS["stalled_waits"], _CENSUS["max_poll_gap_cycles"],
+               _CENSUS["max_poll_gap_cycles"] / 2100.0, _CENSUS["faults_in_injection_tests"],
+               "NONE" if _CENSUS["worst"] is None else repr(_CENSUS["worst"])))
+    terminalreporter.write_line(line)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        import json
+        with open(os.path.join(out, "cluster_census.json"), "w") as f:
+            json.dump(_CENSUS, f, default=str)

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), "libdeepj_hip.so does not export " + n
-    assert lib.dj_abi_version() == 3
+    assert lib.dj_abi_version() == 4
     bound = {n for n in _lib._SIGS if n not in _lib.OPTIONAL}
     assert bound <= set(names), bound - set(names)
 

@@ -3,7 +3,8 @@ world size 1 on the one GPU of the test box, in a FRESH child process, driving (
 (make_step with its all-reduce forced) and (b) the collective branch of Model._train_step (DEEPJ_DIST_WORLD1=1) for 3
 steps each on the production kernel selection (bf16, B16 x T16 x N128: 64 time-axis tiles -> the weight-stationary
 cluster kernel): parameters and losses equal the non-distributed path, exactly one collective per step, no cluster
-fault with RCCL's kernels on the same device.  This is the N = 1 end of the path the driver launches at N = 2, 4, 8
+fault with RCCL's kernels on the same device; (c) the same with DEEPJ_DDP_EXACT=1 (dist.all_gather of the pitch_bins
+parts + dj_train_fwd_bwd_mb); (d) bench.py's `scaled` record (BASELINE configs[4]) with its 187.6 MB all-reduce forced.  This is the N = 1 end of the path the driver launches at N = 2, 4, 8
 (no multi-GPU node is available to the builder: the multi-rank arithmetic is covered by the 2-rank gloo tests)."""
 import json
 import os
@@ -34,6 +35,12 @@ def counted(*a, **k):
     calls["n"] += 1
     return _orig(*a, **k)
 dist.all_reduce = counted
+gathers = {{"n": 0}}
+_orig_gather = dist.all_gather
+def counted_gather(*a, **k):
+    gathers["n"] += 1
+    return _orig_gather(*a, **k)
+dist.all_gather = counted_gather
 
 B, T, N, STEPS = 16, 16, 128, 3
 cfg = DeepJConfig(num_notes=N, time_steps=T, dtype="bf16")
@@ -60,11 +67,15 @@ out["bench_param_maxdiff"] = float(np.abs(p1 - p0).max())
 out["bench_param_moved"] = float(np.abs(p1 - pinit).max())
 out["bench_update_rel_l2"] = float(np.linalg.norm(p1 - p0) / np.linalg.norm(p1 - pinit))
 
-def run_model(dist_branch):
+def run_model(dist_branch, exact=False):
     if dist_branch:
         os.environ["DEEPJ_DIST_WORLD1"] = "1"
     else:
         os.environ.pop("DEEPJ_DIST_WORLD1", None)
+    if exact:
+        os.environ["DEEPJ_DDP_EXACT"] = "1"
+    else:
+        os.environ.pop("DEEPJ_DDP_EXACT", None)
     m = build_models(time_steps=T, config=cfg, seed=5)[0]
     x = [b.cpu().numpy() for b in batch]
     losses = [m.train_on_batch([x[0], x[1], x[2], x[3]], [x[4]]) for _ in range(STEPS)]
@@ -81,6 +92,39 @@ out["model_faults"] = [mf1, mf0, k1, k0]
 out["model_loss"] = [ml1, ml0]
 out["model_param_maxdiff"] = float(np.abs(w1 - w0).max())
 out["model_update_rel_l2"] = float(np.linalg.norm(w1 - w0) / np.linalg.norm(w1 - winit))
+
+# exact mode (DEEPJ_DDP_EXACT=1) over RCCL: dist.all_gather of the pitch_bins parts + dj_train_fwd_bwd_mb, then the one
+# all-reduce -- at world size 1 the global batch IS the shard, so the result must be the non-distributed step's
+calls["n"] = 0; gathers["n"] = 0
+we, mle, mfe, ke = run_model(True, exact=True)
+out["exact_collectives"] = [calls["n"], gathers["n"]]
+out["exact_faults"] = [mfe, ke]
+out["exact_loss"] = [mle, ml0]
+out["exact_param_maxdiff"] = float(np.abs(we - w0).max())
+out["exact_update_rel_l2"] = float(np.linalg.norm(we - w0) / np.linalg.norm(we - winit))
+os.environ.pop("DEEPJ_DDP_EXACT", None); os.environ.pop("DEEPJ_DIST_WORLD1", None)
+
+# BASELINE configs[4] (bench.py --config scaled: 3 x 1024 per axis, B128 x T256 x N128 as two exact micro-batches through
+# the 218 GiB workspace) with its 187.6 MB gradient all-reduce forced through RCCL: 2 timed steps + the profiled one
+free, _ = torch.cuda.mem_get_info(dev)
+if free > 235 * 2 ** 30:
+    calls["n"] = 0
+    r1 = bench.scaled_record("bf16", 2, 2, 0, None, dev, 0, 1, dist, force_collective=True, return_params=True)
+    out["scaled_collectives"] = calls["n"]
+    r0 = bench.scaled_record("bf16", 2, 2, 0, None, dev, 0, 1, dist, force_collective=False, return_params=True)
+    ps1, ps0 = r1.pop("params"), r0.pop("params")
+    from music_generator_amd.engine import DeepJConfig as _DC
+    pinit_s = init_params_numpy(_DC(num_notes=128, time_steps=256, dtype="bf16", time_axis_units=1024, note_axis_units=1024,
+                                    time_axis_layers=3, note_axis_layers=3), seed=1234)
+    out["scaled_faults"] = [r1["cluster_faults"], r0["cluster_faults"]]
+    out["scaled_loss"] = [r1["final_loss"], r0["final_loss"]]
+    out["scaled_ms"] = [r1["ms_per_step"], r0["ms_per_step"]]
+    out["scaled_param_maxdiff"] = float(np.abs(ps1 - ps0).max())
+    out["scaled_update_rel_l2"] = float(np.linalg.norm(ps1 - ps0) / np.linalg.norm(ps1 - pinit_s))
+else:
+    out["scaled_skipped"] = "needs a 218 GiB workspace; %.0f GiB free" % (free / 2 ** 30)
+from music_generator_amd import engine as _E
+out["fault_log"] = [[e["what"], e["expired"], e["misplaced"]] for e in _E.FAULT_LOG]
 dist.barrier()
 dist.destroy_process_group()
 print("RESULT " + json.dumps(out), flush=True)
@@ -97,7 +141,7 @@ def test_rccl_world1_drives_bench_step_and_model_step(gpu_device, tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DEEPJ_DIST_WORLD1"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
     o = json.loads(line[len("RESULT "):])
@@ -116,6 +160,16 @@ def test_rccl_world1_drives_bench_step_and_model_step(gpu_device, tmp_path):
     assert o["model_faults"] == [0, 0, 0, 0]
     assert o["model_param_maxdiff"] < 3 * 2e-3 and o["model_update_rel_l2"] < 5e-3, o
     assert all(abs(a - b) < 1e-4 * abs(b) for a, b in zip(*o["model_loss"])), o["model_loss"]
+    # exact mode over RCCL: one all_gather + one all_reduce per step, the non-distributed step's numbers, no fault
+    assert o["exact_collectives"] == [steps, steps] and o["exact_faults"] == [0, 0]
+    assert o["exact_param_maxdiff"] < 3 * 2e-3 and o["exact_update_rel_l2"] < 5e-3, o
+    assert all(abs(a - b) < 1e-4 * abs(b) for a, b in zip(*o["exact_loss"])), o["exact_loss"]
+    # the scaled config's step with its 187.6 MB all-reduce through RCCL (2 timed + 1 profiled step)
+    if "scaled_skipped" not in o:
+        assert o["scaled_collectives"] == 3 and o["scaled_faults"] == [0, 0]
+        assert abs(o["scaled_loss"][0] - o["scaled_loss"][1]) < 1e-3 * abs(o["scaled_loss"][1]), o["scaled_loss"]
+        assert o["scaled_param_maxdiff"] < 3 * 2e-3 and o["scaled_update_rel_l2"] < 2e-2, o
+    assert o["fault_log"] == []
 
 
 WORKER2 = r'''
@@ -134,7 +188,7 @@ try:
 except Exception as e:
     print("RESULT " + json.dumps({{"skip": "gloo cannot all-reduce device tensors here: %s" % str(e)[:120]}}), flush=True)
     sys.exit(0)
-B, T, N = 128, 16, 128                                  # global batch 128 -> 64 per rank: 256 time-axis tiles per rank, a full-chip cluster grid each
+B, T, N = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 cfg = DeepJConfig(num_notes=N, time_steps=T, dtype="bf16")
 a = synthetic_batch(N, T, B, seed=0)
 x, y = [a[0], a[1], a[2], a[3]], [a[4]]
@@ -142,30 +196,27 @@ m = build_models(time_steps=T, config=cfg, seed=5)[0]
 np.random.seed(0)
 hist = m.fit(x, y, epochs=3, batch_size=B, verbose=0, shuffle=False)
 w = np.concatenate([v.ravel() for v in m.get_weights()])
+from music_generator_amd import engine as E
 print("RESULT " + json.dumps({{"rank": rank, "loss": hist.history["loss"], "digest": float(np.dot(w, np.cos(np.arange(w.size) * 0.37))),
-                              "wnorm": float(np.linalg.norm(w)), "fell_back": bool(m._s.kernel_flags & KF_NO_CLUSTER)}}), flush=True)
+                              "wnorm": float(np.linalg.norm(w)), "fell_back": bool(m._s.kernel_flags & KF_NO_CLUSTER),
+                              "fault_log": [[e["what"], e["expired"], e["misplaced"]] for e in E.FAULT_LOG]}}), flush=True)
 dist.barrier()
 dist.destroy_process_group()
 '''
 
 
-def test_two_ranks_share_one_gpu(gpu_device, tmp_path):
-    """Data parallel with TWO ranks on the ONE GPU of the test box (gloo carries the collective; RCCL refuses two ranks on
-    one device): both processes run the real bf16 training step -- cluster kernels included -- at the same time on the
-    same device, which is exactly the situation the cluster kernels' run-time checks exist for (another process's
-    kernels keep members from being co-resident).  Whatever happens -- clean steps, or expired waits counted, summed over
-    the ranks in the step's one all-reduce and answered by both ranks falling back to the per-tile kernel together --
-    the run must end with a finite, falling loss and IDENTICAL weights on both ranks."""
+def _two_ranks(tmp_path, shape, env_common=None, env_rank=None):
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     script = tmp_path / "worker2.py"
     script.write_text(WORKER2.format(root=ROOT, port=port))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_common or {}))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DEEPJ_DIST_WORLD1"):
         env.pop(k, None)
-    procs = [subprocess.Popen([sys.executable, str(script), str(r)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)] + [str(v) for v in shape],
+                              env=dict(env, **((env_rank or {}).get(r, {}))), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                               text=True) for r in range(2)]
     outs = [p.communicate(timeout=600) for p in procs]
     for p, (so, se) in zip(procs, outs):
@@ -173,11 +224,35 @@ def test_two_ranks_share_one_gpu(gpu_device, tmp_path):
     res = [json.loads([ln for ln in so.splitlines() if ln.startswith("RESULT ")][-1][7:]) for so, _ in outs]
     if "skip" in res[0]:
         pytest.skip(res[0]["skip"])
-    print("two ranks on one GPU:", res)
-    a, b = sorted(res, key=lambda r: r["rank"])
+    return sorted(res, key=lambda r: r["rank"])
+
+
+def test_two_ranks_share_one_gpu(gpu_device, tmp_path):
+    """Data parallel with TWO ranks on the ONE GPU of the test box (gloo carries the collective; RCCL refuses two ranks on
+    one device): both processes run the real bf16 training step at the BASELINE per-rank shape (64 sequences each) at the
+    same time on the same device.  Two full-chip grids of spin-waiting cluster workgroups from two processes cannot both
+    be co-resident -- that is what the bounded waits exist for, and whether one expires would depend on the dispatch
+    order of the day -- so this rehearsal runs the per-tile kernels (DEEPJ_CLUSTER=0) and is deterministic: replicas
+    bit-identical, loss falling, nothing fell back, nothing in the fault log.  The joint fallback itself is the next test."""
+    a, b = _two_ranks(tmp_path, (128, 16, 128), env_common={"DEEPJ_CLUSTER": "0"})
+    print("two ranks on one GPU:", a, b)
     assert a["digest"] == b["digest"] and a["wnorm"] == b["wnorm"]          # replicas stay bit-identical
     assert a["loss"] == b["loss"] and all(np.isfinite(a["loss"])) and a["loss"][-1] < a["loss"][0]
-    assert a["fell_back"] == b["fell_back"]                                 # the census travels in the all-reduce
+    assert not a["fell_back"] and not b["fell_back"] and a["fault_log"] == [] and b["fault_log"] == []
+
+
+@pytest.mark.fault_injection
+def test_two_ranks_fall_back_together_on_an_injected_fault(gpu_device, tmp_path):
+    """The fault census travels in the step's ONE all-reduce: with a placement fault injected into rank 1 ONLY
+    (DEEPJ_DEBUG_CLUSTER_FAULT=1 in that process's environment; both ranks' cluster grids are small enough to be
+    co-resident: 6 tiles -> 64 workgroups each), BOTH ranks see the count, both switch to the per-tile kernels and repeat
+    the step, and the replicas stay bit-identical.  Rank 0 recorded no fault of its own."""
+    a, b = _two_ranks(tmp_path, (8, 8, 48), env_rank={1: {"DEEPJ_DEBUG_CLUSTER_FAULT": "1"}})
+    print("injected fault in rank 1:", a, b)
+    assert a["fell_back"] and b["fell_back"]
+    assert a["digest"] == b["digest"] and a["wnorm"] == b["wnorm"]
+    assert a["loss"] == b["loss"] and all(np.isfinite(a["loss"])) and a["loss"][-1] < a["loss"][0]
+    assert a["fault_log"] == [] and len(b["fault_log"]) == 1 and b["fault_log"][0][2] > 0      # misplaced, in rank 1 only
 
 
 def test_bench_two_rank_flow_on_one_gpu(gpu_device):

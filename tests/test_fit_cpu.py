@@ -272,10 +272,11 @@ def test_cluster_fault_repeats_the_step_on_the_per_tile_kernel(monkeypatch, caps
     assert all(np.array_equal(a, b) for a, b in zip(before, model.get_weights()))     # nothing was applied
 
 
-def test_stepwise_generation_repeats_a_faulted_step_once():
+def test_stepwise_generation_never_hides_a_cluster_fault(monkeypatch):
     """generate._fused_step: a time step whose device call reports a cluster fault (NaN-poisoned rows would be sampled
-    as silence) is computed again, once -- it has no device-side state -- and a second fault raises.  Fake engine on
-    the CPU: the host logic only."""
+    as silence) RAISES.  Only with DEEPJ_GENERATE_RETRY=1 (explicit hang protection) is it computed again, once -- it
+    has no device-side state -- counted in `repeated_steps`; a second fault raises.  Fake engine on the CPU: the host
+    logic only."""
     import types
     import torch
     from music_generator_amd import generate as Gn
@@ -293,7 +294,7 @@ def test_stepwise_generation_repeats_a_faulted_step_once():
             nxt[:, 5, 0] = float(self.calls)          # which call produced the notes that are used
             return nxt, torch.tensor([g * NUM_NOTES + g, 0], dtype=torch.int32)
 
-        def cluster_faults(self):
+        def cluster_faults(self, what="census"):
             return self.faults.pop(0) if self.faults else 0
 
         def raise_on_cluster_faults(self, what):
@@ -309,7 +310,12 @@ def test_stepwise_generation_repeats_a_faulted_step_once():
     eng = FakeEngine([0])                                   # healthy: one call
     Gn._fused_step(shared, eng, pieces)
     assert eng.calls == 1 and pieces[0].next_note[5, 0] == 1.0 and Gn.repeated_steps == before
-    eng = FakeEngine([3, 0])                                # one fault: the step is repeated, the second result is used
+    eng = FakeEngine([3, 0])                                # default: a fault raises, nothing is repeated
+    with pytest.raises(RuntimeError):
+        Gn._fused_step(shared, eng, pieces)
+    assert eng.calls == 1 and Gn.repeated_steps == before
+    monkeypatch.setenv("DEEPJ_GENERATE_RETRY", "1")
+    eng = FakeEngine([3, 0])                                # opt-in: the step is repeated, the second result is used
     pos = np.random.get_state()[2]
     Gn._fused_step(shared, eng, pieces)
     assert eng.calls == 2 and pieces[0].next_note[5, 0] == 2.0 and Gn.repeated_steps == before + 1

@@ -300,72 +300,7 @@ def test_lstm_fwd_bwd(gpu_device, dtype, H, S, Ls, sigm):
     if S % 32:
         full = dZd.float().cpu().reshape(tiles, Ls, 32, 4 * H)
         assert float(full[-1, :, S % 32:, :].abs().max()) == 0.0
-    if dtype == "bf16" and H == 256:
-        # the same sweep on PAIRS of workgroups (dj_lstm_bwd_pair: what the training step uses for the time axis): both
-        # dZ layouts, against the per-tile kernel (same numbers up to the summation order of dz U^T) and the oracle
-        cl = torch.zeros(lib.dj_lstm_cluster_scratch_bytes(), dtype=torch.uint8, device=gpu_device)
-        for cts_p, entry in ((0, lib.dj_lstm_bwd_pair), (cts, lib.dj_lstm_bwd_pair), (0, lib.dj_lstm_bwd_dual),
-                             (cts, lib.dj_lstm_bwd_dual)):
-            dZp = torch.zeros((4 * H // 256) * cts if cts_p else R * 4 * H, dtype=Zd.dtype, device=gpu_device)
-            db3 = torch.zeros_like(db)
-            L.check(entry(DT[dtype], H, tiles, Ls, L.ptr(Gd), L.ptr(upb), L.ptr(Cd), L.ptr(dHd), L.ptr(dZp),
-                          cts_p, L.ptr(db3), sigm, L.ptr(cl), _st()), "bwd pair / dual")
-            torch.cuda.synchronize()
-            assert lib.dj_lstm_cluster_faults(L.ptr(cl)) == 0
-            if cts_p:
-                dZp = dZp.reshape(4 * H // 256, cts)[:, :R * 256].reshape(4 * H // 256, R, 256).permute(1, 0, 2).reshape(R, 4 * H)
-            else:
-                dZp = dZp.reshape(R, 4 * H)
-            scale = float(dZd.float().abs().max())
-            assert float((dZp.float() - dZd.float()).abs().max()) <= 1e-2 * scale
-            torch.testing.assert_close(from_rows(dZp.float().cpu(), S, Ls), zx_ref.grad, rtol=rt * 2, atol=at * 5)
-            torch.testing.assert_close(db3.cpu(), zx_ref.grad.sum(dim=(0, 1)), rtol=rt * 2, atol=at * 20)
-            if S % 32:
-                full = dZp.float().cpu().reshape(tiles, Ls, 32, 4 * H)
-                assert float(full[-1, :, S % 32:, :].abs().max()) == 0.0
-        assert lib.dj_lstm_bwd_pair(DT[dtype], 128, tiles, Ls, L.ptr(Gd), L.ptr(upb), L.ptr(Cd), L.ptr(dHd), L.ptr(dZd), 0,
-                                    L.ptr(db), sigm, L.ptr(cl), _st()) >= 1000
 
-
-@pytest.mark.parametrize("entry", ["dj_lstm_bwd_pair", "dj_lstm_bwd_dual"])
-@pytest.mark.parametrize("tiles,Ls", [(8, 4), (9, 1), (17, 33), (2, 2), (64, 6), (301, 3)])
-def test_lstm_bwd_pair_tile_counts(gpu_device, tiles, Ls, entry):
-    """dj_lstm_bwd_pair / dj_lstm_bwd_dual (two tiles per workgroup pair, interleaved) against dj_lstm_bwd on the same
-    (random) stash / cell states / upstream gradient: pair groups that are full, partly filled and absent; a single
-    step (no exchange at all); odd tile counts (the dual form hands its last tile to the per-tile kernel); more tiles
-    than one launch holds (301 > 256: two launches); column-tile-major dZ.  The two kernels sum dz U^T in a different k order, so dz agrees
-    to bf16 rounding of nearly equal fp32 sums, not bit for bit."""
-    L, lib = _lib()
-    H, R = 256, tiles * Ls * 32
-    g = torch.Generator().manual_seed(100 + tiles)
-    U = torch.randn(H, 4 * H, generator=g) * (1.0 / H ** 0.5)
-    upb = torch.empty(H * 4 * H * 2, dtype=torch.uint8, device=gpu_device)
-    L.check(lib.dj_lstm_pack(1, H, L.ptr(U.to(gpu_device)), None, L.ptr(upb), _st()), "pack")
-    Z = torch.randint(0, 256, (R * 4 * H,), generator=g, dtype=torch.uint8).to(gpu_device)       # 8-bit gate codes
-    Cc = (torch.randn(R * H, generator=g) * 0.7).to(torch.bfloat16).to(gpu_device)
-    dH = (torch.randn(R, H, generator=g) * 0.1).to(torch.bfloat16).to(gpu_device)
-    cts = R * 256
-    outs = []
-    cl = torch.zeros(lib.dj_lstm_cluster_scratch_bytes(), dtype=torch.uint8, device=gpu_device)
-    for pair in (False, True):
-        dZ = torch.zeros(4 * cts, dtype=torch.bfloat16, device=gpu_device)
-        db = torch.zeros(4 * H, dtype=torch.float32, device=gpu_device)
-        if pair:
-            L.check(getattr(lib, entry)(1, H, tiles, Ls, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ), cts,
-                                        L.ptr(db), 0, L.ptr(cl), _st()), entry)
-        else:
-            L.check(lib.dj_lstm_bwd(1, H, tiles, Ls, L.ptr(Z), L.ptr(upb), L.ptr(Cc), L.ptr(dH), L.ptr(dZ), cts, L.ptr(db),
-                                    0, _st()), "bwd")
-        torch.cuda.synchronize()
-        outs.append((dZ.float().cpu(), db.cpu()))
-    assert lib.dj_lstm_cluster_faults(L.ptr(cl)) == 0
-    (dz0, db0), (dz1, db1) = outs
-    assert torch.isfinite(dz1).all()
-    scale = float(dz0.abs().max())
-    assert scale > 0
-    assert float((dz1 - dz0).abs().max()) <= 1e-2 * scale
-    assert float((dz1 - dz0).abs().mean()) <= 2e-4 * scale
-    torch.testing.assert_close(db1, db0, rtol=2e-3, atol=2e-3 * float(db0.abs().max()))
 
 
 def test_nadam_matches_oracle(gpu_device):
@@ -450,7 +385,7 @@ def _fwd_fused_case(gpu_device, dtype, H, S, Ls, D, sigm):
     torch.testing.assert_close(from_rows(Hd.float().cpu(), S, Ls), Href, rtol=rt, atol=at * 5)
     torch.testing.assert_close(from_rows(from_frag(Cd.float().cpu(), R, H), S, Ls), Cref, rtol=rt, atol=at * 5)
     check_stash(Gd, R, H, S, Ls, dtype, sigm, Zref)
-    assert lib.dj_lstm_cluster_faults(L.ptr(cl)) == 0      # no wait expired, every cluster sat on one XCD
+    assert lib.dj_lstm_cluster_faults(L.ptr(cl), _st()) == 0      # no wait expired, every cluster sat on one XCD
     if dtype == "bf16" and H == 256:
         # the same sweep without the scratch takes the per-tile kernel: same h to the last bit is not promised
         # (different summation order), same numbers to bf16 tolerance is
@@ -526,14 +461,15 @@ def test_lstm_bwd_remainder_input_gradient(gpu_device):
     assert bool((got[:, :256] == 7.0).all()) and bool((got[:, 260:] == 7.0).all())
 
 
-@pytest.mark.parametrize("H,S,Ls", [(256, 96, 9), (128, 64, 12)])
+@pytest.mark.parametrize("H,S,Ls", [(256, 96, 9), (128, 64, 12), (256, 64, 128), (128, 64, 128)])
 def test_gate_stash_quantiser_bounds_dz(gpu_device, H, S, Ls):
     """The 8-bit activated-gate stash of the bf16 kernels (include/deepj_hip.h 'Gate stash': |error| <= 1/508 for
     i, f, o and 1/254 for g, codes 0 / 255 = saturated hard_sigmoid) tested as a QUANTISER: the same forward is run by
     the bf16 kernels (8-bit stash) and by the fp32 kernels (z stash, exact activations in BPTT) on identical operand
     values; BPTT of both on the same upstream gradient; the difference in dz and in the bias gradient is bounded at
     ~2x what the encoding explains, far below the whole-step gradient tolerance.  Pre-activations are scaled so that
-    a good share of the gates saturate (codes 0 and 255 both present)."""
+    a good share of the gates saturate (codes 0 and 255 both present).  The 128-step cases are the reference's window
+    (constants.py:67): the stash error of every step feeds the recurrent gradient of all earlier steps."""
     L, lib = _lib()
     D, sigm = 24, 0
     x, W, U, b = _lstm_setup(S, Ls, D, H, 3 * H + S)
