@@ -41,8 +41,8 @@ PEAK_HBM_GBS = 8000.0                              # HBM3E, same guide
 def _fused_xw(cfg, d, H):
     """Mirror of dj_api.hip fuse_xw at the bench shape (>= 128 sequence tiles): is x*W of a layer with input
     width d and H units computed inside the recurrent forward kernel?"""
-    if H not in (128, 256):
-        return False
+    if H not in (128, 256):      # generic width (scaled model): bf16 folds x*W into every step's GEMM (dj_step.hip, round 4)
+        return cfg.dtype == "bf16" and os.environ.get("DEEPJ_STEP_EPILOGUE", "1") != "0"
     return d <= (288 if (H == 128 and cfg.dtype == "bf16") else 2 * H)
 
 
@@ -624,7 +624,9 @@ def main():
         # note-steps/s per GPU / HBM peak
         nsps = B * T * N * args.steps / elapsed
         cf_ = category_flops(cfg, B, T, N)
-        flops_ns = 3 * (cf_["gemm_xw"] + cf_["lstm_fwd_time"] + cf_["lstm_fwd_note"]) / (B * T * N)
+        # (+ the octave conv and the heads, which the MFMA categories above do not carry: 2*24*3*64 and 2*Hn*3 per note-step)
+        flops_ns = 3 * ((cf_["gemm_xw"] + cf_["lstm_fwd_time"] + cf_["lstm_fwd_note"]) / (B * T * N)
+                        + 2 * 2 * cfg.octave * cfg.note_units * cfg.octave_units + 2 * cfg.note_axis_units * 3)
         stash_ns = stash_bytes_per_note_step(cfg, 2 if args.dtype == "bf16" else 4)
         roof.update({"whole_step_mfma_frac": round(flops_ns * nsps / (PEAK_TFLOPS[args.dtype] * 1e12), 4),
                      "whole_step_stash_hbm_frac": round(stash_ns * nsps / (PEAK_HBM_GBS * 1e9), 4),

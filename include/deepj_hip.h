@@ -52,8 +52,8 @@ typedef struct dj_config {
 
 /* Kernel-selection flags (dj_config.kernel_flags: per engine; none changes results beyond summation order).  The
  * DEEPJ_* environment variables of the same meaning (DEEPJ_CLUSTER=0, DEEPJ_CLUSTER_PAIR=0, DEEPJ_CLUSTER_F32=0,
- * DEEPJ_CLUSTER_COOP=0, DEEPJ_FUSE_DX=0, DEEPJ_GEN_KSPLIT=0, DEEPJ_DEBUG_CLUSTER_FAULT=1, DEEPJ_DEBUG_CLUSTER_LATE=1,
- * DEEPJ_FUSE_XW_MIN_TILES=n)
+ * DEEPJ_CLUSTER_COOP=0, DEEPJ_FUSE_DX=0, DEEPJ_GEN_KSPLIT=0, DEEPJ_STEP_EPILOGUE=0, DEEPJ_DEBUG_CLUSTER_FAULT=1,
+ * DEEPJ_DEBUG_CLUSTER_LATE=1, DEEPJ_FUSE_XW_MIN_TILES=n)
  * are read ONCE, at the first call into the library, as process-wide defaults that are OR-ed with these bits; there
  * is no getenv on the launch path.  dj_env_reload() reads them again (tests that switch kernels inside one process).
  * A hipGraph captured from these calls keeps the selection in force at capture time.  dj_generate_prepare and
@@ -68,6 +68,8 @@ typedef struct dj_config {
 #define DJ_KF_DEBUG_CLUSTER_FAULT 64 /* cluster launches fail their placement check (fault-handling tests)            */
 #define DJ_KF_DEBUG_CLUSTER_LATE 128 /* the last member of every cluster never arrives in round 0: every other wave's  */
                                      /*   bound runs out, once (tests of the expiry path and its cost)                */
+#define DJ_KF_NO_STEP_EPILOGUE 256   /* generic-width layers (scaled model) in bf16: one GEMM + one gate launch per step   */
+                                     /*   instead of the cell as the GEMM's epilogue                                      */
 /* (ABI 3 had two opt-in re-decompositions of the H = 256 BPTT sweep, DJ_KF_BWD_PAIR / _DUAL; they were slower and now
  * live in tools/bwd_decompositions/, outside this library) */
 int32_t dj_env_reload(void);
@@ -288,7 +290,7 @@ int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, 
  * co-resident, e.g. the device shared with another stream's kernels) lets the bounded wait run out; a cluster whose
  * members report different hardware XCC ids (dispatch not round-robin over the XCDs, which the exchange through one
  * XCD's L2 relies on) is detected in round 0.  In both cases the affected tiles carry NaN from there on (so does the
- * loss) and the event is counted.  The bound counts POLLS (2^17 of them, ~100 ms of actual polling), not elapsed
+ * loss) and the event is counted.  The bound counts POLLS (2^19 of them, ~100 ms of actual polling), not elapsed
  * time: time during which the whole queue is off the device (another process's time slice, a driver-side eviction)
  * does not count against it.  The first wave whose bound runs out releases every other waiter of its cluster (a poison
  * bit in the counter) and no poisoned wave waits again, so a faulted launch costs one bound, not one per step.

@@ -139,7 +139,8 @@ int make_plan(const dj_config* cfg, Plan& p) {
   for (int l = 0; l < p.Lt; ++l) {
     const LstmP& L = p.tl[l];
     p.w_sp_t[l] = wtake(p.BT * L.D * 4); p.w_dpre_t[l] = wtake(p.BT * L.D * 4);
-    p.w_Wt_t[l] = wtake((int64_t)4 * L.H * (L.DP + 128) * p.esz); p.w_Wc_t[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
+    // (generic-width layers: room for the forward cell GEMM's operand [4H][K1p + H], dj_launch_pack_wu_gates)
+    p.w_Wt_t[l] = wtake((int64_t)4 * L.H * (L.DP + 128 + (rec_persistent(L.H) ? 0 : L.H)) * p.esz); p.w_Wc_t[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
     p.w_Uf_t[l] = wtake((int64_t)L.H * 4 * L.H * p.esz); p.w_Ub_t[l] = wtake((int64_t)L.H * 4 * L.H * p.esz);
     p.w_Wp_t[l] = wtake((int64_t)(L.D + 31) / 32 * 32 * 4 * L.H * p.esz);
     p.w_X_t[l] = wtake(p.Mt * L.DP * p.esz); p.w_Z_t[l] = wtake(p.Mt * stash_row_bytes(p, L.H));
@@ -149,7 +150,7 @@ int make_plan(const dj_config* cfg, Plan& p) {
   for (int l = 0; l < p.Ln; ++l) {
     const LstmP& L = p.nl[l];
     p.w_sp_n[l] = wtake(p.BT * L.D * 4); p.w_dpre_n[l] = wtake(p.BT * L.D * 4);
-    p.w_Wt_n[l] = wtake((int64_t)4 * L.H * (L.DP + 128) * p.esz); p.w_Wc_n[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
+    p.w_Wt_n[l] = wtake((int64_t)4 * L.H * (L.DP + 128 + (rec_persistent(L.H) ? 0 : L.H)) * p.esz); p.w_Wc_n[l] = wtake((int64_t)L.D * 4 * L.H * p.esz);
     p.w_Uf_n[l] = wtake((int64_t)L.H * 4 * L.H * p.esz); p.w_Ub_n[l] = wtake((int64_t)L.H * 4 * L.H * p.esz);
     p.w_Wp_n[l] = wtake((int64_t)(L.D + 31) / 32 * 32 * 4 * L.H * p.esz);
     p.w_X_n[l] = wtake(p.Mn * L.DP * p.esz); p.w_Z_n[l] = wtake(p.Mn * stash_row_bytes(p, L.H));
@@ -231,6 +232,7 @@ EnvDefaults read_env() {
   if (off("DEEPJ_CLUSTER_COOP")) d.flags |= DJ_KF_NO_CLUSTER_COOP;
   if (off("DEEPJ_FUSE_DX")) d.flags |= DJ_KF_NO_FUSE_DX;
   if (off("DEEPJ_GEN_KSPLIT")) d.flags |= DJ_KF_NO_GEN_KSPLIT;
+  if (off("DEEPJ_STEP_EPILOGUE")) d.flags |= DJ_KF_NO_STEP_EPILOGUE;
   if (on("DEEPJ_DEBUG_CLUSTER_FAULT")) d.flags |= DJ_KF_DEBUG_CLUSTER_FAULT;
   if (on("DEEPJ_DEBUG_CLUSTER_LATE")) d.flags |= DJ_KF_DEBUG_CLUSTER_LATE;
   if (const char* e = getenv("DEEPJ_FUSE_XW_MIN_TILES")) d.fuse_xw_min_tiles = atoll(e);
@@ -242,6 +244,8 @@ EnvDefaults& env_defaults() {
 }
 inline uint32_t kflags(const dj_config& c) { return (uint32_t)c.kernel_flags | env_defaults().flags; }
 
+// generic-width layers in bf16: the LSTM cell runs as the epilogue of each step's recurrent GEMM (dj_step.hip, CellEpi)
+inline bool step_epilogue(const dj_config& c) { return c.dtype == DJ_BF16 && !(kflags(c) & DJ_KF_NO_STEP_EPILOGUE); }
 // the weight-stationary cluster kernels may be used by this plan (host side: cleared per engine after a cluster fault)
 inline bool cluster_enabled(const dj_config& c) { return !(kflags(c) & DJ_KF_NO_CLUSTER); }
 
@@ -277,14 +281,17 @@ int prep_layer(const Ctx& c, const LstmP& L, int64_t wWt, int64_t wWc, int64_t w
                bool need_bwd) {
   const int dt = c.p.c.dtype;
   ProfScope ps(PC_PREP, c.st);
-  if (fuse_xw(c.p.c, L))   // input kernel W as MFMA B fragments for the fused x*W inside the recurrent kernel
+  const bool cell = !rec_persistent(L.H) && step_epilogue(c.p.c);
+  if (cell)         // [W ; U]^T with gate-interleaved rows: ONE operand for z_t = [x_t | h_{t-1}] [W ; U] (dj_step.hip)
+    RUN(dj_launch_pack_wu_gates(dt, c.P + L.W, c.P + L.U, L.D, dj_step_k1p(L.DP), L.H, c.at(wWt), c.st));
+  else if (fuse_xw(c.p.c, L))   // input kernel W as MFMA B fragments for the fused x*W inside the recurrent kernel
     RUN(dj_launch_lstm_pack_w(dt, L.H, c.P + L.W, L.D, dj_lstm_fused_nkx(dt, L.H, L.D), c.at(wWt), c.st));
   else              // k-contiguous Bt operand of the separate x*W GEMM
     RUN(dj_launch_cvt_transpose(dt, c.P + L.W, L.D, 4 * L.H, c.at(wWt), L.DP, c.st));
   if (rec_persistent(L.H)) {
     RUN(dj_launch_lstm_pack(dt, L.H, c.P + L.U, c.at(wUf), need_bwd ? c.at(wUb) : nullptr, c.st));
   } else {          // per-step path: U^T [4H, H] for r = h U, and U [H, 4H] in the operand dtype for dh = dz U^T
-    RUN(dj_launch_cvt_transpose(dt, c.P + L.U, L.H, 4 * L.H, c.at(wUf), L.H, c.st));
+    if (!cell) RUN(dj_launch_cvt_transpose(dt, c.P + L.U, L.H, 4 * L.H, c.at(wUf), L.H, c.st));
     if (need_bwd && dt != DJ_F32) RUN(dj_launch_cvt_copy(dt, c.P + L.U, (int64_t)L.H * 4 * L.H, c.at(wUb), c.st));
   }
   if (need_bwd && fuse_dx(c.p.c, L)) RUN(dj_launch_lstm_pack_wt(dt, L.H, c.P + L.W, L.D, c.at(wWp), c.st));
@@ -322,6 +329,14 @@ int lstm_layer_fwd(const Ctx& c, const LstmP& L, int64_t tiles, int steps, int64
                                  c.P + L.b, c.train ? c.at(wZ) : nullptr, c.at(wUf), c.at(wH),
                                  c.train ? c.at(wC) : nullptr, c.p.c.recurrent_sigmoid,
                                  cluster_enabled(c.p.c) ? c.at(c.p.w_cluster) : nullptr, kflags(c.p.c), c.st));
+    return 0;
+  }
+  if (!rec_persistent(L.H) && step_epilogue(c.p.c)) {
+    // generic width, bf16: one launch per recurrence step, z_t = [x_t | h_{t-1}] [W ; U] + b with the cell as its epilogue
+    ProfScope ps(is_note ? PC_LSTM_FWD_NOTE : PC_LSTM_FWD_TIME, c.st);
+    RUN(dj_launch_lstm_step_fwd_fused(L.H, (int)tiles, steps, c.at(wX), L.DP, L.D, c.at(wWt), c.P + L.b,
+                                      c.train ? c.at(wZ) : nullptr, c.at(wH), c.train ? c.at(wC) : nullptr,
+                                      c.at<float>(c.p.w_step), c.p.c.recurrent_sigmoid, c.st));
     return 0;
   }
   if (!rec_persistent(L.H)) {        // per-step path: z row-major in the operand dtype, in place in the stash buffer

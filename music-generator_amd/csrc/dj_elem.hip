@@ -843,6 +843,22 @@ __global__ void cvt_transpose_kernel(const float* __restrict__ W, int K, int N, 
   int n = idx / ld, k = idx % ld;
   out[idx] = dj_from_f32<T>(k < K ? W[(int64_t)k * N + n] : 0.f);
 }
+// B operand of the per-step forward GEMM whose epilogue is the cell (dj_kernels.h CellEpi): [W ; U]^T with its rows (the
+// gate columns) interleaved in groups of 8 units x 4 gates and k = [input columns, zero pad to K1p, hidden units]
+template <typename T>
+__global__ void pack_wu_gates_kernel(const float* __restrict__ W, const float* __restrict__ U, int D, int K1p, int H,
+                                     T* __restrict__ out) {
+  const int ld = K1p + H;
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)4 * H * ld) return;
+  const int np = (int)(idx / ld), k = (int)(idx % ld);
+  const int G = np >> 5, g = (np >> 3) & 3, e = np & 7;
+  const int64_t col = (int64_t)g * H + 8 * G + e;
+  float v = 0.f;
+  if (k < D) v = W[(int64_t)k * 4 * H + col];
+  else if (k >= K1p) v = U[(int64_t)(k - K1p) * 4 * H + col];
+  out[idx] = dj_from_f32<T>(v);
+}
 template <typename T> __global__ void cvt_copy_kernel(const float* __restrict__ W, int64_t n, T* __restrict__ out) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < n) out[idx] = dj_from_f32<T>(W[idx]);
@@ -1068,6 +1084,14 @@ int dj_launch_cvt_transpose(int dtype, const float* W, int K, int N, void* out, 
                                    ld),
                 hipLaunchKernelGGL(cvt_transpose_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, st, W, K, N,
                                    (bf16_t*)out, ld))
+  return (int)hipGetLastError();
+}
+int dj_launch_pack_wu_gates(int dtype, const float* W, const float* U, int D, int K1p, int H, void* out, hipStream_t st) {
+  if ((H % 8) || D > K1p) return 1025;
+  int64_t n = (int64_t)4 * H * (K1p + H);
+  DJ_T_DISPATCH(hipLaunchKernelGGL(pack_wu_gates_kernel<float>, dim3(nblk(n)), dim3(256), 0, st, W, U, D, K1p, H, (float*)out),
+                hipLaunchKernelGGL(pack_wu_gates_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, st, W, U, D, K1p, H,
+                                   (bf16_t*)out))
   return (int)hipGetLastError();
 }
 int dj_launch_cvt_copy(int dtype, const float* W, int64_t n, void* out, hipStream_t st) {

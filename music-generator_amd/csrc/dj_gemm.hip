@@ -835,12 +835,59 @@ __device__ __forceinline__ void load4(const float* p, float* x) {
   x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
 }
 
-template <typename TC, bool CFRAG>
+// ---- forward LSTM cell as the epilogue of a step's GEMM z_t = [x_t | h_{t-1}] [W ; U] (dj_kernels.h CellEpi; scaled
+// model).  One 32 x 32 block of the C^T accumulator: lane (l31, h) holds virtual row `row` = rowb + l31, registers
+// 4 q + e <-> output column colb + 8 q + 4 h + e = gate q of unit 8 (colb / 32) + 4 h + e (gate-interleaved B rows).  The
+// epilogue LOADS only the carry (16 bytes per lane, coalesced): z = acc + bias is rounded to bf16 once -- the value the
+// activations see is the value BPTT reads back from the stash.
+__device__ __forceinline__ float bf16_round(float x) { return dj_to_f32(dj_from_f32<bf16_t>(x)); }
+
+template <bool SIGM>
+__device__ __forceinline__ void cell_fwd_block(const f32x16& a, const CellEpi& ce, const float* __restrict__ bias, int row,
+                                               int colb, int lane, int h) {
+  const int H = ce.H, G = colb >> 5, u0 = 8 * G + 4 * h;
+  const int64_t pr = rbs_row(row, ce.steps);
+  float z[4][4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 bv = *(const float4*)(bias + g * H + u0);
+    z[g][0] = bf16_round(a[4 * g] + bv.x); z[g][1] = bf16_round(a[4 * g + 1] + bv.y);
+    z[g][2] = bf16_round(a[4 * g + 2] + bv.z); z[g][3] = bf16_round(a[4 * g + 3] + bv.w);
+  }
+  float4* cp = (float4*)ce.carry + (((int64_t)(row >> 5) * (H >> 3) + G) * 64 + lane);
+  float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!ce.first) cv = *cp;                                    // step 0 starts from c = 0
+  float c[4] = {cv.x, cv.y, cv.z, cv.w}, hn[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float ig = dj_ract<SIGM>(z[0][e]), fg = dj_ract<SIGM>(z[1][e]), gg = dj_tanh(z[2][e]), og = dj_ract<SIGM>(z[3][e]);
+    c[e] = fg * c[e] + ig * gg;
+    hn[e] = og * dj_tanh(c[e]);
+  }
+  *cp = make_float4(c[0], c[1], c[2], c[3]);
+  store4((bf16_t*)ce.Hs + pr * H + u0, hn[0], hn[1], hn[2], hn[3]);
+  if (ce.Cs) {                                                // training: cell-state and pre-activation stash for BPTT
+    store4((bf16_t*)ce.Cs + pr * H + u0, c[0], c[1], c[2], c[3]);
+    bf16_t* zrow = (bf16_t*)ce.Z + pr * 4 * H + u0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) store4(zrow + g * H, z[g][0], z[g][1], z[g][2], z[g][3]);
+  }
+}
+
+template <int EPI>
+__device__ __forceinline__ void cell_block(const f32x16& a, const CellEpi& ce, const float* bias, int row, int colb, int lane,
+                                           int h) {
+  if constexpr (EPI == 1) cell_fwd_block<false>(a, ce, bias, row, colb, lane, h);
+  if constexpr (EPI == 2) cell_fwd_block<true>(a, ce, bias, row, colb, lane, h);
+}
+
+template <typename TC, bool CFRAG, int EPI = 0>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int K, const bf16_t* __restrict__ A,
                                                                int lda, const bf16_t* __restrict__ Bt, int ldb,
                                                                TC* __restrict__ C, int ldc,
                                                                const float* __restrict__ bias, int ntn, int ntm,
-                                                               int xcd_map, int a_rbs, int c_rbs, int64_t a_cts, int c_acc) {
+                                                               int xcd_map, int a_rbs, int c_rbs, int64_t a_cts, int c_acc,
+                                                               CellEpi ce) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
@@ -869,6 +916,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
   const int rsub = lane >> 3, cp = lane & 7;
   const bf16_t* ra[4];
+  const bf16_t* ra2[4];         // cell epilogue (EPI): the k range past ce.K1p comes from a second matrix (h_{t-1})
   const bf16_t* rb[2];
   int kza[4], kzb[2];
   bool va[4], vb[2];
@@ -889,6 +937,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
         kza[i] = (cp ^ ((row >> 1) & 7)) << 3;
         va[i] = m0 + row < M;
         ra[i] = va[i] ? A + rbs_row(m0 + row, a_rbs) * lda + kza[i] : zl;
+        if constexpr (EPI != 0)
+          ra2[i] = (va[i] && ce.A2) ? (const bf16_t*)ce.A2 + rbs_row(m0 + row, a_rbs) * ce.lda2 + kza[i] : zl;
       }
     }
     const int k0 = i_kt * NT2_BK;
@@ -896,8 +946,15 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
     const int64_t ka = a_cts ? (int64_t)(k0 >> 8) * a_cts + (k0 & 255) : k0;
     const unsigned sa = lds0 + (unsigned)i_slot * NT2_STAGE, sb = sa + NT2_ABYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      glds16((va[i] && k0 + kza[i] < K) ? ra[i] + ka : zl, __builtin_amdgcn_readfirstlane(sa + (unsigned)(w * 4 + i) * 1024u));
+    for (int i = 0; i < 4; ++i) {
+      const bf16_t* src;
+      if constexpr (EPI != 0)      // [x_t | h_{t-1}]: columns [0, K1) of A (zeros up to K1p), then columns of A2
+        src = k0 < ce.K1p ? ((va[i] && k0 + kza[i] < ce.K1) ? ra[i] + k0 : zl)
+                          : ((va[i] && k0 + kza[i] < K) ? ra2[i] + (k0 - ce.K1p) : zl);
+      else
+        src = (va[i] && k0 + kza[i] < K) ? ra[i] + ka : zl;
+      glds16(src, __builtin_amdgcn_readfirstlane(sa + (unsigned)(w * 4 + i) * 1024u));
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       glds16((vb[i] && k0 + kzb[i] < K) ? rb[i] + k0 : zl, __builtin_amdgcn_readfirstlane(sb + (unsigned)(w * 2 + i) * 1024u));
@@ -960,7 +1017,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int colb = n0 + wc * 64 + j * 32, rowb = m0 + wr * 64 + i * 32;
-          if constexpr (CFRAG) {
+          if constexpr (EPI != 0) {
+            if (rowb + l31 < M && colb < N) cell_block<EPI>(acc[i][j], ce, bias, rowb + l31, colb, lane, h);
+          } else if constexpr (CFRAG) {
             const int col = colb + l31;
             if (col < N && rowb < M) {
               const float bv = bias ? bias[col] : 0.f;
@@ -1016,12 +1075,12 @@ static_assert((NT3_NS & (NT3_NS - 1)) == 0, "ring slot counter wraps by masking"
 constexpr int NT3_ABYTES = NT3_BM * NT3_BK * 2, NT3_BBYTES = NT3_BN * NT3_BK * 2, NT3_STAGE = NT3_ABYTES + NT3_BBYTES;
 
 
-template <typename TC, bool CFRAG>
+template <typename TC, bool CFRAG, int EPI = 0>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, int K, const bf16_t* __restrict__ A,
                                                                 int lda, const bf16_t* __restrict__ Bt, int ldb,
                                                                 TC* __restrict__ C, int ldc,
                                                                 const float* __restrict__ bias, int ntn, int ntm,
-                                                                int a_rbs, int c_rbs, int64_t a_cts, int c_acc) {
+                                                                int a_rbs, int c_rbs, int64_t a_cts, int c_acc, CellEpi ce) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 2, wc = w & 3;
@@ -1046,6 +1105,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, in
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
   const int rsub = lane >> 2, cp = lane & 3;
   const bf16_t* ra[2];
+  const bf16_t* ra2[2];         // cell epilogue (EPI): the k range past ce.K1p comes from a second matrix (h_{t-1})
   const bf16_t* rb[2];
   int kz[2];                    // this lane's k offset inside a stage (swizzled 16-byte chunk)
   bool va[2], vb[2];
@@ -1063,6 +1123,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, in
         vb[ii] = n0 + row < N;
         ra[ii] = va[ii] ? A + rbs_row(m0 + row, a_rbs) * lda + kz[ii] : zl;
         rb[ii] = vb[ii] ? Bt + (int64_t)(n0 + row) * ldb + kz[ii] : zl;
+        if constexpr (EPI != 0)
+          ra2[ii] = (va[ii] && ce.A2) ? (const bf16_t*)ce.A2 + rbs_row(m0 + row, a_rbs) * ce.lda2 + kz[ii] : zl;
       }
     }
     const int k0 = i_kt * NT3_BK;
@@ -1071,7 +1133,12 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, in
     const unsigned sa = lds0 + (unsigned)i_slot * NT3_STAGE, sb = sa + NT3_ABYTES;
     const bool kin = k0 + kz[i] < K;
     const unsigned po = (unsigned)(w * 2 + i) * 1024u;
-    glds16((va[i] && kin) ? ra[i] + ka : zl, __builtin_amdgcn_readfirstlane(sa + po));
+    const bf16_t* asrc;
+    if constexpr (EPI != 0)        // [x_t | h_{t-1}]: columns [0, K1) of A (zeros up to K1p), then columns of A2
+      asrc = k0 < ce.K1p ? ((va[i] && k0 + kz[i] < ce.K1) ? ra[i] + k0 : zl) : ((va[i] && kin) ? ra2[i] + (k0 - ce.K1p) : zl);
+    else
+      asrc = (va[i] && kin) ? ra[i] + ka : zl;
+    glds16(asrc, __builtin_amdgcn_readfirstlane(sa + po));
     glds16((vb[i] && kin) ? rb[i] + k0 : zl, __builtin_amdgcn_readfirstlane(sb + po));
   };
   auto dma_advance = [&]() {
@@ -1182,7 +1249,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, in
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int colb = n0 + wc * 64 + j * 32, rowb = m0 + wr * 128 + i * 32;
-          if constexpr (CFRAG) {
+          if constexpr (EPI != 0) {
+            if (rowb + l31 < M && colb < N) cell_block<EPI>(acc[i][j], ce, bias, rowb + l31, colb, lane, h);
+          } else if constexpr (CFRAG) {
             const int col = colb + l31;
             if (col < N && rowb < M) {
               const float bv = bias ? bias[col] : 0.f;
@@ -1285,13 +1354,13 @@ int dj_launch_gemm_nt_ex(int dtype, int M, int N, int K, const void* A, int lda,
     if (ldc % 4) return 1007;
     if (c_frag)
       hipLaunchKernelGGL((gemm_nt_bf16_wide_kernel<bf16_t, true>), dim3(grid3), dim3(512), smem, st, M, N, K,
-                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs, a_cts, c_acc);
+                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs, a_cts, c_acc, CellEpi{});
     else if (c_is_f32)
       hipLaunchKernelGGL((gemm_nt_bf16_wide_kernel<float, false>), dim3(grid3), dim3(512), smem, st, M, N, K,
-                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs, a_cts, c_acc);
+                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs, a_cts, c_acc, CellEpi{});
     else
       hipLaunchKernelGGL((gemm_nt_bf16_wide_kernel<bf16_t, false>), dim3(grid3), dim3(512), smem, st, M, N, K,
-                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs, a_cts, c_acc);
+                         (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn3, ntm3, a_rbs, c_rbs, a_cts, c_acc, CellEpi{});
     return (int)hipGetLastError();
   }
   if (dtype == DJ_BF16) {
@@ -1325,15 +1394,15 @@ int dj_launch_gemm_nt_ex(int dtype, int M, int N, int K, const void* A, int lda,
     if (c_frag)
       hipLaunchKernelGGL((gemm_nt_bf16_dma_kernel<bf16_t, true>), dim3(grid2), dim3(512), smem, st, M, N, K,
                          (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn2, ntm2, xcd_map,
-                         a_rbs, c_rbs, a_cts, c_acc);
+                         a_rbs, c_rbs, a_cts, c_acc, CellEpi{});
     else if (c_is_f32)
       hipLaunchKernelGGL((gemm_nt_bf16_dma_kernel<float, false>), dim3(grid2), dim3(512), smem, st, M, N, K,
                          (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (float*)C, ldc, bias, ntn2, ntm2, xcd_map,
-                         a_rbs, c_rbs, a_cts, c_acc);
+                         a_rbs, c_rbs, a_cts, c_acc, CellEpi{});
     else
       hipLaunchKernelGGL((gemm_nt_bf16_dma_kernel<bf16_t, false>), dim3(grid2), dim3(512), smem, st, M, N, K,
                          (const bf16_t*)A, lda, (const bf16_t*)Bt, ldb, (bf16_t*)C, ldc, bias, ntn2, ntm2, xcd_map,
-                         a_rbs, c_rbs, a_cts, c_acc);
+                         a_rbs, c_rbs, a_cts, c_acc, CellEpi{});
     return (int)hipGetLastError();
   }
   // fp32 (parity mode): register-staged 128 x 128 kernel on v_mfma_f32_32x32x2_f32
@@ -1342,6 +1411,61 @@ int dj_launch_gemm_nt_ex(int dtype, int M, int N, int K, const void* A, int lda,
   hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, block, 0, st, M, N, K, (const float*)A, lda,
                      (const float*)Bt, ldb, (float*)C, ldc, bias, ntn, c_frag, a_rbs, c_rbs);
   return (int)hipGetLastError();
+}
+
+// One recurrence step of the generic-width LSTM path with the cell as the GEMM's epilogue (bf16; CellEpi in dj_kernels.h).
+// Tile choice as dj_launch_gemm_nt_ex (256 x 256, or 256 x 128 when that fills more compute units); N is not split (the
+// epilogue derives gate and unit from the global column), partial tiles are guarded by the kernels.
+template <int EPI>
+static int launch_cell(int M, int N, int K, const bf16_t* A, int lda, int a_rbs, const bf16_t* Bt, int ldb, const CellEpi& ce,
+                       const float* bias, hipStream_t st) {
+  const int64_t wide_tiles = (int64_t)((N + NT3_BN - 1) / NT3_BN) * ((M + NT3_BM - 1) / NT3_BM);
+  const int64_t narrow_tiles = (int64_t)((N + NT2_BN - 1) / NT2_BN) * ((M + NT2_BM - 1) / NT2_BM);
+  const bool few_wide_tiles = wide_tiles < 256 && narrow_tiles >= 2 * wide_tiles;
+  static bool attr_done_dev[DJ_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[dj_current_device()];
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_bf16_wide_kernel<bf16_t, false, EPI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, NT3_NS * NT3_STAGE);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)gemm_nt_bf16_dma_kernel<bf16_t, false, EPI>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, NT2_NS * NT2_STAGE);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  if (N > 128 && !few_wide_tiles) {
+    const int ntn3 = (N + NT3_BN - 1) / NT3_BN, ntm3 = (M + NT3_BM - 1) / NT3_BM;
+    int grid3 = 256;
+    if ((int64_t)ntn3 * ntm3 < 256) grid3 = ((ntn3 * ntm3 + 7) / 8) * 8;
+    hipLaunchKernelGGL((gemm_nt_bf16_wide_kernel<bf16_t, false, EPI>), dim3(grid3), dim3(512), (size_t)NT3_NS * NT3_STAGE, st, M,
+                       N, K, A, lda, Bt, ldb, (bf16_t*)nullptr, 0, bias, ntn3, ntm3, a_rbs, 1, (int64_t)0, 0, ce);
+    return (int)hipGetLastError();
+  }
+  const int ntn2 = (N + NT2_BN - 1) / NT2_BN, ntm2 = (M + NT2_BM - 1) / NT2_BM;
+  int grid2, xcd_map = 0;
+  if (ntn2 <= 32 && ntm2 >= 64) {
+    grid2 = 256;
+    xcd_map = 1;
+  } else {
+    int mrows = 256 / ntn2;
+    if (mrows < 1) mrows = 1;
+    if (mrows > ntm2) mrows = ntm2;
+    grid2 = mrows * ntn2;
+  }
+  hipLaunchKernelGGL((gemm_nt_bf16_dma_kernel<bf16_t, false, EPI>), dim3(grid2), dim3(512), (size_t)NT2_NS * NT2_STAGE, st, M, N,
+                     K, A, lda, Bt, ldb, (bf16_t*)nullptr, 0, bias, ntn2, ntm2, xcd_map, a_rbs, 1, (int64_t)0, 0, ce);
+  return (int)hipGetLastError();
+}
+int dj_launch_gemm_nt_cell(int M, const void* A, int lda, int a_rbs, const void* Bt, int ldb, const CellEpi& ce,
+                           const float* bias, hipStream_t st) {
+  if (M <= 0) return 0;
+  const int N = 4 * ce.H, K = ce.K1p + (ce.A2 ? ce.H : 0);
+  if ((M % 32) || (ce.H % 8) || (lda % 8) || (ldb % 8) || (ce.lda2 % 8) || a_rbs < 1 || !ce.carry || !ce.Hs || !bias ||
+      ce.K1 > ce.K1p || (ce.K1p % 64) || ce.K1 > lda || ldb < ce.K1p + ce.H || (!ce.A2 && !ce.first) || (ce.Cs && !ce.Z))
+    return 1026;
+  const bf16_t *a = (const bf16_t*)A, *b = (const bf16_t*)Bt;
+  return ce.sigm ? launch_cell<2>(M, N, K, a, lda, a_rbs, b, ldb, ce, bias, st)
+                 : launch_cell<1>(M, N, K, a, lda, a_rbs, b, ldb, ce, bias, st);
 }
 
 int dj_launch_gemm_tn(int dtype, int64_t M, int Ka, int ka_valid, int N, const void* A, int lda, const void* B, int ldb, float* C,

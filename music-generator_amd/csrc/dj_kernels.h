@@ -68,7 +68,29 @@ struct DenseBatch {
   int N[DJ_DENSE_BATCH_MAX];
 };
 
+// FORWARD LSTM cell of one recurrence step as the EPILOGUE of that step's GEMM (generic-width path, bf16; dj_step.hip
+// drives it, dj_gemm.hip runs it): z_t = [x_t | h_{t-1}] [W ; U] + b in ONE product over K = K1p + H -- A (the kernel's
+// A operand) holds the rows x_t (K1 valid columns, taken as zero up to K1p, a multiple of 64), A2 the rows h_{t-1} (null
+// at step 0) -- with the rows of the packed B operand [4H][K1p + H] in GATE-INTERLEAVED order (row n' = 32 G + 8 g + e is
+// gate column g H + 8 G + e of W and U: dj_launch_pack_wu_gates), so that a lane of the C^T accumulator block holds all
+// four gates of 4 units of one row and turns them into c_t, h_t on the spot.  No x W pass, no z round trip, no gate launch.
+// Rows are "all sequences at step t" of the sequence-tiled buffers: virtual row v at physical row ((v >> 5) * steps) * 32
+// + (v & 31) of the pointers below, which stand at step t.  Writes Hs and, when training (Cs != null), Cs and z (the
+// stash BPTT reads), all in their natural layouts; `carry` (c_{t-1}) is fp32 in FRAGMENT layout [rows/32][H/8][64 lanes][4]
+// -- 16 bytes per lane, coalesced; only this epilogue touches it.
+struct CellEpi {
+  int H, steps, sigm, first;      // first: step 0 (c_{-1} = 0, carry not read)
+  int K1, K1p, lda2;
+  const void* A2;                 // h_{t-1} rows [.., H] (same row-block stride as A) or null
+  float* carry;
+  void* Z;                        // bf16 [.., 4H]: final pre-activations out (training only)
+  void* Hs;                       // h_t out [.., H]
+  void* Cs;                       // c_t out [.., H] or null (inference)
+};
 // dj_gemm.hip
+// A [M, K1] (lda, row-block stride a_rbs) and ce.A2 [M, H] x Bt [4H, K1p + H]^T (ldb), bias [4H] in natural gate order
+int dj_launch_gemm_nt_cell(int M, const void* A, int lda, int a_rbs, const void* Bt, int ldb, const CellEpi& ce,
+                           const float* bias, hipStream_t st);
 int dj_launch_gemm_nt(int dtype, int M, int N, int K, const void* A, int lda, const void* Bt, int ldb, void* C, int ldc,
                       int c_mode, const float* bias, hipStream_t st);
 // same with row-block strides on A and C (dj_gemm.hip rbs_row): per-step views of sequence-tiled buffers
@@ -123,6 +145,11 @@ int dj_lstm_cluster_fault_line(void* cluster_scratch, int32_t* words_host, hipSt
 int64_t dj_lstm_step_scratch_floats(int H, int64_t ntiles);
 int dj_launch_lstm_step_fwd(int dtype, int H, int ntiles, int steps, void* Z, const void* Ut, void* Hs, void* Cs,
                             float* scratch, int sigm, hipStream_t st);
+// bf16: the whole forward sweep of a generic-width layer as `steps` GEMMs with the cell as their epilogue (CellEpi): X
+// [rows, DP] (D valid columns), WU from dj_launch_pack_wu_gates (K1p = dj_step_k1p(DP)), bias [4H]; Z / Cs null = inference
+int dj_step_k1p(int DP);
+int dj_launch_lstm_step_fwd_fused(int H, int ntiles, int steps, const void* X, int DP, int D, const void* WU,
+                                  const float* bias, void* Z, void* Hs, void* Cs, float* scratch, int sigm, hipStream_t st);
 int dj_launch_lstm_step_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* Uc, const void* Cs,
                             const void* dH, void* dZ, float* dbias, float* scratch, int sigm, hipStream_t st);
 // dj_elem.hip
@@ -143,6 +170,9 @@ int dj_launch_glue_fwd(int dtype, const void* ga, const void* Hin, void* X, hipS
 int dj_launch_glue_bwd(int dtype, const void* ga, const void* dX, void* dH, float* dpre, hipStream_t st);
 int dj_launch_head(int dtype, const void* ha, const void* Hn, void* dH, hipStream_t st);
 int dj_launch_cvt_transpose(int dtype, const float* W, int K, int N, void* out, int ld, hipStream_t st);
+// B operand of the forward cell GEMM (CellEpi): out[n'][k], n' = 32 G + 8 g + e <-> gate column c = g H + 8 G + e,
+// k < D: W[k][c]; D <= k < K1p: 0; K1p <= k < K1p + H: U[k - K1p][c]    (W [D, 4H], U [H, 4H] fp32 Keras layouts)
+int dj_launch_pack_wu_gates(int dtype, const float* W, const float* U, int D, int K1p, int H, void* out, hipStream_t st);
 int dj_launch_cvt_copy(int dtype, const float* W, int64_t n, void* out, hipStream_t st);
 int dj_launch_cvt_to_f32(int dtype, const void* in, int64_t n, float* out, hipStream_t st);
 int dj_launch_nadam(float* p, const float* g, float* m, float* v, int64_t n, const void* na, hipStream_t st);

@@ -699,14 +699,15 @@ __device__ __forceinline__ void cl_load_x(ClXRegs<NR>& q, const bf16_t* xb, int 
 // every waiter comes back to a poll that still shows the old count -- the late member was off the device too -- next to
 // a clock that says the bound is long gone, and all of them "expire" together although nobody is late relative to anybody
 // else (a 1024-step generation test lost 6 waits at once on one box that way).  A poll
-// is only counted when the wave executes it, so the bound below is ~100 ms of ACTUAL polling (each poll is a load
-// from L2 past the L1, 0.5 - 1 us, plus 128 cycles of sleep) whatever happens to the queue in between.
+// is only counted when the wave executes it, so the bound below is ~100 ms of ACTUAL polling (a poll -- a load from L2
+// past the L1 plus 128 cycles of sleep -- measured 384 shader cycles: 2^19 of them are 2.0e8 cycles) whatever happens
+// to the queue in between.
 // STICKY: the first wave of a cluster whose bound does run out (grid not co-resident: a member never arrives) sets
 // CL_POISON in the cluster's counter, which satisfies every later target at once; a wave that sees the bit -- or fails
 // its placement check -- is `dead`: its tile carries NaN from there on and it does not wait again (it keeps storing and
 // arriving, so no partner stalls on it).  A faulted launch therefore costs ONE bound, not one per remaining step.
 constexpr int CL_POISON = 1 << 30;
-constexpr unsigned CL_WAIT_POLLS = 1u << 17;
+constexpr unsigned CL_WAIT_POLLS = 1u << 19;
 constexpr unsigned CL_GAP_NOTE = 1u << 17, CL_GAP_STALL = 1u << 20;   // ~60 us / ~0.5 ms at 2.1 GHz
 enum { CLF_EXPIRED = 0, CLF_MISPLACED = 1, CLF_HOOK = 2, CLF_STALLS = 4, CLF_MAXGAP = 5, CLF_DIAG = 8, CLF_WORDS = 32 };
 constexpr int CLW_GATE = 1 << 28;

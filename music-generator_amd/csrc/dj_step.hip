@@ -13,9 +13,12 @@
 // Buffers are row-major in the sequence-tiled row order of dj_common.h (dj_row); "all sequences
 // at step t" is addressed with the row-block stride of dj_launch_gemm_nt_rbs.  The cell state and
 // its gradient are carried between launches in fp32 (as the persistent kernels carry them in
-// registers); z, c, h stashes have the operand dtype.  bf16: the forward GEMM of a step ACCUMULATES
-// h_{t-1} U into the stash rows of z_t in its epilogue (no fp32 r buffer, the gate kernel reads z and
-// writes h, c only); the gate kernels move 16 bytes per access.
+// registers); z, c, h stashes have the operand dtype.  bf16 FORWARD (round 4, dj_launch_lstm_step_fwd_fused): ONE launch
+// per step and nothing else -- z_t = [x_t | h_{t-1}] [W ; U] + b as one product over K = DP + H whose epilogue IS the
+// cell (dj_kernels.h CellEpi, dj_gemm.hip cell_fwd_block): no x W pass over the layer, no z round trip, no gate launch.
+// DJ_KF_NO_STEP_EPILOGUE keeps the round-3 form: x W as one GEMM, then per step a GEMM that ACCUMULATES h_{t-1} U into
+// the stash rows of z_t in its epilogue (c_mode 3) and a 16-byte gate kernel.  bf16 BPTT: one GEMM (fp32 r out) and one
+// gate kernel per step (the cell as the BPTT GEMM's epilogue was built and measured 2x slower).
 #include "dj_common.h"
 #include "dj_kernels.h"
 
@@ -408,6 +411,28 @@ int dj_launch_lstm_step_fwd(int dtype, int H, int ntiles, int steps, void* Z, co
   float* cst = scratch + (int64_t)ntiles * 32 * 4 * H;
   return dtype == DJ_F32 ? step_fwd_t<float>(H, ntiles, steps, Z, Ut, Hs, Cs, R, cst, sigm, st)
                          : step_fwd_t<bf16_t>(H, ntiles, steps, Z, Ut, Hs, Cs, R, cst, sigm, st);
+}
+
+int dj_step_k1p(int DP) { return (DP + 63) / 64 * 64; }
+
+int dj_launch_lstm_step_fwd_fused(int H, int ntiles, int steps, const void* X, int DP, int D, const void* WU,
+                                  const float* bias, void* Z, void* Hs, void* Cs, float* scratch, int sigm, hipStream_t st) {
+  if (ntiles <= 0 || steps <= 0) return 0;
+  if (H < 32 || (H % 32) || D > DP || (DP % 8)) return 1012;
+  const int nrows = ntiles * 32, K1p = dj_step_k1p(DP);
+  CellEpi ce{};
+  ce.H = H; ce.steps = steps; ce.sigm = sigm; ce.K1 = D; ce.K1p = K1p; ce.lda2 = H;
+  ce.carry = scratch + (int64_t)nrows * 4 * H;               // where the gate-launch form keeps its carry
+  for (int t = 0; t < steps; ++t) {
+    ce.first = t == 0;
+    ce.A2 = t > 0 ? (const bf16_t*)Hs + (int64_t)(t - 1) * 32 * H : nullptr;
+    ce.Z = Z ? (bf16_t*)Z + (int64_t)t * 32 * 4 * H : (bf16_t*)nullptr;
+    ce.Hs = (bf16_t*)Hs + (int64_t)t * 32 * H;
+    ce.Cs = Cs ? (bf16_t*)Cs + (int64_t)t * 32 * H : (bf16_t*)nullptr;
+    const int rc = dj_launch_gemm_nt_cell(nrows, (const bf16_t*)X + (int64_t)t * 32 * DP, DP, steps, WU, K1p + H, ce, bias, st);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 int dj_launch_lstm_step_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* Uc, const void* Cs,

@@ -127,7 +127,10 @@ def _stream_ptr():
 # read-back of a training step): process-wide, empty in a healthy run.  The GPU tests fail on any entry that a test did
 # not inject (tests/conftest.py), so a recurrence on the driver's box cannot hide behind a fallback.
 FAULT_LOG: list = []
-_LIVE = weakref.WeakSet()          # engines alive in this process (census of their stall words at the end of a test)
+_LIVE = weakref.WeakSet()          # engines alive in this process
+# Stall census of the engines that have been destroyed (Engine.__del__ reads the fault line once more): how many there
+# were, the most waits any of them saw with polls > 2^20 cycles apart, the longest gap between two polls of a wait.
+CENSUS = {"engines": 0, "stalled_waits": 0, "max_poll_gap_cycles": 0}
 
 _WAIT_KINDS = {1: "bf16 sweep", 2: "bf16 cooperative body", 3: "fp32 inference sweep", 5: "pair BPTT (tools)",
                6: "two-tile BPTT (tools)"}
@@ -195,6 +198,18 @@ class Engine:
         self.loss = torch.zeros(4, dtype=torch.float32, device=self.device)
         self.last_fault = None                           # the newest FAULT_LOG entry of this engine
         _LIVE.add(self)
+
+    def __del__(self):
+        # last look at the fault line: the stall census goes to the module's CENSUS, counts nobody read to FAULT_LOG
+        try:
+            rep = self.cluster_fault_report()
+            CENSUS["engines"] += 1
+            CENSUS["stalled_waits"] = max(CENSUS["stalled_waits"], rep["stalled_waits"])
+            CENSUS["max_poll_gap_cycles"] = max(CENSUS["max_poll_gap_cycles"], rep["max_poll_gap_cycles"])
+            if rep["expired"] or rep["misplaced"]:
+                self._log_faults("unread when the engine was destroyed", rep, rep["expired"] + rep["misplaced"])
+        except Exception:                                # interpreter / HIP runtime shutting down
+            pass
 
     def set_kernel_flags(self, flags: int):
         """Per-engine kernel selection (DJ_KF_*); e.g. KF_NO_CLUSTER after a cluster fault.  Affects later calls of

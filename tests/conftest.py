@@ -71,18 +71,21 @@ def djenv(monkeypatch):
 # step-wise generation repeated a step, or a live engine holds fault counts nobody read.  The stall census (the longest
 # gap between two polls of any exchange wait: a wave that was off the device) is collected from every engine and
 # printed at the end of the session -- evidence about the box even when nothing expired.
-_CENSUS = {"engines": 0, "stalled_waits": 0, "max_poll_gap_cycles": 0, "faults_in_injection_tests": 0, "worst": None}
+_CENSUS = {"live_readings": 0, "stalled_waits": 0, "max_poll_gap_cycles": 0, "faults_in_injection_tests": 0, "worst": None}
 
 
 def _census_live_engines():
+    """Engines still alive after a test (most die with the test's locals: Engine.__del__ files theirs under E.CENSUS)."""
+    import gc
     from music_generator_amd import engine as E
+    gc.collect()
     unread = []
     for eng in list(E._LIVE):
         try:
             rep = eng.cluster_fault_report()
         except Exception:
             continue
-        _CENSUS["engines"] += 1
+        _CENSUS["live_readings"] += 1
         _CENSUS["stalled_waits"] = max(_CENSUS["stalled_waits"], rep["stalled_waits"])
         if rep["max_poll_gap_cycles"] > _CENSUS["max_poll_gap_cycles"]:
             _CENSUS["max_poll_gap_cycles"] = rep["max_poll_gap_cycles"]
@@ -115,8 +118,8 @@ def cluster_fault_census(request):
                 pass
         del E.FAULT_LOG[n0:]
         return
-    if new:
-        _CENSUS["worst"] = new[0]
+    if new and _CENSUS["worst"] is None:
+        _CENSUS["worst"] = {k: v for k, v in new[0].items()}
     assert not new, "cluster faults observed during the test: " + "; ".join(
         "%s: %s" % (e["what"], E.describe_fault_report(e)) for e in new)
     assert Gn.repeated_steps == r0, "step-wise generation repeated %d steps" % (Gn.repeated_steps - r0)
@@ -124,16 +127,24 @@ def cluster_fault_census(request):
 
 
 def pytest_terminal_summary(terminalreporter):
-    if not _CENSUS["engines"]:
+    try:
+        from music_generator_amd import engine as E
+    except Exception:
         return
-    line = ("cluster exchange census: %d engine readings, waits with polls > 2^20 cycles apart: %d, longest gap between "
-            "two polls of a wait: %d shader cycles (~%.0f us at 2.1 GHz), faults in injection tests: %d, faults elsewhere: %s"
-            % (_CENSUS["engines"], _CENSUS["stalled_waits"], _CENSUS["max_poll_gap_cycles"],
-               _CENSUS["max_poll_gap_cycles"] / 2100.0, _CENSUS["faults_in_injection_tests"],
-               "NONE" if _CENSUS["worst"] is None else repr(_CENSUS["worst"])))
-    terminalreporter.write_line(line)
+    engines = E.CENSUS["engines"] + _CENSUS["live_readings"]
+    if not engines:
+        return
+    stalled = max(E.CENSUS["stalled_waits"], _CENSUS["stalled_waits"])
+    gap = max(E.CENSUS["max_poll_gap_cycles"], _CENSUS["max_poll_gap_cycles"])
+    rec = {"engines": engines, "stalled_waits": stalled, "max_poll_gap_cycles": gap,
+           "faults_in_injection_tests": _CENSUS["faults_in_injection_tests"], "faults_elsewhere": _CENSUS["worst"]}
+    terminalreporter.write_line(
+        "cluster exchange census: %d engines, waits with polls > 2^20 cycles apart: %d, longest gap between two polls of a "
+        "wait: %d shader cycles (~%.0f us at 2.1 GHz; 0 = below the 2^17-cycle recording threshold), faults in injection "
+        "tests: %d, faults elsewhere: %s" % (engines, stalled, gap, gap / 2100.0, rec["faults_in_injection_tests"],
+                                            "NONE" if rec["faults_elsewhere"] is None else repr(rec["faults_elsewhere"])))
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         import json
         with open(os.path.join(out, "cluster_census.json"), "w") as f:
-            json.dump(_CENSUS, f, default=str)
+            json.dump(rec, f, default=str)

@@ -3,7 +3,7 @@
 #   tools/ab.sh base p1s1 ...  -> gpurun_out/ab_<name>.log, summary on stdout ("base" = the in-tree library)
 for v in "$@"; do
   if [ "$v" = base ]; then unset DEEPJ_LIB; else export DEEPJ_LIB=$PWD/music-generator_amd/lib/libdeepj_hip.$v.so; fi
-  timeout -k 10 200 python bench.py --steps 10 --warmup 3 --cpu-sample 0 --gen-steps 0 > gpurun_out/ab_$v.log 2>&1 || { echo "$v FAILED"; tail -3 gpurun_out/ab_$v.log; exit 1; }
+  timeout -k 10 200 python bench.py --steps 20 --warmup 3 --cpu-sample 0 --gen-steps 0 --no-fp32 --scaled-steps 0 > gpurun_out/ab_$v.log 2>&1 || { echo "$v FAILED"; tail -3 gpurun_out/ab_$v.log; exit 1; }
   python - "$v" <<'PY'
 import json, sys
 v = sys.argv[1]
