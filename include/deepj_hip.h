@@ -56,6 +56,9 @@ typedef struct dj_config {
  * DEEPJ_DEBUG_CLUSTER_LATE=1, DEEPJ_FUSE_XW_MIN_TILES=n)
  * are read ONCE, at the first call into the library, as process-wide defaults that are OR-ed with these bits; there
  * is no getenv on the launch path.  dj_env_reload() reads them again (tests that switch kernels inside one process).
+ * dj_env_reload() is for single-threaded test set-up: it rewrites the process defaults without synchronisation, so no
+ * other thread may be inside the library while it runs.  Every bit is honoured PER ENGINE through dj_config.kernel_flags
+ * (the effective flags of a call are passed down to the launchers).
  * A hipGraph captured from these calls keeps the selection in force at capture time.  dj_generate_prepare and
  * dj_generate_step_prepared must see the same flags (the packed-weight layout depends on them): same cfg, and no
  * dj_env_reload() in between. */

@@ -609,7 +609,6 @@ struct WgradArgs {
   float* dW; float* dU;              // fp32, += (atomics)
   const bf16_t* zeros;               // >= 16 zero bytes
   int ntn, ntiles, xcd_map;
-  int sup_a, sup_b;                  // > 0: tiles are dealt in super-tiles of sup_a row tiles x sup_b column tiles (below)
   int64_t rows_per_split;
 };
 constexpr int WG_BK = 32, WG_T = 256, WG_TILE_BYTES = WG_BK * WG_T * 2, WG_STAGE = 2 * WG_TILE_BYTES, WG_NS = 4;
@@ -629,17 +628,7 @@ __global__ __launch_bounds__(512) void lstm_wgrad_bf16_kernel(WgradArgs a) {
     tile = blockIdx.x % a.ntiles;
     split = blockIdx.x / a.ntiles;
   }
-  // With more tiles than one XCD runs at a time (32 compute units: the scaled model has 8 x 16 = 128 per split) the
-  // workgroups that are resident TOGETHER should form a square-ish block of the output: 2 row tiles x 16 column tiles at a
-  // time re-read every dZ column slice 4 times per split (PMC: 83.8 GB per launch against 25.1 GB algorithmic); super-tiles
-  // of 4 x 8 read dZ twice and X / H twice.
-  int rt = tile / a.ntn, ct = tile % a.ntn;
-  if (a.sup_a > 0) {
-    const int per = a.sup_a * a.sup_b, st = tile / per, wi = tile % per, sbn = a.ntn / a.sup_b;
-    rt = (st / sbn) * a.sup_a + wi / a.sup_b;
-    ct = (st % sbn) * a.sup_b + wi % a.sup_b;
-  }
-  const int n0 = ct * WG_T, v0 = rt * WG_T;            // v0: first virtual A column of the tile
+  const int n0 = (tile % a.ntn) * WG_T, v0 = (tile / a.ntn) * WG_T;   // v0: first virtual A column of the tile
   const int64_t ms = (int64_t)split * a.rows_per_split;
   int64_t me = ms + a.rows_per_split;
   if (me > a.M) me = a.M;
@@ -1545,15 +1534,6 @@ int dj_launch_lstm_wgrad(int dtype, int64_t M, int steps, const void* X, int DP,
     a.ntn = N / WG_T;
     int nta = (DP + H + WG_T - 1) / WG_T;
     a.ntiles = a.ntn * nta;
-    a.sup_a = a.sup_b = 0;
-    if (a.ntiles > 32) {                               // super-tiles of 32 = what one XCD holds at a time
-      const int shapes[4][2] = {{4, 8}, {8, 4}, {2, 16}, {16, 2}};
-      for (const auto& sh : shapes)
-        if (nta % sh[0] == 0 && a.ntn % sh[1] == 0) {
-          a.sup_a = sh[0]; a.sup_b = sh[1];
-          break;
-        }
-    }
     int64_t want = (256 + a.ntiles - 1) / a.ntiles;
     want = (want + 7) / 8 * 8;                       // multiple of 8 row splits: one XCD per split residue
     int64_t rps = (M + want - 1) / want;

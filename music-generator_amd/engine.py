@@ -201,7 +201,11 @@ class Engine:
 
     def __del__(self):
         # last look at the fault line: the stall census goes to the module's CENSUS, counts nobody read to FAULT_LOG
+        # (not while the interpreter is shutting down: no HIP calls from a finalizer then)
         try:
+            import sys
+            if sys is None or sys.is_finalizing():
+                return
             rep = self.cluster_fault_report()
             CENSUS["engines"] += 1
             CENSUS["stalled_waits"] = max(CENSUS["stalled_waits"], rep["stalled_waits"])
