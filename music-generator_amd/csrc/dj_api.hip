@@ -477,7 +477,11 @@ int note_axis_forward(const Ctx& c, int64_t wHin, int in_na, int d_out_site, con
 // step are one contiguous 16 KiB block per 256-column tile, which is what the weight-gradient GEMM streams per stage;
 // with row-major dZ its 512-byte pieces at 2 KiB stride were fetched from HBM once per row tile: 1.6x the bytes)
 inline int64_t dz_tile_stride(const Ctx& c, const LstmP& L, int64_t M) {
-  return (c.p.c.dtype == DJ_BF16 && rec_persistent(L.H)) ? M * 256 : 0;
+  if (c.p.c.dtype != DJ_BF16) return 0;
+  // (round 4: the generic-width path too -- at the scaled shape the weight-gradient GEMM read 3.3x its algorithmic bytes
+  // from the row-major dZ; DJ_KF_NO_STEP_EPILOGUE keeps the round-3 layout with the rest of that form)
+  if (!rec_persistent(L.H)) return ((4 * L.H) % 256 == 0 && step_epilogue(c.p.c)) ? M * 256 : 0;
+  return M * 256;
 }
 
 int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int steps, int64_t M, int64_t wX,
@@ -493,7 +497,7 @@ int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int st
                              c.p.c.recurrent_sigmoid, fdx ? c.at(wWp) : nullptr, L.D, fdx ? c.at(wdX) : nullptr, L.DP, c.st));
     } else {
       const void* Uc = dt == DJ_F32 ? (const void*)(c.P + L.U) : (const void*)c.at(wUb);
-      RUN(dj_launch_lstm_step_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), Uc, c.at(wC), c.at(wdH), c.at(wdZ), G + L.b,
+      RUN(dj_launch_lstm_step_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), Uc, c.at(wC), c.at(wdH), c.at(wdZ), cts, G + L.b,
                                   c.at<float>(c.p.w_step), c.p.c.recurrent_sigmoid, c.st));
     }
   }

@@ -1310,7 +1310,7 @@ int dj_launch_gemm_nt_rbs(int dtype, int M, int N, int K, const void* A, int lda
 int dj_launch_gemm_nt_ex(int dtype, int M, int N, int K, const void* A, int lda, int a_rbs, int64_t a_cts, const void* Bt,
                          int ldb, void* C, int ldc, int c_rbs, int c_mode, const float* bias, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  if (a_cts && (dtype != DJ_BF16 || lda != 256 || a_rbs != 1)) return 1008;
+  if (a_cts && (dtype != DJ_BF16 || lda != 256)) return 1008;      // (composes with a row-block stride: per-step views)
   if (a_rbs < 1 || c_rbs < 1 || (c_mode == 2 && c_rbs != 1)) return 1006;
   const int epl = dtype == DJ_F32 ? 4 : 8;
   if ((K % epl) || (lda % epl) || (ldb % epl)) return 1001;
@@ -1368,7 +1368,7 @@ int dj_launch_gemm_nt_ex(int dtype, int M, int N, int K, const void* A, int lda,
     // persistent grid: one workgroup per CU.  XCD-aware schedule when there is enough work:
     // 32 slots per XCD are split into teams of ntn2 workgroups, one A panel per team at a time.
     int grid2, xcd_map = 0;
-    if (ntn2 <= 32 && ntm2 >= 64) {
+    if (ntn2 <= 32 && (ntm2 >= 64 || (32 % ntn2 == 0 && ntm2 >= 8 * (32 / ntn2)))) {   // (.. or exactly enough m-tiles for one per team)
       grid2 = 256;
       xcd_map = 1;
     } else {
@@ -1443,7 +1443,7 @@ static int launch_cell(int M, int N, int K, const bf16_t* A, int lda, int a_rbs,
   }
   const int ntn2 = (N + NT2_BN - 1) / NT2_BN, ntm2 = (M + NT2_BM - 1) / NT2_BM;
   int grid2, xcd_map = 0;
-  if (ntn2 <= 32 && ntm2 >= 64) {
+  if (ntn2 <= 32 && (ntm2 >= 64 || (32 % ntn2 == 0 && ntm2 >= 8 * (32 / ntn2)))) {   // (.. or exactly enough m-tiles for one per team)
     grid2 = 256;
     xcd_map = 1;
   } else {

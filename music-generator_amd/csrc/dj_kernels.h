@@ -150,8 +150,9 @@ int dj_launch_lstm_step_fwd(int dtype, int H, int ntiles, int steps, void* Z, co
 int dj_step_k1p(int DP);
 int dj_launch_lstm_step_fwd_fused(int H, int ntiles, int steps, const void* X, int DP, int D, const void* WU,
                                   const float* bias, void* Z, void* Hs, void* Cs, float* scratch, int sigm, hipStream_t st);
+// dz_cts: 0 = dZ row-major [rows, 4H]; bf16 with 4H % 256 == 0: column-tile-major [4H/256][rows][256], as dj_launch_lstm_bwd
 int dj_launch_lstm_step_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* Uc, const void* Cs,
-                            const void* dH, void* dZ, float* dbias, float* scratch, int sigm, hipStream_t st);
+                            const void* dH, void* dZ, int64_t dz_cts, float* dbias, float* scratch, int sigm, hipStream_t st);
 // dj_elem.hip
 int dj_launch_dense_small(const float* A, int M, int K, const float* W, const float* b, float* C, int N, int act_tanh,
                           hipStream_t st);

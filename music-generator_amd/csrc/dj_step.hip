@@ -214,7 +214,8 @@ template <bool SIGM>
 __global__ __launch_bounds__(256) void step_bwd8_kernel(const bf16_t* __restrict__ Z, const bf16_t* __restrict__ Cs,
                                                         const bf16_t* __restrict__ dH, const float* __restrict__ Rb,
                                                         float* __restrict__ dcs, bf16_t* __restrict__ dZ,
-                                                        float* __restrict__ dbpart, int H, int nrows, int steps, int t) {
+                                                        float* __restrict__ dbpart, int H, int nrows, int steps, int t,
+                                                        int64_t dz_cts) {
   __shared__ float red[32][4 * 64 + 1];
   const int tid = threadIdx.x, r = tid >> 3, cg = tid & 7;
   const int v = blockIdx.y * 32 + r, u = blockIdx.x * 64 + cg * 8;
@@ -256,10 +257,17 @@ __global__ __launch_bounds__(256) void step_bwd8_kernel(const bf16_t* __restrict
       dcc[e] = dc * fg;
     }
     st8f(dcs + (int64_t)v * H + u, dcc);
-    st8(dZ + pr * 4 * H + u, dzi);
-    st8(dZ + pr * 4 * H + H + u, dzf);
-    st8(dZ + pr * 4 * H + 2 * H + u, dzg);
-    st8(dZ + pr * 4 * H + 3 * H + u, dzo);
+    if (dz_cts) {      // column-tile-major dZ [4H/256][rows][256]: what the weight-gradient GEMM streams per stage
+      st8(dZ + (int64_t)(u >> 8) * dz_cts + pr * 256 + (u & 255), dzi);
+      st8(dZ + (int64_t)((H + u) >> 8) * dz_cts + pr * 256 + ((H + u) & 255), dzf);
+      st8(dZ + (int64_t)((2 * H + u) >> 8) * dz_cts + pr * 256 + ((2 * H + u) & 255), dzg);
+      st8(dZ + (int64_t)((3 * H + u) >> 8) * dz_cts + pr * 256 + ((3 * H + u) & 255), dzo);
+    } else {
+      st8(dZ + pr * 4 * H + u, dzi);
+      st8(dZ + pr * 4 * H + H + u, dzf);
+      st8(dZ + pr * 4 * H + 2 * H + u, dzg);
+      st8(dZ + pr * 4 * H + 3 * H + u, dzo);
+    }
   } else {
 #pragma unroll
     for (int e = 0; e < 8; ++e) dzi[e] = dzf[e] = dzg[e] = dzo[e] = 0.f;
@@ -349,7 +357,7 @@ int step_fwd_t(int H, int ntiles, int steps, void* Z, const void* Ut, void* Hs, 
 
 template <typename T>
 int step_bwd_t(int H, int ntiles, int steps, const void* Z, const void* Uc, const void* Cs, const void* dH, void* dZ,
-               float* dbias, float* Rb, float* dcs, int sigm, hipStream_t st) {
+               int64_t dz_cts, float* dbias, float* Rb, float* dcs, int sigm, hipStream_t st) {
   const int dtype = sizeof(T) == 4 ? DJ_F32 : DJ_BF16;
   const int nrows = ntiles * 32;
   const int64_t n = (int64_t)nrows * (H >> 2);
@@ -365,18 +373,21 @@ int step_bwd_t(int H, int ntiles, int steps, const void* Z, const void* Uc, cons
   for (int t = steps - 1; t >= 0; --t) {
     if (t < steps - 1) {
       // recurrent part of dh_t = dz_{t+1} U^T  (Bt = U [H, 4H], k-contiguous)
-      int rc = dj_launch_gemm_nt_rbs(dtype, nrows, H, 4 * H, (const T*)dZ + (int64_t)(t + 1) * 32 * 4 * H, 4 * H, steps,
-                                     Uc, 4 * H, Rb, H, 1, 1, nullptr, st);
+      // (dz_cts: A column-tile-major -- the rows of step t + 1 start (t + 1) * 32 rows into every 256-column tile)
+      int rc = dz_cts ? dj_launch_gemm_nt_ex(dtype, nrows, H, 4 * H, (const T*)dZ + (int64_t)(t + 1) * 32 * 256, 256, steps,
+                                             dz_cts, Uc, 4 * H, Rb, H, 1, 1, nullptr, st)
+                      : dj_launch_gemm_nt_rbs(dtype, nrows, H, 4 * H, (const T*)dZ + (int64_t)(t + 1) * 32 * 4 * H, 4 * H,
+                                              steps, Uc, 4 * H, Rb, H, 1, 1, nullptr, st);
       if (rc) return rc;
     }
     if constexpr (sizeof(T) == 2) {
       const dim3 grid8((unsigned)((H + 63) / 64), (unsigned)((nrows + 31) / 32));
       if (sigm)
         hipLaunchKernelGGL(step_bwd8_kernel<true>, grid8, block, 0, st, (const bf16_t*)Z, (const bf16_t*)Cs,
-                           (const bf16_t*)dH, Rb, dcs, (bf16_t*)dZ, dbpart, H, nrows, steps, t);
+                           (const bf16_t*)dH, Rb, dcs, (bf16_t*)dZ, dbpart, H, nrows, steps, t, dz_cts);
       else
         hipLaunchKernelGGL(step_bwd8_kernel<false>, grid8, block, 0, st, (const bf16_t*)Z, (const bf16_t*)Cs,
-                           (const bf16_t*)dH, Rb, dcs, (bf16_t*)dZ, dbpart, H, nrows, steps, t);
+                           (const bf16_t*)dH, Rb, dcs, (bf16_t*)dZ, dbpart, H, nrows, steps, t, dz_cts);
     } else if (sigm)
       hipLaunchKernelGGL((step_bwd_kernel<T, true>), grid, block, 0, st, (const T*)Z, (const T*)Cs, (const T*)dH, Rb, dcs,
                          (T*)dZ, H, nrows, steps, t);
@@ -436,12 +447,13 @@ int dj_launch_lstm_step_fwd_fused(int H, int ntiles, int steps, const void* X, i
 }
 
 int dj_launch_lstm_step_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* Uc, const void* Cs,
-                            const void* dH, void* dZ, float* dbias, float* scratch, int sigm, hipStream_t st) {
+                            const void* dH, void* dZ, int64_t dz_cts, float* dbias, float* scratch, int sigm, hipStream_t st) {
   if (ntiles <= 0 || steps <= 0) return 0;
   if (H < 32 || (H % 32)) return 1012;
   if ((int64_t)ntiles * 32 * (H >> 2) >= ((int64_t)1 << 31)) return 1014;
   float* Rb = scratch;
   float* dcs = scratch + (int64_t)ntiles * 32 * 4 * H;
-  return dtype == DJ_F32 ? step_bwd_t<float>(H, ntiles, steps, Z, Uc, Cs, dH, dZ, dbias, Rb, dcs, sigm, st)
-                         : step_bwd_t<bf16_t>(H, ntiles, steps, Z, Uc, Cs, dH, dZ, dbias, Rb, dcs, sigm, st);
+  if (dz_cts && (dtype == DJ_F32 || (4 * H) % 256 || dz_cts < (int64_t)ntiles * 32 * steps * 256)) return 1015;
+  return dtype == DJ_F32 ? step_bwd_t<float>(H, ntiles, steps, Z, Uc, Cs, dH, dZ, 0, dbias, Rb, dcs, sigm, st)
+                         : step_bwd_t<bf16_t>(H, ntiles, steps, Z, Uc, Cs, dH, dZ, dz_cts, dbias, Rb, dcs, sigm, st);
 }
