@@ -93,7 +93,10 @@ def category_bytes(cfg, B, T, N, esize):
     out = {k: 0 for k in ("gemm_xw", "gemm_dx", "gemm_dw", "lstm_fwd_time", "lstm_bwd_time", "lstm_fwd_note",
                           "lstm_bwd_note")}
     for axis, H, dims in (("time", Ht, t_in), ("note", Hn, n_in)):
-        s = (1 if esize == 2 else 4) if H in (128, 256) else esize     # persistent kernels only (dj_lstm.hip GateEnc)
+        # 8-bit activated-gate codes: the persistent bf16 kernels (dj_lstm.hip GateEnc) and, since round 4, the generic-width
+        # path with the cell epilogue (dj_common.h dj_gate_code*); fp32 keeps z
+        coded = esize == 2 and (H in (128, 256) or _fused_xw(cfg, 1, H))
+        s = 1 if coded else (4 if H in (128, 256) else esize)
         for d in dims:
             fused = _fused_xw(cfg, d, H)
             out["lstm_fwd_" + axis] += rows * (esize * ((d + 2 * H) if fused else 6 * H) + s * 4 * H)

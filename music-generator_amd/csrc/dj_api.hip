@@ -498,7 +498,7 @@ int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int st
     } else {
       const void* Uc = dt == DJ_F32 ? (const void*)(c.P + L.U) : (const void*)c.at(wUb);
       RUN(dj_launch_lstm_step_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), Uc, c.at(wC), c.at(wdH), c.at(wdZ), cts, G + L.b,
-                                  c.at<float>(c.p.w_step), c.p.c.recurrent_sigmoid, c.st));
+                                  c.at<float>(c.p.w_step), c.p.c.recurrent_sigmoid, step_epilogue(c.p.c), c.st));
     }
   }
   {

@@ -119,6 +119,24 @@ template <bool SIGM> __device__ __forceinline__ float dj_ract_grad(float x, floa
   return dj_hsig_grad(x);
 }
 
+// ---------------------------------------------------------------- 8-bit activated-gate codes (bf16 gate stash)
+// What a bf16 forward sweep leaves for BPTT per gate value: i, f, o in [0, 1] as code = clamp(ceil(254 y), 0, 255), decoded
+// as the interval midpoint (code - 1/2) / 254 clamped to [0, 1] (|error| <= 1/508); codes 0 and 255 are reserved for the
+// SATURATED hard_sigmoid, so its derivative mask (0.2 inside, 0 outside) is exact; g = tanh: code = round(127 g) + 128
+// (|error| <= 1/254).  (dj_lstm.hip GateEnc / GateDec are the persistent kernels' forms of the same code; these serve the
+// generic-width path: the cell epilogue of dj_gemm.hip writes, the gate kernel of dj_step.hip reads.)
+template <bool SIGM> __device__ __forceinline__ float dj_gate_code01(float z, float y) {
+  if constexpr (SIGM) return ceilf(y * 254.f);
+  return ceilf(__builtin_amdgcn_fmed3f(fmaf(z, 50.8f, 127.f), 0.f, 255.f));          // 254 (0.2 z + 0.5)
+}
+__device__ __forceinline__ float dj_gate_code_g(float g) { return floorf(fmaf(g, 127.f, 128.5f)); }
+template <bool SIGM> __device__ __forceinline__ void dj_gate_dec01(float code, float& y, float& dy) {
+  y = __builtin_amdgcn_fmed3f(fmaf(code, 1.f / 254.f, -0.5f / 254.f), 0.f, 1.f);
+  if constexpr (SIGM) dy = y * (1.f - y);
+  else dy = (fabsf(code - 127.5f) < 127.25f) ? 0.2f : 0.f;                            // codes 1 .. 254: the linear part
+}
+__device__ __forceinline__ float dj_gate_dec_g(float code) { return fmaf(code, 1.f / 127.f, -128.f / 127.f); }
+
 // ---------------------------------------------------------------- MFMA wrappers
 // One "k-chunk" of operand fragments per lane:
 //   float : 4 consecutive k-steps of the 32x32x2 op  -> f32x4  (k = 8 per chunk)

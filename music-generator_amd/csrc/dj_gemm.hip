@@ -838,9 +838,10 @@ __device__ __forceinline__ void load4(const float* p, float* x) {
 // ---- forward LSTM cell as the epilogue of a step's GEMM z_t = [x_t | h_{t-1}] [W ; U] (dj_kernels.h CellEpi; scaled
 // model).  One 32 x 32 block of the C^T accumulator: lane (l31, h) holds virtual row `row` = rowb + l31, registers
 // 4 q + e <-> output column colb + 8 q + 4 h + e = gate q of unit 8 (colb / 32) + 4 h + e (gate-interleaved B rows).  The
-// epilogue LOADS only the carry (16 bytes per lane, coalesced): z = acc + bias is rounded to bf16 once -- the value the
-// activations see is the value BPTT reads back from the stash.
-__device__ __forceinline__ float bf16_round(float x) { return dj_to_f32(dj_from_f32<bf16_t>(x)); }
+// epilogue LOADS only the carry (16 bytes per lane, coalesced), and of its stores only h_t (row-major: the next step's A
+// operand) is scattered: the cell-state stash and the gate stash -- the ACTIVATED gates as 8-bit codes (dj_common.h), as
+// the persistent bf16 kernels keep them -- go to the accumulators' own fragment layout, one coalesced 8- / 16-byte store
+// per lane and block.  The forward values themselves are not quantised.
 
 template <bool SIGM>
 __device__ __forceinline__ void cell_fwd_block(const f32x16& a, const CellEpi& ce, const float* __restrict__ bias, int row,
@@ -851,26 +852,31 @@ __device__ __forceinline__ void cell_fwd_block(const f32x16& a, const CellEpi& c
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const float4 bv = *(const float4*)(bias + g * H + u0);
-    z[g][0] = bf16_round(a[4 * g] + bv.x); z[g][1] = bf16_round(a[4 * g + 1] + bv.y);
-    z[g][2] = bf16_round(a[4 * g + 2] + bv.z); z[g][3] = bf16_round(a[4 * g + 3] + bv.w);
+    z[g][0] = a[4 * g] + bv.x; z[g][1] = a[4 * g + 1] + bv.y; z[g][2] = a[4 * g + 2] + bv.z; z[g][3] = a[4 * g + 3] + bv.w;
   }
-  float4* cp = (float4*)ce.carry + (((int64_t)(row >> 5) * (H >> 3) + G) * 64 + lane);
+  // this lane's slot in the FRAGMENT layout [row block][unit group][64 lanes]: carry (16 B), c stash (8 B), gate codes (16 B)
+  const int64_t fb = ((int64_t)(row >> 5) * (H >> 3) + G) * 64 + lane;
+  const int64_t fs = ((int64_t)(row >> 5) * ce.steps * (H >> 3) + G) * 64 + lane;     // the stashes hold every step
+  float4* cp = (float4*)ce.carry + fb;
   float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (!ce.first) cv = *cp;                                    // step 0 starts from c = 0
   float c[4] = {cv.x, cv.y, cv.z, cv.w}, hn[4];
+  uint32_t code[4] = {0u, 0u, 0u, 0u};                        // word g: the four units' codes of gate g
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const float ig = dj_ract<SIGM>(z[0][e]), fg = dj_ract<SIGM>(z[1][e]), gg = dj_tanh(z[2][e]), og = dj_ract<SIGM>(z[3][e]);
     c[e] = fg * c[e] + ig * gg;
     hn[e] = og * dj_tanh(c[e]);
+    code[0] = __builtin_amdgcn_cvt_pk_u8_f32(dj_gate_code01<SIGM>(z[0][e], ig), e, code[0]);
+    code[1] = __builtin_amdgcn_cvt_pk_u8_f32(dj_gate_code01<SIGM>(z[1][e], fg), e, code[1]);
+    code[2] = __builtin_amdgcn_cvt_pk_u8_f32(dj_gate_code_g(gg), e, code[2]);
+    code[3] = __builtin_amdgcn_cvt_pk_u8_f32(dj_gate_code01<SIGM>(z[3][e], og), e, code[3]);
   }
   *cp = make_float4(c[0], c[1], c[2], c[3]);
   store4((bf16_t*)ce.Hs + pr * H + u0, hn[0], hn[1], hn[2], hn[3]);
-  if (ce.Cs) {                                                // training: cell-state and pre-activation stash for BPTT
-    store4((bf16_t*)ce.Cs + pr * H + u0, c[0], c[1], c[2], c[3]);
-    bf16_t* zrow = (bf16_t*)ce.Z + pr * 4 * H + u0;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) store4(zrow + g * H, z[g][0], z[g][1], z[g][2], z[g][3]);
+  if (ce.Cs) {      // training: what BPTT reads back -- c_t (bf16) and the ACTIVATED gates as 8-bit codes, both coalesced
+    *(uint2*)((bf16_t*)ce.Cs + fs * 4) = make_uint2(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]));
+    *(uint4*)((uint8_t*)ce.Z + fs * 16) = make_uint4(code[0], code[1], code[2], code[3]);
   }
 }
 

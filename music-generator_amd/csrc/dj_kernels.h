@@ -75,17 +75,18 @@ struct DenseBatch {
 // gate column g H + 8 G + e of W and U: dj_launch_pack_wu_gates), so that a lane of the C^T accumulator block holds all
 // four gates of 4 units of one row and turns them into c_t, h_t on the spot.  No x W pass, no z round trip, no gate launch.
 // Rows are "all sequences at step t" of the sequence-tiled buffers: virtual row v at physical row ((v >> 5) * steps) * 32
-// + (v & 31) of the pointers below, which stand at step t.  Writes Hs and, when training (Cs != null), Cs and z (the
-// stash BPTT reads), all in their natural layouts; `carry` (c_{t-1}) is fp32 in FRAGMENT layout [rows/32][H/8][64 lanes][4]
+// + (v & 31) of the pointers below, which stand at step t.  Writes Hs (row-major) and, when training (Cs != null), the
+// two stashes BPTT reads (step_bwd8c_kernel); `carry` (c_{t-1}) is fp32 in FRAGMENT layout [rows/32][H/8][64 lanes][4]
 // -- 16 bytes per lane, coalesced; only this epilogue touches it.
 struct CellEpi {
   int H, steps, sigm, first;      // first: step 0 (c_{-1} = 0, carry not read)
   int K1, K1p, lda2;
   const void* A2;                 // h_{t-1} rows [.., H] (same row-block stride as A) or null
   float* carry;
-  void* Z;                        // bf16 [.., 4H]: final pre-activations out (training only)
-  void* Hs;                       // h_t out [.., H]
-  void* Cs;                       // c_t out [.., H] or null (inference)
+  void* Z;                        // gate stash out (training only): 8-bit activated-gate codes, FRAGMENT layout
+                                  //   [row block of the step][H/8][64 lanes][16 B = 4 gates x 4 units] (dj_common.h codes)
+  void* Hs;                       // h_t out [.., H] row-major
+  void* Cs;                       // c_t stash out, bf16 in the same fragment layout (8 B per lane), or null (inference)
 };
 // dj_gemm.hip
 // A [M, K1] (lda, row-block stride a_rbs) and ce.A2 [M, H] x Bt [4H, K1p + H]^T (ldb), bias [4H] in natural gate order
@@ -151,8 +152,11 @@ int dj_step_k1p(int DP);
 int dj_launch_lstm_step_fwd_fused(int H, int ntiles, int steps, const void* X, int DP, int D, const void* WU,
                                   const float* bias, void* Z, void* Hs, void* Cs, float* scratch, int sigm, hipStream_t st);
 // dz_cts: 0 = dZ row-major [rows, 4H]; bf16 with 4H % 256 == 0: column-tile-major [4H/256][rows][256], as dj_launch_lstm_bwd
+// codes: Z / Cs are the stashes of dj_launch_lstm_step_fwd_fused (8-bit gate codes, bf16 c, fragment layout) instead of
+// row-major z / c in the operand dtype
 int dj_launch_lstm_step_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* Uc, const void* Cs,
-                            const void* dH, void* dZ, int64_t dz_cts, float* dbias, float* scratch, int sigm, hipStream_t st);
+                            const void* dH, void* dZ, int64_t dz_cts, float* dbias, float* scratch, int sigm, int codes,
+                            hipStream_t st);
 // dj_elem.hip
 int dj_launch_dense_small(const float* A, int M, int K, const float* W, const float* b, float* C, int N, int act_tanh,
                           hipStream_t st);

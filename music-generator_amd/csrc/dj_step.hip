@@ -292,6 +292,104 @@ __global__ __launch_bounds__(256) void step_bwd8_kernel(const bf16_t* __restrict
   }
 }
 
+// The same cell for a forward sweep that ran as GEMMs with the cell epilogue (dj_gemm.hip cell_fwd_block): the gate stash
+// holds the ACTIVATED gates as 8-bit codes and the cell-state stash c_t as bf16, both in the accumulators' fragment layout
+// [row block of a step][unit group of 8][64 lanes] (lane = 32 * (unit >> 2 & 1) + sequence & 31; 16 / 8 bytes per lane) --
+// half the stash bytes of the z form, no transcendental per gate, and every access of a thread is 8 or 16 contiguous bytes
+// of a 0.5 / 1 KiB block.  Same geometry, outputs and bias-gradient partials as step_bwd8_kernel.
+template <bool SIGM>
+__global__ __launch_bounds__(256) void step_bwd8c_kernel(const uint8_t* __restrict__ Zc, const bf16_t* __restrict__ Cf,
+                                                         const bf16_t* __restrict__ dH, const float* __restrict__ Rb,
+                                                         float* __restrict__ dcs, bf16_t* __restrict__ dZ,
+                                                         float* __restrict__ dbpart, int H, int nrows, int steps, int t,
+                                                         int64_t dz_cts) {
+  __shared__ float red[32][4 * 64 + 1];
+  const int tid = threadIdx.x, r = tid >> 3, cg = tid & 7;
+  const int v = blockIdx.y * 32 + r, u = blockIdx.x * 64 + cg * 8;
+  const bool live = v < nrows && u < H;
+  float dzi[8], dzf[8], dzg[8], dzo[8];
+  if (live) {
+    const int64_t pr = step_row(v, steps, t);
+    // fragment slots of this thread's units u .. u + 3 (lane l31) and u + 4 .. u + 7 (lane 32 + l31) at steps t and t - 1
+    const int64_t fs = (((int64_t)(v >> 5) * steps + t) * (H >> 3) + (u >> 3)) * 64 + (v & 31);
+    const uint4 q0 = *(const uint4*)(Zc + fs * 16), q1 = *(const uint4*)(Zc + (fs + 32) * 16);
+    const uint2 c0 = *(const uint2*)(Cf + fs * 4), c1 = *(const uint2*)(Cf + (fs + 32) * 4);
+    uint2 p0 = make_uint2(0u, 0u), p1 = make_uint2(0u, 0u);
+    if (t > 0) {
+      const int64_t fp = fs - (int64_t)(H >> 3) * 64;
+      p0 = *(const uint2*)(Cf + fp * 4);
+      p1 = *(const uint2*)(Cf + (fp + 32) * 4);
+    }
+    const uint32_t cw[4] = {c0.x, c0.y, c1.x, c1.y}, pw[4] = {p0.x, p0.y, p1.x, p1.y};
+    float ct[8], cp[8], dh[8], dcc[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ct[2 * i] = __uint_as_float(cw[i] << 16); ct[2 * i + 1] = __uint_as_float(cw[i] & 0xFFFF0000u);
+      cp[2 * i] = __uint_as_float(pw[i] << 16); cp[2 * i + 1] = __uint_as_float(pw[i] & 0xFFFF0000u);
+    }
+    ld8(dH + pr * H + u, dh);
+    if (t < steps - 1) {
+      float rr[8];
+      ld8f(Rb + (int64_t)v * H + u, rr);
+      ld8f(dcs + (int64_t)v * H + u, dcc);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dh[e] += rr[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dcc[e] = 0.f;
+    }
+    const uint32_t gw[2][4] = {{q0.x, q0.y, q0.z, q0.w}, {q1.x, q1.y, q1.z, q1.w}};     // [half][gate]: 4 codes each
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int hh = e >> 2, sh = 8 * (e & 3);
+      float ig, fg, og, di, df, dO;
+      dj_gate_dec01<SIGM>((float)((gw[hh][0] >> sh) & 0xFFu), ig, di);
+      dj_gate_dec01<SIGM>((float)((gw[hh][1] >> sh) & 0xFFu), fg, df);
+      const float gg = dj_gate_dec_g((float)((gw[hh][2] >> sh) & 0xFFu));
+      dj_gate_dec01<SIGM>((float)((gw[hh][3] >> sh) & 0xFFu), og, dO);
+      const float tc = dj_tanh(ct[e]);
+      const float dc = dcc[e] + dh[e] * og * (1.f - tc * tc);
+      dzo[e] = dh[e] * tc * dO;
+      dzi[e] = dc * gg * di;
+      dzf[e] = dc * cp[e] * df;
+      dzg[e] = dc * ig * (1.f - gg * gg);
+      dcc[e] = dc * fg;
+    }
+    st8f(dcs + (int64_t)v * H + u, dcc);
+    if (dz_cts) {
+      st8(dZ + (int64_t)(u >> 8) * dz_cts + pr * 256 + (u & 255), dzi);
+      st8(dZ + (int64_t)((H + u) >> 8) * dz_cts + pr * 256 + ((H + u) & 255), dzf);
+      st8(dZ + (int64_t)((2 * H + u) >> 8) * dz_cts + pr * 256 + ((2 * H + u) & 255), dzg);
+      st8(dZ + (int64_t)((3 * H + u) >> 8) * dz_cts + pr * 256 + ((3 * H + u) & 255), dzo);
+    } else {
+      st8(dZ + pr * 4 * H + u, dzi);
+      st8(dZ + pr * 4 * H + H + u, dzf);
+      st8(dZ + pr * 4 * H + 2 * H + u, dzg);
+      st8(dZ + pr * 4 * H + 3 * H + u, dzo);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dzi[e] = dzf[e] = dzg[e] = dzo[e] = 0.f;
+  }
+  if (!dbpart) return;                       // uniform
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[r][0 * 64 + cg * 8 + e] = dj_to_f32(dj_from_f32<bf16_t>(dzi[e]));
+    red[r][1 * 64 + cg * 8 + e] = dj_to_f32(dj_from_f32<bf16_t>(dzf[e]));
+    red[r][2 * 64 + cg * 8 + e] = dj_to_f32(dj_from_f32<bf16_t>(dzg[e]));
+    red[r][3 * 64 + cg * 8 + e] = dj_to_f32(dj_from_f32<bf16_t>(dzo[e]));
+  }
+  __syncthreads();
+  const int g = tid >> 6, uu = tid & 63;
+  if (blockIdx.x * 64 + uu < H) {
+    float sum = 0.f;
+#pragma unroll 8
+    for (int rr = 0; rr < 32; ++rr) sum += red[rr][g * 64 + uu];
+    float* dst = dbpart + (int64_t)blockIdx.y * 4 * H + g * H + blockIdx.x * 64 + uu;
+    *dst += sum;
+  }
+}
+
 // dbias[c] += sum over row blocks of dbpart[rb][c]
 __global__ __launch_bounds__(256) void dbpart_fold_kernel(const float* __restrict__ dbpart, int nrb, int cols,
                                                           float* __restrict__ out) {
@@ -357,7 +455,7 @@ int step_fwd_t(int H, int ntiles, int steps, void* Z, const void* Ut, void* Hs, 
 
 template <typename T>
 int step_bwd_t(int H, int ntiles, int steps, const void* Z, const void* Uc, const void* Cs, const void* dH, void* dZ,
-               int64_t dz_cts, float* dbias, float* Rb, float* dcs, int sigm, hipStream_t st) {
+               int64_t dz_cts, float* dbias, float* Rb, float* dcs, int sigm, bool codes, hipStream_t st) {
   const int dtype = sizeof(T) == 4 ? DJ_F32 : DJ_BF16;
   const int nrows = ntiles * 32;
   const int64_t n = (int64_t)nrows * (H >> 2);
@@ -382,7 +480,14 @@ int step_bwd_t(int H, int ntiles, int steps, const void* Z, const void* Uc, cons
     }
     if constexpr (sizeof(T) == 2) {
       const dim3 grid8((unsigned)((H + 63) / 64), (unsigned)((nrows + 31) / 32));
-      if (sigm)
+      if (codes) {      // stashes of the cell-epilogue forward: 8-bit gate codes + bf16 c, fragment layout
+        if (sigm)
+          hipLaunchKernelGGL(step_bwd8c_kernel<true>, grid8, block, 0, st, (const uint8_t*)Z, (const bf16_t*)Cs,
+                             (const bf16_t*)dH, Rb, dcs, (bf16_t*)dZ, dbpart, H, nrows, steps, t, dz_cts);
+        else
+          hipLaunchKernelGGL(step_bwd8c_kernel<false>, grid8, block, 0, st, (const uint8_t*)Z, (const bf16_t*)Cs,
+                             (const bf16_t*)dH, Rb, dcs, (bf16_t*)dZ, dbpart, H, nrows, steps, t, dz_cts);
+      } else if (sigm)
         hipLaunchKernelGGL(step_bwd8_kernel<true>, grid8, block, 0, st, (const bf16_t*)Z, (const bf16_t*)Cs,
                            (const bf16_t*)dH, Rb, dcs, (bf16_t*)dZ, dbpart, H, nrows, steps, t, dz_cts);
       else
@@ -437,7 +542,7 @@ int dj_launch_lstm_step_fwd_fused(int H, int ntiles, int steps, const void* X, i
   for (int t = 0; t < steps; ++t) {
     ce.first = t == 0;
     ce.A2 = t > 0 ? (const bf16_t*)Hs + (int64_t)(t - 1) * 32 * H : nullptr;
-    ce.Z = Z ? (bf16_t*)Z + (int64_t)t * 32 * 4 * H : (bf16_t*)nullptr;
+    ce.Z = Z ? (uint8_t*)Z + (int64_t)t * 32 * 4 * H : (uint8_t*)nullptr;      // gate codes: one byte per gate value
     ce.Hs = (bf16_t*)Hs + (int64_t)t * 32 * H;
     ce.Cs = Cs ? (bf16_t*)Cs + (int64_t)t * 32 * H : (bf16_t*)nullptr;
     const int rc = dj_launch_gemm_nt_cell(nrows, (const bf16_t*)X + (int64_t)t * 32 * DP, DP, steps, WU, K1p + H, ce, bias, st);
@@ -447,13 +552,15 @@ int dj_launch_lstm_step_fwd_fused(int H, int ntiles, int steps, const void* X, i
 }
 
 int dj_launch_lstm_step_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* Uc, const void* Cs,
-                            const void* dH, void* dZ, int64_t dz_cts, float* dbias, float* scratch, int sigm, hipStream_t st) {
+                            const void* dH, void* dZ, int64_t dz_cts, float* dbias, float* scratch, int sigm, int codes,
+                            hipStream_t st) {
   if (ntiles <= 0 || steps <= 0) return 0;
   if (H < 32 || (H % 32)) return 1012;
   if ((int64_t)ntiles * 32 * (H >> 2) >= ((int64_t)1 << 31)) return 1014;
   float* Rb = scratch;
   float* dcs = scratch + (int64_t)ntiles * 32 * 4 * H;
   if (dz_cts && (dtype == DJ_F32 || (4 * H) % 256 || dz_cts < (int64_t)ntiles * 32 * steps * 256)) return 1015;
-  return dtype == DJ_F32 ? step_bwd_t<float>(H, ntiles, steps, Z, Uc, Cs, dH, dZ, 0, dbias, Rb, dcs, sigm, st)
-                         : step_bwd_t<bf16_t>(H, ntiles, steps, Z, Uc, Cs, dH, dZ, dz_cts, dbias, Rb, dcs, sigm, st);
+  if (codes && dtype == DJ_F32) return 1015;
+  return dtype == DJ_F32 ? step_bwd_t<float>(H, ntiles, steps, Z, Uc, Cs, dH, dZ, 0, dbias, Rb, dcs, sigm, false, st)
+                         : step_bwd_t<bf16_t>(H, ntiles, steps, Z, Uc, Cs, dH, dZ, dz_cts, dbias, Rb, dcs, sigm, codes != 0, st);
 }
