@@ -16,6 +16,9 @@
 // registers); z, c, h stashes have the operand dtype.  bf16 FORWARD (round 4, dj_launch_lstm_step_fwd_fused): ONE launch
 // per step and nothing else -- z_t = [x_t | h_{t-1}] [W ; U] + b as one product over K = DP + H whose epilogue IS the
 // cell (dj_kernels.h CellEpi, dj_gemm.hip cell_fwd_block): no x W pass over the layer, no z round trip, no gate launch.
+// Its training stash is the four ACTIVATED gates as 8-bit codes (dj_common.h dj_gate_code01 / dj_gate_code_g, the persistent
+// kernels' quantiser) and c_t as bf16, both in the accumulators' fragment layout (coalesced 16- / 8-byte stores); BPTT's
+// gate kernel for that stash is step_bwd8c_kernel.
 // DJ_KF_NO_STEP_EPILOGUE keeps the round-3 form: x W as one GEMM, then per step a GEMM that ACCUMULATES h_{t-1} U into
 // the stash rows of z_t in its epilogue (c_mode 3) and a 16-byte gate kernel.  bf16 BPTT: one GEMM (fp32 r out) and one
 // gate kernel per step (the cell as the BPTT GEMM's epilogue was built and measured 2x slower).
