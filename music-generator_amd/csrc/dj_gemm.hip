@@ -835,6 +835,39 @@ __device__ __forceinline__ void load4(const float* p, float* x) {
   x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
 }
 
+// v_permlane32_swap: lanes 32..63 of `a` trade places with lanes 0..31 of `b` (gfx950).  After it a lane of the lower half
+// holds (own a, the upper partner's a) and a lane of the upper half (the lower partner's b, own b).
+__device__ __forceinline__ void half_swap(uint32_t& a, uint32_t& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+// Row-major bf16 store of one 32 x 32 block of the C^T accumulator.  Lane (l31, h) holds row l31, columns 8 g + 4 h + e: four
+// 8-byte pieces, 32 bytes apart.  A store instruction costs the memory pipe per LANE, not per byte (section 8 of DESIGN.md:
+// a wave's scattered 8-byte store took as long as a coalesced 16-byte one), so the two halves of the wave first trade
+// pieces -- the lower half keeps g = 0, 1 and receives the partner's, the upper half g = 2, 3 -- and every lane then owns
+// columns [16 h, 16 h + 16) of its row: two 16-byte stores instead of four 8-byte ones.  All 64 lanes must call (the
+// swap); `ok` guards the stores.  `p` = this lane's row + the block's first column, 16-byte aligned.
+__device__ __forceinline__ void store_block_rows16(bf16_t* p, const f32x16& a, const float* __restrict__ bias_blk, int h,
+                                                   bool ok) {
+  uint2 r[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias_blk) bv = *(const float4*)(bias_blk + 8 * g + 4 * h);
+    r[g] = make_uint2(pack_bf16x2(a[4 * g] + bv.x, a[4 * g + 1] + bv.y), pack_bf16x2(a[4 * g + 2] + bv.z, a[4 * g + 3] + bv.w));
+  }
+  half_swap(r[0].x, r[2].x);
+  half_swap(r[0].y, r[2].y);
+  half_swap(r[1].x, r[3].x);
+  half_swap(r[1].y, r[3].y);
+  if (ok) {
+    uint4* q = (uint4*)(p + 16 * h);
+    q[0] = make_uint4(r[0].x, r[0].y, r[2].x, r[2].y);
+    q[1] = make_uint4(r[1].x, r[1].y, r[3].x, r[3].y);
+  }
+}
+
 // ---- forward LSTM cell as the epilogue of a step's GEMM z_t = [x_t | h_{t-1}] [W ; U] (dj_kernels.h CellEpi; scaled
 // model).  One 32 x 32 block of the C^T accumulator: lane (l31, h) holds virtual row `row` = rowb + l31, registers
 // 4 q + e <-> output column colb + 8 q + 4 h + e = gate q of unit 8 (colb / 32) + 4 h + e (gate-interleaved B rows).  The
@@ -844,7 +877,7 @@ __device__ __forceinline__ void load4(const float* p, float* x) {
 // per lane and block.  The forward values themselves are not quantised.
 
 template <bool SIGM>
-__device__ __forceinline__ void cell_fwd_block(const f32x16& a, const CellEpi& ce, const float* __restrict__ bias, int row,
+__device__ __forceinline__ uint2 cell_fwd_block(const f32x16& a, const CellEpi& ce, const float* __restrict__ bias, int row,
                                                int colb, int lane, int h) {
   const int H = ce.H, G = colb >> 5, u0 = 8 * G + 4 * h;
   const int64_t pr = rbs_row(row, ce.steps);
@@ -873,18 +906,38 @@ __device__ __forceinline__ void cell_fwd_block(const f32x16& a, const CellEpi& c
     code[3] = __builtin_amdgcn_cvt_pk_u8_f32(dj_gate_code01<SIGM>(z[3][e], og), e, code[3]);
   }
   *cp = make_float4(c[0], c[1], c[2], c[3]);
-  store4((bf16_t*)ce.Hs + pr * H + u0, hn[0], hn[1], hn[2], hn[3]);
   if (ce.Cs) {      // training: what BPTT reads back -- c_t (bf16) and the ACTIVATED gates as 8-bit codes, both coalesced
     *(uint2*)((bf16_t*)ce.Cs + fs * 4) = make_uint2(pack_bf16x2(c[0], c[1]), pack_bf16x2(c[2], c[3]));
     *(uint4*)((uint8_t*)ce.Z + fs * 16) = make_uint4(code[0], code[1], code[2], code[3]);
   }
+  return make_uint2(pack_bf16x2(hn[0], hn[1]), pack_bf16x2(hn[2], hn[3]));     // h_t of units u0 .. u0 + 3: stored by the caller
 }
 
 template <int EPI>
-__device__ __forceinline__ void cell_block(const f32x16& a, const CellEpi& ce, const float* bias, int row, int colb, int lane,
-                                           int h) {
-  if constexpr (EPI == 1) cell_fwd_block<false>(a, ce, bias, row, colb, lane, h);
-  if constexpr (EPI == 2) cell_fwd_block<true>(a, ce, bias, row, colb, lane, h);
+__device__ __forceinline__ uint2 cell_block(const f32x16& a, const CellEpi& ce, const float* bias, int row, int colb, int lane,
+                                            int h) {
+  if constexpr (EPI == 1) return cell_fwd_block<false>(a, ce, bias, row, colb, lane, h);
+  if constexpr (EPI == 2) return cell_fwd_block<true>(a, ce, bias, row, colb, lane, h);
+  return make_uint2(0u, 0u);
+}
+// The cells of a wave's two column blocks (unit groups G, G + 1) of one row block, and h_t of both: a lane of block j holds
+// units 4 h .. 4 h + 3 of group G + j (8 bytes); after one swap per word the lower half of the wave owns all 8 units of
+// group G and the upper half those of G + 1 -- one 16-byte store per lane into the row-major h (the next step's A operand)
+template <int EPI>
+__device__ __forceinline__ void cell_block_pair(const f32x16& a0, const f32x16& a1, const CellEpi& ce, const float* bias,
+                                                int row, int M, int colb, int N, int lane, int h) {
+  const bool rok = row < M, two = colb + 32 < N;              // `two` is wave-uniform
+  uint2 h0 = make_uint2(0u, 0u), h1 = h0;
+  if (rok && colb < N) h0 = cell_block<EPI>(a0, ce, bias, row, colb, lane, h);
+  if (rok && two) h1 = cell_block<EPI>(a1, ce, bias, row, colb + 32, lane, h);
+  bf16_t* hrow = (bf16_t*)ce.Hs + rbs_row(row, ce.steps) * ce.H + 8 * (colb >> 5);
+  if (two) {
+    half_swap(h0.x, h1.x);
+    half_swap(h0.y, h1.y);
+    if (rok) *(uint4*)(hrow + 8 * h) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  } else if (rok && colb < N) {
+    *(uint2*)(hrow + 4 * h) = h0;
+  }
 }
 
 template <typename TC, bool CFRAG, int EPI = 0>
@@ -898,6 +951,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
   const int nk = (K + NT2_BK - 1) / NT2_BK;
+  // row-major bf16 output whose rows take 16-byte stores (store_block_rows16); not for the accumulating epilogue
+  const bool vec16 = !c_acc && (ldc & 7) == 0 && (((uintptr_t)C | (uintptr_t)bias) & 15) == 0;
   // tile schedule of this persistent workgroup: tile(tl) = (mt0 + tl*mstride, nt)
   int nt, mt0, mstride, my_tiles;
   if (xcd_map) {
@@ -1024,7 +1079,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
         for (int j = 0; j < 2; ++j) {
           const int colb = n0 + wc * 64 + j * 32, rowb = m0 + wr * 64 + i * 32;
           if constexpr (EPI != 0) {
-            if (rowb + l31 < M && colb < N) cell_block<EPI>(acc[i][j], ce, bias, rowb + l31, colb, lane, h);
+            if (j == 0) cell_block_pair<EPI>(acc[i][0], acc[i][1], ce, bias, rowb + l31, M, colb, N, lane, h);
           } else if constexpr (CFRAG) {
             const int col = colb + l31;
             if (col < N && rowb < M) {
@@ -1034,6 +1089,11 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_dma_kernel(int M, int N, int
               for (int r = 0; r < 16; ++r) x[r] = acc[i][j][r] + bv;
               store_frag(C + (((int64_t)(rowb >> 5) * (N >> 5) + (colb >> 5)) * 64 + lane) * 16, x);
             }
+          } else if (sizeof(TC) == 2 && vec16 && colb + 32 <= N) {     // wave-uniform
+            const int row = rowb + l31;
+            if (rowb < M)
+              store_block_rows16((bf16_t*)C + rbs_row(row < M ? row : rowb, c_rbs) * ldc + colb, acc[i][j],
+                                 bias ? bias + colb : nullptr, h, row < M);
           } else {
             const int row = rowb + l31;
             if (row < M && colb < N) {
@@ -1091,6 +1151,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, in
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 2, wc = w & 3;
   const int nk = (K + NT3_BK - 1) / NT3_BK;
+  // row-major bf16 output whose rows take 16-byte stores (store_block_rows16); not for the accumulating epilogue
+  const bool vec16 = !c_acc && (ldc & 7) == 0 && (((uintptr_t)C | (uintptr_t)bias) & 15) == 0;
   // this workgroup's tiles: q = slot, slot + slots, ... over the (m-tile, n-tile) pairs of its XCD
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = (int)(gridDim.x >> 3);
   const int mt_xcd = ntm > xcd ? (ntm - xcd + 7) / 8 : 0;       // m-tiles xcd, xcd+8, ...
@@ -1256,7 +1318,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, in
         for (int j = 0; j < 2; ++j) {
           const int colb = n0 + wc * 64 + j * 32, rowb = m0 + wr * 128 + i * 32;
           if constexpr (EPI != 0) {
-            if (rowb + l31 < M && colb < N) cell_block<EPI>(acc[i][j], ce, bias, rowb + l31, colb, lane, h);
+            if (j == 0) cell_block_pair<EPI>(acc[i][0], acc[i][1], ce, bias, rowb + l31, M, colb, N, lane, h);
           } else if constexpr (CFRAG) {
             const int col = colb + l31;
             if (col < N && rowb < M) {
@@ -1266,6 +1328,11 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_wide_kernel(int M, int N, in
               for (int r = 0; r < 16; ++r) x[r] = acc[i][j][r] + bv;
               store_frag(C + (((int64_t)(rowb >> 5) * (N >> 5) + (colb >> 5)) * 64 + lane) * 16, x);
             }
+          } else if (sizeof(TC) == 2 && vec16 && colb + 32 <= N) {     // wave-uniform
+            const int row = rowb + l31;
+            if (rowb < M)
+              store_block_rows16((bf16_t*)C + rbs_row(row < M ? row : rowb, c_rbs) * ldc + colb, acc[i][j],
+                                 bias ? bias + colb : nullptr, h, row < M);
           } else {
             const int row = rowb + l31;
             if (row < M && colb < N) {

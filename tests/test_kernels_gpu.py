@@ -135,6 +135,14 @@ def test_gemm_nt(gpu_device, dtype, M, N, K):
                                        L.ptr(bias.to(gpu_device)), _st()), "gemm_nt tiled A")
         assert torch.equal(Ct, Cd)
     if dtype == "bf16":
+        # the epilogue writes rows with 16-byte stores when C, bias and ldc allow it (store_block_rows16: the two halves of a
+        # wave trade pieces); a C that is only 8-byte aligned takes the 8-byte path: same values, nothing outside [M, N]
+        buf = torch.zeros(M * ldc + 12, dtype=Ad.dtype, device=gpu_device)
+        L.check(lib.dj_gemm_nt(DT[dtype], M, N, K, L.ptr(Ad), K, L.ptr(Bd), K, L.ptr(buf) + 8, ldc, 0,
+                               L.ptr(bias.to(gpu_device)), _st()), "gemm_nt, C 8-byte aligned")
+        assert torch.equal(buf[4:4 + M * ldc].view(M, ldc), Cd)
+        assert float(buf[:4].abs().max()) == 0.0 and float(buf[4 + M * ldc:].abs().max()) == 0.0
+    if dtype == "bf16":
         # c_mode 3: C += A Bt^T + bias in place (the per-step recurrent product of the scaled model's forward sweep)
         C0 = _op(torch.randn(M, ldc, generator=g), dtype)
         Ca = C0.clone().to(gpu_device)
