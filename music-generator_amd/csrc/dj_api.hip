@@ -233,8 +233,10 @@ EnvDefaults read_env() {
   if (off("DEEPJ_FUSE_DX")) d.flags |= DJ_KF_NO_FUSE_DX;
   if (off("DEEPJ_GEN_KSPLIT")) d.flags |= DJ_KF_NO_GEN_KSPLIT;
   if (off("DEEPJ_STEP_EPILOGUE")) d.flags |= DJ_KF_NO_STEP_EPILOGUE;
+  if (off("DEEPJ_TAGGED_EXCHANGE")) d.flags |= DJ_KF_COUNTED_EXCHANGE;
   if (on("DEEPJ_DEBUG_CLUSTER_FAULT")) d.flags |= DJ_KF_DEBUG_CLUSTER_FAULT;
   if (on("DEEPJ_DEBUG_CLUSTER_LATE")) d.flags |= DJ_KF_DEBUG_CLUSTER_LATE;
+  if (on("DEEPJ_DEBUG_CLUSTER_MUTE")) d.flags |= DJ_KF_DEBUG_CLUSTER_MUTE;
   if (const char* e = getenv("DEEPJ_FUSE_XW_MIN_TILES")) d.fuse_xw_min_tiles = atoll(e);
   return d;
 }

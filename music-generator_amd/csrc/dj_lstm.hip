@@ -632,8 +632,10 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
 // "wave s" of the per-tile kernel: 4*NKX + 64 KiB) stay in LDS for the whole sweep; wave w multiplies the 32
 // rows of tile w, [x_t | h_{t-1}], with them, so the cell update stays lane-local.  Per step a workgroup now
 // reads 8 x (16 KiB x + 16 KiB h) instead of 1 MiB of weights.  Every member writes its 32-unit slice of
-// h_t; a per-cluster counter in L2 closes the step.  The x_t W half does not depend on the exchange and runs
-// before the wait.
+// h_t into a two-slot ring in L2.  In the training sweep (lstm_fwd_cluster_kernel) the slices ANNOUNCE THEMSELVES by a
+// tag in a spare exponent bit ("TAGGED exchange" below: round 4; 2.56 -> 2.38 ms per step of the baseline shape);
+// in the inference pair and under DJ_KF_COUNTED_EXCHANGE a per-cluster counter in L2 closes the step (acknowledged
+// stores, workgroup barrier, atomic, poll).  The x_t W half does not depend on the exchange and runs before the wait.
 //  * x rows are fetched as full 128-byte lines (8 lanes per row) and turned into A fragments through a 4 KiB
 //    LDS tile per wave, 64 columns per round (fragments read straight from the rows are 32 segments of 32 bytes
 //    per instruction).
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
 //                     wait ("bounded exchange waits" below)
 //     [.., +8 MiB)    hx: [tile][step parity][k-chunk][lane] x 16 bytes
 // Coherence: the members of a cluster must run on ONE XCD, whose L2 is then the coherence point for their h slices
-// (stores acknowledged before the counter moves, exchange loads bypass L1 with sc1).  Round-robin dispatch puts
+// (counted protocol: stores acknowledged before the counter moves; both: exchange loads bypass L1 with sc1).  Round-robin dispatch puts
 // blocks b and b + 8 on one XCD; HIP does not promise it, so it is VERIFIED per launch: every member publishes its
 // hardware XCC id in round 0 and every wave compares the eight of its cluster.  A mismatch, like an expired wait
 // (grid not co-resident), poisons the tile's cell state with NaN and is counted -- never a silent wrong answer,
@@ -670,6 +672,21 @@ __device__ __forceinline__ uint4 ld_sc1(const uint4* p) {
 }
 
 template <int NR> struct ClXRegs { uint4 v[NR][4]; };
+// A 16-byte piece of the row-major h_t.  Nothing in the launch reads these rows again (the exchange has its own copy), so
+// they go out NON-TEMPORAL like the stashes: streamed through an XCD's L2 at 0.5 GB per launch they otherwise push the
+// exchange ring out before its slots are overwritten (tools/l2_writeback.hip: an overwritten L2-resident line costs no
+// fabric write at all).  `keep`: the rows are the input of the upper layer of a pair, which reads them from this L2.
+__device__ __forceinline__ void cl_store_h(bf16_t* p, const uint4& v, bool keep) {
+  if (keep) {
+    *(uint4*)p = v;
+  } else {
+    __builtin_nontemporal_store(v.x, (unsigned*)p);
+    __builtin_nontemporal_store(v.y, (unsigned*)p + 1);
+    __builtin_nontemporal_store(v.z, (unsigned*)p + 2);
+    __builtin_nontemporal_store(v.w, (unsigned*)p + 3);
+  }
+}
+
 // rows r8, r8+8, r8+16, r8+24 of a 32-row block, 16 bytes at column 64 r + 8 xc each (zero past DP), rounds R0..R1-1
 template <int NR, int R0, int R1>
 __device__ __forceinline__ void cl_load_x(ClXRegs<NR>& q, const bf16_t* xb, int DP, int xc) {
@@ -689,7 +706,8 @@ __device__ __forceinline__ void cl_load_x(ClXRegs<NR>& q, const bf16_t* xb, int 
 //   [4] waits that saw two consecutive polls more than CL_GAP_STALL cycles apart   } stall census: cumulative, never
 //   [5] the longest poll-to-poll gap seen, in units of 1024 shader cycles          } reset by the fault census
 //   [8] 1 = words 9..20 describe the FIRST expired wait since the host last took the census:
-//       [9] who (kind << 24 | cluster << 12 | member << 8 | wave; kind 1 = bf16 sweep, 2 = cooperative body, 3 = fp32,
+//       [9] who (kind << 24 | cluster << 12 | member << 8 | wave; kind 1 = bf16 sweep, 2 = cooperative body, 3 = fp32, 4 = bf16 sweep waiting for TAGGED h
+//       fragments ([11] = fragments that had arrived, [12] = 16),
 //       5 / 6 = pair / two-tile BPTT experiments (tools/); bit 28 = the wait was for the PRODUCING layer's counter),
 //       [10] step, [11] counter value seen last, [12] target, [13] polls made, [14..15] shader cycles from the first poll
 //       to the last (64 bit), [16] longest poll-to-poll gap in cycles (saturating), [17] hardware XCC id + 1
@@ -708,11 +726,39 @@ __device__ __forceinline__ void cl_load_x(ClXRegs<NR>& q, const bf16_t* xb, int 
 // arriving, so no partner stalls on it).  A faulted launch therefore costs ONE bound, not one per remaining step.
 constexpr int CL_POISON = 1 << 30;
 constexpr unsigned CL_WAIT_POLLS = 1u << 19;
+constexpr unsigned CL_WAIT_POLLS_TAGGED = 1u << 17;    // a tagged poll (up to 16 fragment loads, every wave of the cluster
+                                                       // at it) measured 1,660 cycles: again ~0.1 s of polling
 constexpr unsigned CL_GAP_NOTE = 1u << 17, CL_GAP_STALL = 1u << 20;   // ~60 us / ~0.5 ms at 2.1 GHz
 enum { CLF_EXPIRED = 0, CLF_MISPLACED = 1, CLF_HOOK = 2, CLF_STALLS = 4, CLF_MAXGAP = 5, CLF_DIAG = 8, CLF_WORDS = 32 };
 constexpr int CLW_GATE = 1 << 28;
 __device__ __forceinline__ int cl_who(int kind, int cid, int member, int wave) {
   return kind << 24 | (cid & 0xfff) << 12 | (member & 15) << 8 | (wave & 255);
+}
+// stall census of a finished wait (rare: a healthy poll returns within microseconds)
+__device__ __noinline__ void cl_note_gap(int* fault, unsigned maxgap, int lane) {
+  if (maxgap > CL_GAP_NOTE && lane == 0) {
+    atomicMax(fault + CLF_MAXGAP, (int)(maxgap >> 10));
+    if (maxgap > CL_GAP_STALL) atomicAdd(fault + CLF_STALLS, 1);
+  }
+}
+// an expired wait: counted, and the first one since the last census described (words CLF_DIAG ..)
+__device__ __noinline__ void cl_note_expired(int* fault, int who, int t, int v, int target, unsigned polls,
+                                                unsigned long long t0, unsigned maxgap, int lane) {
+  if (lane == 0) {
+    atomicAdd(fault + CLF_EXPIRED, 1);
+    if (atomicCAS(fault + CLF_DIAG, 0, 1) == 0) {
+      const unsigned long long el = __builtin_readcyclecounter() - t0;
+      fault[CLF_DIAG + 1] = who;
+      fault[CLF_DIAG + 2] = t;
+      fault[CLF_DIAG + 3] = v;
+      fault[CLF_DIAG + 4] = target;
+      fault[CLF_DIAG + 5] = (int)polls;
+      fault[CLF_DIAG + 6] = (int)(unsigned)el;
+      fault[CLF_DIAG + 7] = (int)(unsigned)(el >> 32);
+      fault[CLF_DIAG + 8] = (int)maxgap;
+      fault[CLF_DIAG + 9] = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15) + 1;
+    }
+  }
 }
 // wave-uniform bounded wait for *cnt >= target (every lane polls the same word: one request); returns the value seen
 // (CL_POISON set: some wave of the cluster has given up), or -1 = this wave's bound ran out (counted, described)
@@ -730,26 +776,9 @@ __device__ __forceinline__ int cl_wait(int* cnt, int target, int* fault, int who
     last = now;
     maxgap = gap > maxgap ? gap : maxgap;
   } while (v < target && ++polls < CL_WAIT_POLLS);     // the last poll is always looked at before giving up
-  if (maxgap > CL_GAP_NOTE && lane == 0) {             // stall census (rare: a healthy poll returns within microseconds)
-    atomicMax(fault + CLF_MAXGAP, (int)(maxgap >> 10));
-    if (maxgap > CL_GAP_STALL) atomicAdd(fault + CLF_STALLS, 1);
-  }
+  cl_note_gap(fault, maxgap, lane);
   if (v >= target) return v;
-  if (lane == 0) {
-    atomicAdd(fault + CLF_EXPIRED, 1);
-    if (atomicCAS(fault + CLF_DIAG, 0, 1) == 0) {
-      const unsigned long long el = __builtin_readcyclecounter() - t0;
-      fault[CLF_DIAG + 1] = who;
-      fault[CLF_DIAG + 2] = t;
-      fault[CLF_DIAG + 3] = v;
-      fault[CLF_DIAG + 4] = target;
-      fault[CLF_DIAG + 5] = (int)polls;
-      fault[CLF_DIAG + 6] = (int)(unsigned)el;
-      fault[CLF_DIAG + 7] = (int)(unsigned)(el >> 32);
-      fault[CLF_DIAG + 8] = (int)maxgap;
-      fault[CLF_DIAG + 9] = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15) + 1;
-    }
-  }
+  cl_note_expired(fault, who, t, v, target, polls, t0, maxgap, lane);
   return -1;
 }
 // One exchange wait of a wave under the sticky protocol above.  true = the wave's tile has to be poisoned NOW (its own
@@ -762,6 +791,52 @@ __device__ __forceinline__ bool cl_wait_step(int* cnt, int target, int* fault, i
   if (seen) *seen = v < 0 ? CL_POISON : v;
   if (v >= 0 && !(v & CL_POISON)) return false;
   if (v < 0 && lane == 0) __hip_atomic_fetch_or(cnt, CL_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  dead = true;
+  return true;
+}
+// ---- TAGGED exchange (the training sweep, lstm_fwd_cluster_kernel): the h slices announce themselves.
+// |h| < 1, so bit 14 of a bf16 h (the top exponent bit) is always 0; the sender puts a TAG there -- in elements 0 and 4 of
+// every 16-byte piece, one per 8-byte half -- that flips every time a ring slot is rewritten: h_t carries ((t + 2) >> 1) & 1
+// and lives in slot t & 1, whose previous content h_{t-2} carried the opposite.  A reader loads the 16 fragments of
+// h_{t-1}, and the ones whose tags match ARE h_{t-1}: no counter, no acknowledged store, no workgroup barrier and no
+// atomic between a member's last gate and its partners' products (the counted protocol spent four L2 round trips per
+// step there: store acknowledgement, atomic, poll, loads).  Stale pieces are polled again (only those), under the same
+// poll bound, census and description as a counted wait; a wave whose bound runs out poisons its tile and sets CL_POISON
+// in the cluster's counter (for the record: nobody waits on the counter after round 0).  Why two slots are enough
+// without a "done reading" signal: a member writes h_{t+1} into the slot of h_{t-1} only after it has read h_t of ALL
+// members, and each of those was written after its author had finished reading h_{t-1}.  Round 0 (h_{-1} = 0 into slot
+// 1, zeros with the wrong tag into slot 0, both acknowledged before the round-0 arrival) and the placement check stay
+// on the counter, so a slot never shows a previous launch's bytes.  A poisoned tile's NaNs survive in the 6 untagged
+// elements of every piece.
+constexpr unsigned CL_TAG = 0x4000u;
+__device__ __forceinline__ unsigned cl_tag_of(int t) { return (unsigned)(((t + 2) >> 1) & 1) << 14; }   // tag of h_t
+__device__ __forceinline__ unsigned cl_piece_stale(const uint4& v, unsigned e) { return ((v.x ^ e) | (v.z ^ e)) & CL_TAG; }
+// slow path of a tagged read: some piece of `ah` was stale.  true = the bound ran out (counted, described; `dead` set)
+template <int NKC>
+__device__ __forceinline__ bool cl_wait_tagged(const uint4* hx, uint4 (&ah)[NKC], unsigned e, int* cnt, int* fault, int who,
+                                               int t, int lane, bool& dead) {
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  unsigned last = (unsigned)t0, maxgap = 0, polls = 0;
+  int nstale;
+#pragma nounroll
+  do {
+    __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc)
+      if (__any(cl_piece_stale(ah[kc], e) != 0)) ah[kc] = ld_sc1(hx + kc * 64);     // wave-uniform
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    nstale = 0;
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) nstale += __any(cl_piece_stale(ah[kc], e) != 0) ? 1 : 0;
+    const unsigned now = (unsigned)__builtin_readcyclecounter();
+    const unsigned gap = now - last;
+    last = now;
+    maxgap = gap > maxgap ? gap : maxgap;
+  } while (nstale && ++polls < CL_WAIT_POLLS_TAGGED);
+  cl_note_gap(fault, maxgap, lane);
+  if (!nstale) return false;
+  cl_note_expired(fault, who, t, NKC - nstale, NKC, polls, t0, maxgap, lane);     // "counter" = fragments that did arrive
+  if (lane == 0) __hip_atomic_fetch_or(cnt, CL_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   dead = true;
   return true;
 }
@@ -778,7 +853,7 @@ struct ClPair {
   int* gate;                // upper layer: counter line of the producing cluster; null = X is ready at launch
   int role;                 // 0 / 1: half of the grid (cluster ids and hx slots of the halves are disjoint)
 };
-template <bool SIGM, int NKX>
+template <bool SIGM, int NKX, bool TAGGED = false>
 __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__ X, int DP,
                                                       const bf16_t* __restrict__ Wpack, const float* __restrict__ bias,
                                                       StashElem<bf16_t>* __restrict__ Zst,
@@ -832,6 +907,10 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
       uint4* hxo = hxb + ((hx_tile * 2 + 1) * 16 + 2 * s) * 64 + lane;
       hxo[0] = make_uint4(0, 0, 0, 0);
       hxo[64] = make_uint4(0, 0, 0, 0);
+      if constexpr (TAGGED) {      // slot 0 must not show a previous launch's h with the tag h_0 will carry (1): zeros, tag 0
+        hxo[-16 * 64] = make_uint4(0, 0, 0, 0);
+        hxo[-16 * 64 + 64] = make_uint4(0, 0, 0, 0);
+      }
     }
     if (tid == 0) __hip_atomic_store(xccs + s, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -901,7 +980,7 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
   if (active) cl_load_x<NR, 0, NR>(xq, X + (tile * steps * 32 + xr8) * DP + xc * 8, DP, xc);
   for (int t = 0; t < steps; ++t) {
     if (!active) {                 // wave without a tile: the step barrier only (the branch is wave-uniform)
-      __syncthreads();
+      if constexpr (!TAGGED) __syncthreads();
       continue;
     }
     const int64_t rb = tile * steps + t;
@@ -941,14 +1020,17 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
     {
       // a member that never arrives (grid not co-resident) is never a silent wrong answer: the wait is bounded and
       // counted (cl_wait), and the cell state is poisoned, so every later h of this tile, and the loss, is NaN
-      bool bad = cl_wait_step(cnt, ARRIVALS * (t + 1), fault, who, t, lane, dead);
-      // upper layer of a pair: x_{t+1} (requested below) exists once the producer has closed step t + 2; the counter
-      // is polled only when the last value seen does not cover it (the producer is faster and runs away)
-      if (gate && t + 1 < steps && seen < ARRIVALS * (t + 4))
-        bad |= cl_wait_step(gate, ARRIVALS * (t + 4), fault, who | CLW_GATE, t, lane, dead, &seen);
-      if (bad) {
+      bool bad = false;
+      if constexpr (!TAGGED) {
+        bad = cl_wait_step(cnt, ARRIVALS * (t + 1), fault, who, t, lane, dead);
+        // upper layer of a pair: x_{t+1} (requested below) exists once the producer has closed step t + 2; the counter
+        // is polled only when the last value seen does not cover it (the producer is faster and runs away)
+        if (gate && t + 1 < steps && seen < ARRIVALS * (t + 4))
+          bad |= cl_wait_step(gate, ARRIVALS * (t + 4), fault, who | CLW_GATE, t, lane, dead, &seen);
+        if (bad) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) c[r] = __builtin_nanf("");
+          for (int r = 0; r < 16; ++r) c[r] = __builtin_nanf("");
+        }
       }
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
@@ -958,9 +1040,29 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
       for (int kc = 0; kc < R::NKC; ++kc) ah[kc] = ld_sc1(hx + kc * 64);
       asm volatile("" ::: "memory");
       // the first rounds of x_{t+1} go out right behind the h fragments, always 4*NRA requests, so the wait below
-      // is a constant
-      cl_load_x<NR, 0, NRA>(xq, xnext, DP, xc);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NRA) : "memory");
+      // is a constant (tagged exchange: behind the tag check, whose slow path then has their registers to itself)
+      if constexpr (!TAGGED) {
+        cl_load_x<NR, 0, NRA>(xq, xnext, DP, xc);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NRA) : "memory");
+      } else {                     // the fragments whose tags match are h_{t-1}; the others are asked for again
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned e = cl_tag_of(t - 1);
+        unsigned stale = 0;
+#pragma unroll
+        for (int kc = 0; kc < R::NKC; ++kc) stale |= cl_piece_stale(ah[kc], e);
+        if (!dead && __any(stale != 0))
+          bad = cl_wait_tagged<R::NKC>(hx, ah, e, cnt, fault, cl_who(4, cid, s, w), t, lane, dead);
+        if (bad) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c[r] = __builtin_nanf("");
+        }
+#pragma unroll
+        for (int kc = 0; kc < R::NKC; ++kc) {
+          ah[kc].x &= ~CL_TAG;
+          ah[kc].z &= ~CL_TAG;
+        }
+        cl_load_x<NR, 0, NRA>(xq, xnext, DP, xc);
+      }
 #pragma unroll
       for (int kc = 0; kc < R::NKC; ++kc) {
         Frag a;
@@ -990,7 +1092,15 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
     {
       uint4* hxo = hxb + ((hx_tile * 2 + (t & 1)) * 16 + 2 * s) * 64 + lane;
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) hxo[jj * 64] = *(const uint4*)(ht + l31 * 32 + 16 * jj + 8 * h);
+      for (int jj = 0; jj < 2; ++jj) {
+        uint4 pv = *(const uint4*)(ht + l31 * 32 + 16 * jj + 8 * h);
+        if constexpr (TAGGED) {
+          pv.x = (pv.x & ~CL_TAG) | cl_tag_of(t);
+          pv.z = (pv.z & ~CL_TAG) | cl_tag_of(t);
+          if ((hook & 4) && s == CL_M - 1 && t >= 2) continue;      // test hook: this member's slices stop arriving
+        }
+        hxo[jj * 64] = pv;
+      }
     }
     asm volatile("" ::: "memory");
     // then the row-major h slice (32 rows x 64 bytes -> 2 x 16-byte vectors per lane) and the stash
@@ -1007,7 +1117,7 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
         for (int e = 0; e < 8; ++e) xo[e] = dj_from_f32<T>(dj_to_f32(he[e]) + sp8[e]);
         __builtin_memcpy(&hv, xo, 16);
       }
-      *(uint4*)(Hout + (rb * 32 + row) * H + s * 32 + cq) = hv;
+      cl_store_h(Hout + (rb * 32 + row) * H + s * 32 + cq, hv, pr.sp_out != nullptr);
     }
     // c and the gate stash are not read again before BPTT: non-temporal stores keep them from pushing the x rows and
     // the h exchange slots out of L2 (PMC: reads of the time-layer-1 launch 0.86 -> 0.58 GB, x alone is 0.54; the
@@ -1035,17 +1145,19 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
     // stores are acknowledged in order: wait until only the ones issued after the exchange copy are outstanding
     // (2 h + 2 c + 4 gate-stash stores; they drain under the next step and at the latest at the end of the kernel)
     asm volatile("" ::: "memory");
-    constexpr int NST = GateEnc<T, SIGM>::STORES;          // 16-byte stores per gate block
-    if (Zst && Cout)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + 4 * NST) : "memory");
-    else if (Zst)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + 4 * NST) : "memory");
-    else if (Cout)
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (!TAGGED) {
+      constexpr int NST = GateEnc<T, SIGM>::STORES;          // 16-byte stores per gate block
+      if (Zst && Cout)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + 4 * NST) : "memory");
+      else if (Zst)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + 4 * NST) : "memory");
+      else if (Cout)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   if (pr.sp_out) {          // the rows of the last step are out: one more round for the consuming layer
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1267,7 +1379,7 @@ __device__ __forceinline__ void lstm_fwd_cluster_coop_body(const bf16_t* __restr
           for (int e = 0; e < 8; ++e) xo[e] = dj_from_f32<T>(dj_to_f32(he[e]) + sp8[e]);
           __builtin_memcpy(&hv, xo, 16);
         }
-        *(uint4*)(Hout + (rb * 32 + row) * H + s * 32 + cq) = hv;
+        cl_store_h(Hout + (rb * 32 + row) * H + s * 32 + cq, hv, pr.sp_out != nullptr);
       }
       asm volatile("" ::: "memory");
       asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -1433,7 +1545,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_f32_kernel(const float* 
     }
   }
 }
-template <bool SIGM, int NKX>
+template <bool SIGM, int NKX, bool TAGGED>
 __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __restrict__ X, int DP,
                                                                const bf16_t* __restrict__ Wpack,
                                                                const float* __restrict__ bias,
@@ -1443,7 +1555,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_kernel(const bf16_t* __r
                                                                int steps, int* __restrict__ cl, int ntiles) {
   ClPair pr;
   pr.sp_out = nullptr; pr.sp_D = 0; pr.n_seq = 1; pr.n_b = 1; pr.gate = nullptr; pr.role = 0;
-  lstm_fwd_cluster_body<SIGM, NKX>(X, DP, Wpack, bias, Zst, Upack, Hout, Cout, steps, cl, ntiles, pr, (int)gridDim.x);
+  lstm_fwd_cluster_body<SIGM, NKX, TAGGED>(X, DP, Wpack, bias, Zst, Upack, Hout, Cout, steps, cl, ntiles, pr, (int)gridDim.x);
 }
 // two stacked inference layers as a wavefront (ClPair): blocks [0, n) = the lower layer (input width 96 -> 8 k-chunks),
 // blocks [n, 2n) = the upper one (256 -> 16); X1 is both the lower layer's output and the upper layer's input
@@ -1966,31 +2078,31 @@ int launch_fwd_fused(int ntiles, int steps, const void* X, int DP, int NKX, cons
               : launch_fwd_fused_s<T, H, false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, st);
 }
 
-template <bool SIGM, int NKX>
+template <bool SIGM, int NKX, bool TAGGED>
 int launch_fwd_cluster_k(int ntiles, int steps, const void* X, int DP, const void* Wpack, const float* bias,
                          void* Zst, const void* Upack, void* Hout, void* Cout, size_t smem, void* scratch,
                          hipStream_t st) {
   static bool attr_done_dev[DJ_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[dj_current_device()];
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_cluster_kernel<SIGM, NKX>,
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_fwd_cluster_kernel<SIGM, NKX, TAGGED>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
   // whole groups of 64 blocks = 8 XCDs x 8 members; wave slots beyond ntiles stay idle
-  hipLaunchKernelGGL((lstm_fwd_cluster_kernel<SIGM, NKX>), dim3((ntiles + 63) / 64 * 64), dim3(512), smem, st, (const bf16_t*)X, DP,
+  hipLaunchKernelGGL((lstm_fwd_cluster_kernel<SIGM, NKX, TAGGED>), dim3((ntiles + 63) / 64 * 64), dim3(512), smem, st, (const bf16_t*)X, DP,
                      (const bf16_t*)Wpack, bias, (uint8_t*)Zst, (const bf16_t*)Upack, (bf16_t*)Hout, (bf16_t*)Cout, steps,
                      (int*)scratch, ntiles);
   return (int)hipGetLastError();
 }
-template <bool SIGM>
+template <bool SIGM, bool TAGGED>
 int launch_fwd_cluster_s(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
                          void* Zst, const void* Upack, void* Hout, void* Cout, size_t smem, void* scratch,
                          hipStream_t st) {
   switch (NKX) {   // the input widths the model has (dj_lstm_fused_nkx): 94 -> 8 chunks, 256 -> 16
-    case 8: return launch_fwd_cluster_k<SIGM, 8>(ntiles, steps, X, DP, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st);
-    case 16: return launch_fwd_cluster_k<SIGM, 16>(ntiles, steps, X, DP, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st);
+    case 8: return launch_fwd_cluster_k<SIGM, 8, TAGGED>(ntiles, steps, X, DP, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st);
+    case 16: return launch_fwd_cluster_k<SIGM, 16, TAGGED>(ntiles, steps, X, DP, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st);
   }
   return 1016;
 }
@@ -2018,12 +2130,15 @@ int cluster_reset(void* scratch, hipStream_t st) {
 // Test hooks (word 2 of the fault line), so that the fault handling can be exercised on hardware, deterministically:
 // DJ_KF_DEBUG_CLUSTER_FAULT (bit 0 of the word): the next launches fail their placement check (fallback in fit, errors
 // in predict / generation); DJ_KF_DEBUG_CLUSTER_LATE (bit 1): the last member of every cluster never arrives in round 0,
-// so every other wave's bound really runs out -- once (poison bit, sticky), which the launch duration shows.
+// so every other wave's bound really runs out -- once (poison bit, sticky), which the launch duration shows;
+// DJ_KF_DEBUG_CLUSTER_MUTE (bit 2): the last member of every cluster stops publishing its h slices at step 2 of a tagged
+// sweep, so every wave's bound runs out on the fragments of step 2 -- all at once, and no poisoned wave waits again.
 __global__ void cl_hook_kernel(int* f, int v) { f[CLF_HOOK] = v; }
 int cluster_fault_hook(void* scratch, uint32_t kf, hipStream_t st) {
   static void* armed[16] = {};                        // scratches whose hook word is set (a handful of engines at most)
   static int armed_v[16] = {};
-  const int want = ((kf & DJ_KF_DEBUG_CLUSTER_FAULT) ? 1 : 0) | ((kf & DJ_KF_DEBUG_CLUSTER_LATE) ? 2 : 0);
+  const int want = ((kf & DJ_KF_DEBUG_CLUSTER_FAULT) ? 1 : 0) | ((kf & DJ_KF_DEBUG_CLUSTER_LATE) ? 2 : 0) |
+                   ((kf & DJ_KF_DEBUG_CLUSTER_MUTE) ? 4 : 0);
   int slot = -1, free_slot = -1;
   for (int i = 0; i < 16; ++i) {
     if (armed[i] == scratch) slot = i;
@@ -2049,8 +2164,12 @@ int launch_fwd_cluster(int ntiles, int steps, const void* X, int DP, int NKX, co
   // counters and XCC ids of every cluster start at zero in every launch (cl_reset_kernel: a kernel node under graph capture)
   if (int rc = cluster_reset(scratch, st)) return rc;
   if (int rc = cluster_fault_hook(scratch, kf, st)) return rc;
-  return sigm ? launch_fwd_cluster_s<true>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st)
-              : launch_fwd_cluster_s<false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st);
+  // the h slices announce themselves by their tags ("TAGGED exchange" above) unless the caller asks for the counted protocol
+  if (kf & DJ_KF_COUNTED_EXCHANGE)
+    return sigm ? launch_fwd_cluster_s<true, false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st)
+                : launch_fwd_cluster_s<false, false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st);
+  return sigm ? launch_fwd_cluster_s<true, true>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st)
+              : launch_fwd_cluster_s<false, true>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st);
 }
 
 int launch_fwd_cluster_pair(int ntiles, int steps, const ClPairArgs& a, int sigm, void* scratch, uint32_t kf,

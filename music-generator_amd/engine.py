@@ -132,7 +132,8 @@ _LIVE = weakref.WeakSet()          # engines alive in this process
 # were, the most waits any of them saw with polls > 2^20 cycles apart, the longest gap between two polls of a wait.
 CENSUS = {"engines": 0, "stalled_waits": 0, "max_poll_gap_cycles": 0}
 
-_WAIT_KINDS = {1: "bf16 sweep", 2: "bf16 cooperative body", 3: "fp32 inference sweep", 5: "pair BPTT (tools)",
+_WAIT_KINDS = {1: "bf16 sweep", 2: "bf16 cooperative body", 3: "fp32 inference sweep",
+               4: "bf16 sweep, tagged h fragments (counter = fragments that had arrived)", 5: "pair BPTT (tools)",
                6: "two-tile BPTT (tools)"}
 
 

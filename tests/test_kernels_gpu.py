@@ -138,7 +138,7 @@ def test_gemm_nt(gpu_device, dtype, M, N, K):
         # the epilogue writes rows with 16-byte stores when C, bias and ldc allow it (store_block_rows16: the two halves of a
         # wave trade pieces); a C that is only 8-byte aligned takes the 8-byte path: same values, nothing outside [M, N]
         buf = torch.zeros(M * ldc + 12, dtype=Ad.dtype, device=gpu_device)
-        L.check(lib.dj_gemm_nt(DT[dtype], M, N, K, L.ptr(Ad), K, L.ptr(Bd), K, L.ptr(buf) + 8, ldc, 0,
+        L.check(lib.dj_gemm_nt(DT[dtype], M, N, K, L.ptr(Ad), K, L.ptr(Bd), K, C.c_void_p(buf.data_ptr() + 8), ldc, 0,
                                L.ptr(bias.to(gpu_device)), _st()), "gemm_nt, C 8-byte aligned")
         assert torch.equal(buf[4:4 + M * ldc].view(M, ldc), Cd)
         assert float(buf[:4].abs().max()) == 0.0 and float(buf[4 + M * ldc:].abs().max()) == 0.0
@@ -344,19 +344,19 @@ def test_nadam_matches_oracle(gpu_device):
                                       (256, 2048, 6, 256), (256, 8192, 3, 94),
                                       # two cluster launches: 256 tiles + 75 tiles on a grid of 128 wave slots
                                       (256, 331 * 32, 2, 94), (256, 150, 9, 94)])
-def test_lstm_fwd_fused_input_projection(gpu_device, dtype, H, S, Ls, D):
+def test_lstm_fwd_fused_input_projection(gpu_device, djenv, dtype, H, S, Ls, D):
     """z = x W + h U + b inside the recurrent kernel (dj_lstm_fwd_fused) vs the restated cell."""
-    _fwd_fused_case(gpu_device, dtype, H, S, Ls, D, 0)
+    _fwd_fused_case(gpu_device, dtype, H, S, Ls, D, 0, djenv)
 
 
 @pytest.mark.parametrize("H,S,Ls,D", [(256, 2048, 4, 256), (256, 96, 4, 94), (128, 64, 5, 128)])
-def test_lstm_fwd_fused_recurrent_sigmoid(gpu_device, H, S, Ls, D):
+def test_lstm_fwd_fused_recurrent_sigmoid(gpu_device, djenv, H, S, Ls, D):
     """The same kernels with recurrent_activation='sigmoid' (template switch; Keras' default is hard_sigmoid), bf16:
     cluster kernel (64 tiles), per-tile H = 256, register-stationary H = 128."""
-    _fwd_fused_case(gpu_device, "bf16", H, S, Ls, D, 1)
+    _fwd_fused_case(gpu_device, "bf16", H, S, Ls, D, 1, djenv)
 
 
-def _fwd_fused_case(gpu_device, dtype, H, S, Ls, D, sigm):
+def _fwd_fused_case(gpu_device, dtype, H, S, Ls, D, sigm, djenv=None):
     L, lib = _lib()
     ract = torch.sigmoid if sigm else O.hard_sigmoid
     DP = (D + 7) // 8 * 8
@@ -401,6 +401,17 @@ def _fwd_fused_case(gpu_device, dtype, H, S, Ls, D, sigm):
         L.check(lib.dj_lstm_fwd_fused(DT[dtype], H, tiles, Ls, L.ptr(Xd), DP, D, L.ptr(wpack), L.ptr(b.to(gpu_device)),
                                       None, L.ptr(upf), L.ptr(Hd2), None, sigm, None, _st()), "fwd_fused per-tile")
         torch.testing.assert_close(Hd2.float().cpu(), Hd.float().cpu(), rtol=rt, atol=at * 5)
+        if djenv is not None:
+            # the cluster sweep's two exchange protocols -- h slices that announce themselves by a tag in a spare exponent
+            # bit (default) and the per-step counter (DJ_KF_COUNTED_EXCHANGE) -- are the same sums in the same order:
+            # h, c and the gate stash must agree to the last bit
+            djenv.set("DEEPJ_TAGGED_EXCHANGE", "0")
+            Hd3 = torch.zeros_like(Hd); Cd3 = torch.zeros_like(Cd); Gd3 = stash_buffer(R, H, dtype, gpu_device)
+            L.check(lib.dj_lstm_fwd_fused(DT[dtype], H, tiles, Ls, L.ptr(Xd), DP, D, L.ptr(wpack), L.ptr(b.to(gpu_device)),
+                                          L.ptr(Gd3), L.ptr(upf), L.ptr(Hd3), L.ptr(Cd3), sigm, L.ptr(cl), _st()), "counted")
+            djenv.unset("DEEPJ_TAGGED_EXCHANGE")
+            assert torch.equal(Hd3, Hd) and torch.equal(Cd3, Cd) and torch.equal(Gd3, Gd)
+            assert lib.dj_lstm_cluster_faults(L.ptr(cl), _st()) == 0
 
 
 @pytest.mark.parametrize("D", [128, 90])

@@ -426,6 +426,69 @@ def test_expired_wait_is_counted_described_and_costs_one_bound(gpu_device, djenv
     assert np.isfinite(host[0]) and host[1] == 0 and eng.cluster_faults() == 0
 
 
+def _cluster_step(gpu_device, T, kernel_flags=0, seed=5):
+    """one bf16 training step at B16 x T x N128 (64 time-axis tiles = 8 clusters) -> engine, [loss, faults..], gradient"""
+    from music_generator_amd.engine import Engine
+    B = 16
+    ocfg, dcfg = _cfgs(time_steps=T, num_notes=128, dtype="bf16")
+    flat = O.flatten_params(ocfg, O.init_params(ocfg, seed=11))
+    batch = O.synthetic_batch(ocfg, B, seed=3, T=T)
+    eng = Engine(dcfg, B, T, device=gpu_device, input_dropout=0.2, dropout=0.5, kernel_flags=kernel_flags)
+    P = torch.from_numpy(flat).to(gpu_device)
+    G = torch.empty_like(P)
+    dn = [torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(gpu_device) for a in batch]
+    torch.cuda.synchronize()
+    loss = eng.train_fwd_bwd(P, G, *dn, seed=seed)
+    return eng, loss.cpu().numpy(), G
+
+
+def test_tagged_and_counted_exchange_agree(gpu_device, djenv):
+    """The time-axis sweep's members exchange h slices that announce themselves by a tag in a spare exponent bit (|h| < 1)
+    instead of closing every step through the cluster's counter (DJ_KF_COUNTED_EXCHANGE keeps that protocol).  The
+    sweeps themselves agree to the last bit (tests/test_kernels_gpu.py); a whole step carries atomically summed
+    reductions (loss, weight gradients), so here: to their rounding, over a recurrence long enough for both ring slots
+    and both tag values to be reused many times."""
+    from music_generator_amd._lib import KF_COUNTED_EXCHANGE
+    for name in ("DEEPJ_TAGGED_EXCHANGE", "DEEPJ_CLUSTER"):
+        djenv.unset(name)
+    for T in (5, 64):
+        e1, l1, g1 = _cluster_step(gpu_device, T)
+        e2, l2, g2 = _cluster_step(gpu_device, T, kernel_flags=KF_COUNTED_EXCHANGE)
+        assert np.isfinite(l1[0]) and l1[1] == 0 and l2[1] == 0
+        assert abs(l1[0] - l2[0]) <= 2e-6 * abs(l1[0]), (T, l1, l2)
+        assert float((g1 - g2).abs().max()) <= 1e-5 * float(g1.abs().max()), T
+        assert e1.cluster_faults() == 0 and e2.cluster_faults() == 0
+
+
+@pytest.mark.fault_injection
+def test_muted_member_expires_the_tagged_waits_once(gpu_device, djenv):
+    """DEEPJ_DEBUG_CLUSTER_MUTE: the last member of every cluster stops publishing its h slices at step 2 of a tagged
+    sweep.  Every wave of the cluster -- the muted member's own included -- then polls two stale fragments of h_2 until
+    its bound runs out (2^17 polls of the fragments), all of them at the same time; each is counted, the first is described (kind: tagged
+    fragments, step 3, 14 of 16 fragments there), the tiles are poisoned (NaN loss), and no poisoned wave waits again:
+    the launch costs one bound, not one per remaining step."""
+    import time
+    from music_generator_amd import engine as E
+    for name in ("DEEPJ_TAGGED_EXCHANGE", "DEEPJ_CLUSTER"):
+        djenv.unset(name)
+    djenv.set("DEEPJ_DEBUG_CLUSTER_MUTE", "1")
+    n0, t0 = len(E.FAULT_LOG), time.time()
+    eng, host, _ = _cluster_step(gpu_device, 24)
+    dt = time.time() - t0
+    rep = eng.cluster_fault_report()
+    print("muted-member launch: %.3f s, [loss, faults, expired, misplaced] = %s, report %s" % (dt, host, rep))
+    assert np.isnan(host[0]) and host[2] >= 8 and host[3] == 0 and host[1] == host[2]
+    f = rep["first_expired"]
+    assert f is not None and f["kernel"].startswith("bf16 sweep, tagged") and f["step"] == 3
+    assert f["counter_seen"] == 14 and f["target"] == 16 and f["polls"] == 2 ** 17
+    assert 0.02 < dt < 6.0, dt                                       # two launches (time layers), one bound each
+    assert eng.take_async_faults(host[1]) == int(host[1])
+    assert len(E.FAULT_LOG) == n0 + 1
+    djenv.unset("DEEPJ_DEBUG_CLUSTER_MUTE")
+    eng2, host2, _ = _cluster_step(gpu_device, 24)
+    assert np.isfinite(host2[0]) and host2[1] == 0 and eng2.cluster_faults() == 0
+
+
 @pytest.mark.fault_injection
 def test_injected_cluster_fault_is_never_silent(gpu_device, djenv, capsys):
     """DEEPJ_DEBUG_CLUSTER_FAULT makes the bf16 cluster kernels fail their placement check on the device (rows
