@@ -672,12 +672,14 @@ __device__ __forceinline__ uint4 ld_sc1(const uint4* p) {
 }
 
 template <int NR> struct ClXRegs { uint4 v[NR][4]; };
-// A 16-byte piece of the row-major h_t.  Nothing in the launch reads these rows again (the exchange has its own copy), so
-// they go out NON-TEMPORAL like the stashes: streamed through an XCD's L2 at 0.5 GB per launch they otherwise push the
-// exchange ring out before its slots are overwritten (tools/l2_writeback.hip: an overwritten L2-resident line costs no
-// fabric write at all).  `keep`: the rows are the input of the upper layer of a pair, which reads them from this L2.
-__device__ __forceinline__ void cl_store_h(bf16_t* p, const uint4& v, bool keep) {
-  if (keep) {
+// A 16-byte piece of the row-major h_t.  In the training sweep nothing in the launch reads these rows again (the exchange
+// has its own copy), so they go out NON-TEMPORAL like the stashes (NT: a compile-time switch -- with a run-time one the
+// four dword stores were neither merged nor all marked); in the inference pair the rows are the input of the upper
+// layer, which reads them from this L2.  (tools/l2_writeback.hip: an overwritten L2-resident line costs no fabric write
+// at all -- the 0.5 GB per launch the exchange ring adds to WRITE_SIZE are capacity evictions by what streams through.)
+template <bool NT>
+__device__ __forceinline__ void cl_store_h(bf16_t* p, const uint4& v) {
+  if constexpr (!NT) {
     *(uint4*)p = v;
   } else {
     __builtin_nontemporal_store(v.x, (unsigned*)p);
@@ -694,9 +696,13 @@ __device__ __forceinline__ void cl_load_x(ClXRegs<NR>& q, const bf16_t* xb, int 
   for (int r = R0; r < R1; ++r)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bool ok = r * 64 + xc * 8 < DP;
-      const uint4 v = *(const uint4*)(xb + (ok ? 8 * i * DP + r * 64 : 0));
-      q.v[r][i] = ok ? v : make_uint4(0, 0, 0, 0);
+      // columns past DP: ANY finite values will do -- the packed W is zero for k >= D (pack_w_fwd_kernel) -- so the lane
+      // re-reads the start of its rows instead of being masked.  (With `ok ? v : 0` the compiler put every pair of requests
+      // under its own exec branch, and its vmcnt bookkeeping then had to assume the path on which all LATER requests of the
+      // step are skipped: the wait for x_t at the top of a step came out as vmcnt(3) -- i.e. wait for the acknowledgement
+      // of the 10 stores the previous step had just issued -- instead of vmcnt(25).)
+      const int co = r * 64 + xc * 8 < DP ? r * 64 : 0;
+      q.v[r][i] = *(const uint4*)(xb + 8 * i * DP + co);
     }
 }
 // ---- bounded exchange waits.
@@ -898,6 +904,17 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
   float bv[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) bv[g] = bias[g * H + s * 32 + l31];
+  const int xr8 = lane >> 3, xc = lane & 7;               // x rows: 8 lanes per row (below)
+  constexpr int NR = (NKX + 3) / 4, NRA = (NR + 1) / 2;   // rounds; those requested with the h fragments
+  ClXRegs<NR> xq;
+  // Tagged sweep: x_0 is requested HERE, in front of round 0, and retired there.  Requested right in front of the step
+  // loop it is still pending at the loop header with no later request behind it on that path, and the compiler's wait
+  // for x_t at the top of a step -- the merge of that path with the back edge, where the step's 10 stores follow the x
+  // requests -- became vmcnt(0): every step then began by waiting for the acknowledgement of the stores the previous
+  // one had just issued, one L2 round trip on the chain that the tagged exchange no longer needs.
+  if constexpr (TAGGED) {
+    if (active) cl_load_x<NR, 0, NR>(xq, X + (tile * steps * 32 + xr8) * DP + xc * 8, DP, xc);
+  }
   // round 0 of the exchange: h_{-1} = 0 goes into the parity-1 slots like any h_t, so that step 0 is a step like the
   // others (a conditional h product costs a second set of accumulators: 64 registers); with it every member
   // publishes the XCD it runs on
@@ -915,6 +932,14 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
     if (tid == 0) __hip_atomic_store(xccs + s, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (TAGGED) {      // x_0 is USED here (an empty statement the compiler cannot look into): its requests stay in
+                               // front of this point and its registers are not pending at the loop header
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        asm volatile("" : "+v"(xq.v[r][i].x), "+v"(xq.v[r][i].y), "+v"(xq.v[r][i].z), "+v"(xq.v[r][i].w));
+  }
   __syncthreads();
   const int hook = __hip_atomic_load(fault + CLF_HOOK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tests only
   if (tid == 0 && !((hook & 2) && s == CL_M - 1)) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -974,10 +999,9 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
   // x rows are fetched as full 128-byte lines, 8 lanes per row (fragments read straight from the rows would be
   // 32 segments of 32 bytes per instruction), ONE STEP AHEAD: the reads of a step otherwise queue behind the
   // write burst of the previous one in HBM (measured: 8 k cycles until x_t arrives, a quarter of the step).
-  const int xr8 = lane >> 3, xc = lane & 7;
-  constexpr int NR = (NKX + 3) / 4, NRA = (NR + 1) / 2;   // rounds; those requested with the h fragments
-  ClXRegs<NR> xq;
-  if (active) cl_load_x<NR, 0, NR>(xq, X + (tile * steps * 32 + xr8) * DP + xc * 8, DP, xc);
+  if constexpr (!TAGGED) {
+    if (active) cl_load_x<NR, 0, NR>(xq, X + (tile * steps * 32 + xr8) * DP + xc * 8, DP, xc);
+  }
   for (int t = 0; t < steps; ++t) {
     if (!active) {                 // wave without a tile: the step barrier only (the branch is wave-uniform)
       if constexpr (!TAGGED) __syncthreads();
@@ -1117,7 +1141,7 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
         for (int e = 0; e < 8; ++e) xo[e] = dj_from_f32<T>(dj_to_f32(he[e]) + sp8[e]);
         __builtin_memcpy(&hv, xo, 16);
       }
-      cl_store_h(Hout + (rb * 32 + row) * H + s * 32 + cq, hv, pr.sp_out != nullptr);
+      cl_store_h<TAGGED>(Hout + (rb * 32 + row) * H + s * 32 + cq, hv);
     }
     // c and the gate stash are not read again before BPTT: non-temporal stores keep them from pushing the x rows and
     // the h exchange slots out of L2 (PMC: reads of the time-layer-1 launch 0.86 -> 0.58 GB, x alone is 0.54; the
@@ -1379,7 +1403,7 @@ __device__ __forceinline__ void lstm_fwd_cluster_coop_body(const bf16_t* __restr
           for (int e = 0; e < 8; ++e) xo[e] = dj_from_f32<T>(dj_to_f32(he[e]) + sp8[e]);
           __builtin_memcpy(&hv, xo, 16);
         }
-        cl_store_h(Hout + (rb * 32 + row) * H + s * 32 + cq, hv, pr.sp_out != nullptr);
+        cl_store_h<false>(Hout + (rb * 32 + row) * H + s * 32 + cq, hv);
       }
       asm volatile("" ::: "memory");
       asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
