@@ -850,21 +850,20 @@ __device__ __forceinline__ void half_swap(uint32_t& a, uint32_t& b) {
 // swap); `ok` guards the stores.  `p` = this lane's row + the block's first column, 16-byte aligned.
 __device__ __forceinline__ void store_block_rows16(bf16_t* p, const f32x16& a, const float* __restrict__ bias_blk, int h,
                                                    bool ok) {
-  uint2 r[4];
+  uint4* q = (uint4*)(p + 16 * h);
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias_blk) bv = *(const float4*)(bias_blk + 8 * g + 4 * h);
-    r[g] = make_uint2(pack_bf16x2(a[4 * g] + bv.x, a[4 * g + 1] + bv.y), pack_bf16x2(a[4 * g + 2] + bv.z, a[4 * g + 3] + bv.w));
-  }
-  half_swap(r[0].x, r[2].x);
-  half_swap(r[0].y, r[2].y);
-  half_swap(r[1].x, r[3].x);
-  half_swap(r[1].y, r[3].y);
-  if (ok) {
-    uint4* q = (uint4*)(p + 16 * h);
-    q[0] = make_uint4(r[0].x, r[0].y, r[2].x, r[2].y);
-    q[1] = make_uint4(r[1].x, r[1].y, r[3].x, r[3].y);
+  for (int k = 0; k < 2; ++k) {        // pieces g = k and g = k + 2 -> the lane's columns [16 h + 8 k, 16 h + 8 k + 8)
+    uint2 r[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int g = k + 2 * j;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias_blk) bv = *(const float4*)(bias_blk + 8 * g + 4 * h);
+      r[j] = make_uint2(pack_bf16x2(a[4 * g] + bv.x, a[4 * g + 1] + bv.y), pack_bf16x2(a[4 * g + 2] + bv.z, a[4 * g + 3] + bv.w));
+    }
+    half_swap(r[0].x, r[1].x);
+    half_swap(r[0].y, r[1].y);
+    if (ok) q[k] = make_uint4(r[0].x, r[0].y, r[1].x, r[1].y);
   }
 }
 

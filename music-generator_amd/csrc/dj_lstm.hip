@@ -702,7 +702,8 @@ __device__ __forceinline__ void cl_load_x(ClXRegs<NR>& q, const bf16_t* xb, int 
       // step are skipped: the wait for x_t at the top of a step came out as vmcnt(3) -- i.e. wait for the acknowledgement
       // of the 10 stores the previous step had just issued -- instead of vmcnt(25).)
       const int co = r * 64 + xc * 8 < DP ? r * 64 : 0;
-      q.v[r][i] = *(const uint4*)(xb + 8 * i * DP + co);
+      const uint4 v = *(const uint4*)(xb + 8 * i * DP + co);
+      q.v[r][i] = make_uint4(v.x, v.y, v.z, v.w);
     }
 }
 // ---- bounded exchange waits.
@@ -741,14 +742,14 @@ __device__ __forceinline__ int cl_who(int kind, int cid, int member, int wave) {
   return kind << 24 | (cid & 0xfff) << 12 | (member & 15) << 8 | (wave & 255);
 }
 // stall census of a finished wait (rare: a healthy poll returns within microseconds)
-__device__ __noinline__ void cl_note_gap(int* fault, unsigned maxgap, int lane) {
+__device__ __forceinline__ void cl_note_gap(int* fault, unsigned maxgap, int lane) {
   if (maxgap > CL_GAP_NOTE && lane == 0) {
     atomicMax(fault + CLF_MAXGAP, (int)(maxgap >> 10));
     if (maxgap > CL_GAP_STALL) atomicAdd(fault + CLF_STALLS, 1);
   }
 }
 // an expired wait: counted, and the first one since the last census described (words CLF_DIAG ..)
-__device__ __noinline__ void cl_note_expired(int* fault, int who, int t, int v, int target, unsigned polls,
+__device__ __forceinline__ void cl_note_expired(int* fault, int who, int t, int v, int target, unsigned polls,
                                                 unsigned long long t0, unsigned maxgap, int lane) {
   if (lane == 0) {
     atomicAdd(fault + CLF_EXPIRED, 1);
@@ -906,14 +907,14 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
   for (int g = 0; g < 4; ++g) bv[g] = bias[g * H + s * 32 + l31];
   const int xr8 = lane >> 3, xc = lane & 7;               // x rows: 8 lanes per row (below)
   constexpr int NR = (NKX + 3) / 4, NRA = (NR + 1) / 2;   // rounds; those requested with the h fragments
-  ClXRegs<NR> xq;
+  [[maybe_unused]] ClXRegs<NR> xq0;
   // Tagged sweep: x_0 is requested HERE, in front of round 0, and retired there.  Requested right in front of the step
   // loop it is still pending at the loop header with no later request behind it on that path, and the compiler's wait
   // for x_t at the top of a step -- the merge of that path with the back edge, where the step's 10 stores follow the x
   // requests -- became vmcnt(0): every step then began by waiting for the acknowledgement of the stores the previous
   // one had just issued, one L2 round trip on the chain that the tagged exchange no longer needs.
   if constexpr (TAGGED) {
-    if (active) cl_load_x<NR, 0, NR>(xq, X + (tile * steps * 32 + xr8) * DP + xc * 8, DP, xc);
+    if (active) cl_load_x<NR, 0, NR>(xq0, X + (tile * steps * 32 + xr8) * DP + xc * 8, DP, xc);
   }
   // round 0 of the exchange: h_{-1} = 0 goes into the parity-1 slots like any h_t, so that step 0 is a step like the
   // others (a conditional h product costs a second set of accumulators: 64 registers); with it every member
@@ -938,7 +939,7 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
     for (int r = 0; r < NR; ++r)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        asm volatile("" : "+v"(xq.v[r][i].x), "+v"(xq.v[r][i].y), "+v"(xq.v[r][i].z), "+v"(xq.v[r][i].w));
+        asm volatile("" : "+v"(xq0.v[r][i].x), "+v"(xq0.v[r][i].y), "+v"(xq0.v[r][i].z), "+v"(xq0.v[r][i].w));
   }
   __syncthreads();
   const int hook = __hip_atomic_load(fault + CLF_HOOK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tests only
@@ -999,7 +1000,10 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
   // x rows are fetched as full 128-byte lines, 8 lanes per row (fragments read straight from the rows would be
   // 32 segments of 32 bytes per instruction), ONE STEP AHEAD: the reads of a step otherwise queue behind the
   // write burst of the previous one in HBM (measured: 8 k cycles until x_t arrives, a quarter of the step).
-  if constexpr (!TAGGED) {
+  ClXRegs<NR> xq;                  // (declared HERE: alive across round 0's statements it became a stack object)
+  if constexpr (TAGGED) {
+    xq = xq0;
+  } else {
     if (active) cl_load_x<NR, 0, NR>(xq, X + (tile * steps * 32 + xr8) * DP + xc * 8, DP, xc);
   }
   for (int t = 0; t < steps; ++t) {
