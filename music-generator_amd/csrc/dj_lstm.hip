@@ -634,7 +634,8 @@ __global__ __launch_bounds__(2 * H) void lstm_fwd_fused_kernel(const T* __restri
 // reads 8 x (16 KiB x + 16 KiB h) instead of 1 MiB of weights.  Every member writes its 32-unit slice of
 // h_t into a two-slot ring in L2.  In the training sweep (lstm_fwd_cluster_kernel) the slices ANNOUNCE THEMSELVES by a
 // tag in a spare exponent bit ("TAGGED exchange" below: round 4; 2.56 -> 2.38 ms per step of the baseline shape);
-// in the inference pair and under DJ_KF_COUNTED_EXCHANGE a per-cluster counter in L2 closes the step (acknowledged
+// so does the cooperative body of the inference pair; in the pair's one-wave form and under DJ_KF_COUNTED_EXCHANGE a
+// per-cluster counter in L2 closes the step (acknowledged
 // stores, workgroup barrier, atomic, poll).  The x_t W half does not depend on the exchange and runs before the wait.
 //  * x rows are fetched as full 128-byte lines (8 lanes per row) and turned into A fragments through a 4 KiB
 //    LDS tile per wave, 64 columns per round (fragments read straight from the rows are 32 segments of 32 bytes
@@ -713,8 +714,8 @@ __device__ __forceinline__ void cl_load_x(ClXRegs<NR>& q, const bf16_t* xb, int 
 //   [4] waits that saw two consecutive polls more than CL_GAP_STALL cycles apart   } stall census: cumulative, never
 //   [5] the longest poll-to-poll gap seen, in units of 1024 shader cycles          } reset by the fault census
 //   [8] 1 = words 9..20 describe the FIRST expired wait since the host last took the census:
-//       [9] who (kind << 24 | cluster << 12 | member << 8 | wave; kind 1 = bf16 sweep, 2 = cooperative body, 3 = fp32, 4 = bf16 sweep waiting for TAGGED h
-//       fragments ([11] = fragments that had arrived, [12] = 16),
+//       [9] who (kind << 24 | cluster << 12 | member << 8 | wave; kind 1 = bf16 sweep, 2 = cooperative body, 3 = fp32, 4 / 7 = bf16 sweep / cooperative body waiting for
+//       TAGGED h fragments ([11] = fragments that had arrived, [12] = 16),
 //       5 / 6 = pair / two-tile BPTT experiments (tools/); bit 28 = the wait was for the PRODUCING layer's counter),
 //       [10] step, [11] counter value seen last, [12] target, [13] polls made, [14..15] shader cycles from the first poll
 //       to the last (64 bit), [16] longest poll-to-poll gap in cycles (saturating), [17] hardware XCC id + 1
@@ -1199,7 +1200,12 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
 // a quarter of the products), park the pre-activations in LDS, and each then updates a quarter of the cells (accumulator
 // registers 4w .. 4w+3 of all four gates, lane-local as before); wave 0 sends the h slice.  Same sums in the same
 // order as the one-wave form: bit-identical results.  Two workgroup barriers per step; waves 4-7 only keep them company.
-template <bool SIGM, int NKX>
+// TAGGED (default; DJ_KF_COUNTED_EXCHANGE keeps the counter): the h slices announce themselves as in the training sweep
+// ("TAGGED exchange" above) -- a generated step is almost nothing BUT the exchange's latency chain.  The lower layer of
+// the pair still moves its counter once per step for the upper layer, which reads ROWS, not fragments: lazily, behind a
+// vmcnt(4) that only asks for the stores of the step BEFORE (long acknowledged), so closing step t promises the rows of
+// step t-1 exactly as the counted protocol does, without anybody waiting for an acknowledgement.
+template <bool SIGM, int NKX, bool TAGGED = false>
 __device__ __forceinline__ void lstm_fwd_cluster_coop_body(const bf16_t* __restrict__ X, int DP,
                                                            const bf16_t* __restrict__ Wpack,
                                                            const float* __restrict__ bias,
@@ -1241,6 +1247,10 @@ __device__ __forceinline__ void lstm_fwd_cluster_coop_body(const bf16_t* __restr
     uint4* hxo = hxb + ((hx_tile * 2 + 1) * 16 + 2 * s) * 64 + lane;
     hxo[0] = make_uint4(0, 0, 0, 0);
     hxo[64] = make_uint4(0, 0, 0, 0);
+    if constexpr (TAGGED) {        // slot 0: zeros with the tag h_0 will NOT carry
+      hxo[-16 * 64] = make_uint4(0, 0, 0, 0);
+      hxo[-16 * 64 + 64] = make_uint4(0, 0, 0, 0);
+    }
   }
   if (tid == 0) __hip_atomic_store(xccs + s, my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1337,13 +1347,10 @@ __device__ __forceinline__ void lstm_fwd_cluster_coop_body(const bf16_t* __restr
     const T* xnext = X + ((tile * steps + (t + 1 < steps ? t + 1 : t)) * 32 + xr8) * DP + xc * 8;
     // ---- h_{t-1} U of gate w
     {
-      bool bad = cl_wait_step(cnt, ARRIVALS * (t + 1), fault, who, t, lane, dead);
+      bool bad = false;
+      if constexpr (!TAGGED) bad = cl_wait_step(cnt, ARRIVALS * (t + 1), fault, who, t, lane, dead);
       if (gate && t + 1 < steps && seen < ARRIVALS * (t + 4))
         bad |= cl_wait_step(gate, ARRIVALS * (t + 4), fault, who | CLW_GATE, t, lane, dead, &seen);
-      if (bad) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) c4[e] = __builtin_nanf("");
-      }
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
       const uint4* hx = hxb + ((hx_tile * 2 + ((t + 1) & 1)) * 16) * 64 + lane;
@@ -1351,8 +1358,28 @@ __device__ __forceinline__ void lstm_fwd_cluster_coop_body(const bf16_t* __restr
 #pragma unroll
       for (int kc = 0; kc < R::NKC; ++kc) ah[kc] = ld_sc1(hx + kc * 64);
       asm volatile("" ::: "memory");
-      cl_load_x<NR, 0, NRA>(xq, xnext, DP, xc);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NRA) : "memory");
+      if constexpr (!TAGGED) {
+        cl_load_x<NR, 0, NRA>(xq, xnext, DP, xc);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NRA) : "memory");
+      } else {                     // the fragments whose tags match are h_{t-1}; the others are asked for again
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned e = cl_tag_of(t - 1);
+        unsigned stale = 0;
+#pragma unroll
+        for (int kc = 0; kc < R::NKC; ++kc) stale |= cl_piece_stale(ah[kc], e);
+        if (!dead && __any(stale != 0))
+          bad |= cl_wait_tagged<R::NKC>(hx, ah, e, cnt, fault, cl_who(7, cid, s, w), t, lane, dead);
+#pragma unroll
+        for (int kc = 0; kc < R::NKC; ++kc) {
+          ah[kc].x &= ~CL_TAG;
+          ah[kc].z &= ~CL_TAG;
+        }
+        cl_load_x<NR, 0, NRA>(xq, xnext, DP, xc);
+      }
+      if (bad) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c4[e] = __builtin_nanf("");
+      }
 #pragma unroll
       for (int kc = 0; kc < R::NKC; ++kc) {
         Frag a;
@@ -1391,7 +1418,14 @@ __device__ __forceinline__ void lstm_fwd_cluster_coop_body(const bf16_t* __restr
       {
         uint4* hxo = hxb + ((hx_tile * 2 + (t & 1)) * 16 + 2 * s) * 64 + lane;
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) hxo[jj * 64] = *(const uint4*)(ht + l31 * 32 + 16 * jj + 8 * h);
+        for (int jj = 0; jj < 2; ++jj) {
+          uint4 pv = *(const uint4*)(ht + l31 * 32 + 16 * jj + 8 * h);
+          if constexpr (TAGGED) {
+            pv.x = (pv.x & ~CL_TAG) | cl_tag_of(t);
+            pv.z = (pv.z & ~CL_TAG) | cl_tag_of(t);
+          }
+          hxo[jj * 64] = pv;
+        }
       }
       asm volatile("" ::: "memory");
 #pragma unroll
@@ -1410,8 +1444,13 @@ __device__ __forceinline__ void lstm_fwd_cluster_coop_body(const bf16_t* __restr
         cl_store_h<false>(Hout + (rb * 32 + row) * H + s * 32 + cq, hv);
       }
       asm volatile("" ::: "memory");
-      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (!TAGGED) {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (pr.sp_out) {      // lower layer of the pair: the counter the upper layer reads, one step behind (above)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
   if (pr.sp_out) {          // the rows of the last step are out: one more round for the consuming layer
@@ -1592,20 +1631,20 @@ struct ClPairArgs {
   bf16_t* X1; const bf16_t* W1; const float* b1; const bf16_t* U1; bf16_t* H1;
   const float* sp1; int sp_D, n_seq, n_b;
 };
-template <bool SIGM, bool COOP>
+template <bool SIGM, bool COOP, bool TAGGED = false>      // TAGGED: the cooperative body's members exchange tagged slices
 __global__ __launch_bounds__(512) void lstm_fwd_cluster_pair_kernel(ClPairArgs a, int steps, int* __restrict__ cl, int ntiles) {
   const int nblocks = (int)gridDim.x >> 1;
   ClPair pr;
   if ((int)blockIdx.x < nblocks) {
     pr.sp_out = a.sp1; pr.sp_D = a.sp_D; pr.n_seq = a.n_seq; pr.n_b = a.n_b; pr.gate = nullptr; pr.role = 0;
     if (COOP)
-      lstm_fwd_cluster_coop_body<SIGM, 8>(a.X0, a.DP0, a.W0, a.b0, a.U0, a.X1, steps, cl, ntiles, pr, nblocks);
+      lstm_fwd_cluster_coop_body<SIGM, 8, TAGGED>(a.X0, a.DP0, a.W0, a.b0, a.U0, a.X1, steps, cl, ntiles, pr, nblocks);
     else
       lstm_fwd_cluster_body<SIGM, 8>(a.X0, a.DP0, a.W0, a.b0, nullptr, a.U0, a.X1, nullptr, steps, cl, ntiles, pr, nblocks);
   } else {
     pr.sp_out = nullptr; pr.sp_D = 0; pr.n_seq = 1; pr.n_b = 1; pr.gate = cl; pr.role = 1;
     if (COOP)
-      lstm_fwd_cluster_coop_body<SIGM, 16>(a.X1, 256, a.W1, a.b1, a.U1, a.H1, steps, cl, ntiles, pr, nblocks);
+      lstm_fwd_cluster_coop_body<SIGM, 16, TAGGED>(a.X1, 256, a.W1, a.b1, a.U1, a.H1, steps, cl, ntiles, pr, nblocks);
     else
       lstm_fwd_cluster_body<SIGM, 16>(a.X1, 256, a.W1, a.b1, nullptr, a.U1, a.H1, nullptr, steps, cl, ntiles, pr, nblocks);
   }
@@ -2210,8 +2249,10 @@ int launch_fwd_cluster_pair(int ntiles, int steps, const ClPairArgs& a, int sigm
   static bool attr_done_dev[DJ_MAX_DEVICES] = {};
   bool& attr_done = attr_done_dev[dj_current_device()];
   if (!attr_done) {
-    const void* fns[4] = {(const void*)lstm_fwd_cluster_pair_kernel<false, false>, (const void*)lstm_fwd_cluster_pair_kernel<true, false>,
-                          (const void*)lstm_fwd_cluster_pair_kernel<false, true>, (const void*)lstm_fwd_cluster_pair_kernel<true, true>};
+    const void* fns[6] = {(const void*)lstm_fwd_cluster_pair_kernel<false, false>, (const void*)lstm_fwd_cluster_pair_kernel<true, false>,
+                          (const void*)lstm_fwd_cluster_pair_kernel<false, true>, (const void*)lstm_fwd_cluster_pair_kernel<true, true>,
+                          (const void*)lstm_fwd_cluster_pair_kernel<false, true, true>,
+                          (const void*)lstm_fwd_cluster_pair_kernel<true, true, true>};
     for (const void* fn : fns) {
       hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return (int)e;
@@ -2223,12 +2264,13 @@ int launch_fwd_cluster_pair(int ntiles, int steps, const ClPairArgs& a, int sigm
   // at most one tile per cluster (8 clusters per layer): the cooperative body, four waves per tile
   const bool coop_off = (kf & DJ_KF_NO_CLUSTER_COOP) != 0;
   const bool coop = ntiles <= 8 && !coop_off;
-#define DJ_PAIR_LAUNCH(S, C_) \
-  hipLaunchKernelGGL((lstm_fwd_cluster_pair_kernel<S, C_>), dim3(128), dim3(512), smem, st, a, steps, (int*)scratch, ntiles)
+  const bool tagged = coop && !(kf & DJ_KF_COUNTED_EXCHANGE);     // the cooperative body's exchange ("TAGGED exchange")
+#define DJ_PAIR_LAUNCH(S, C_, T_) \
+  hipLaunchKernelGGL((lstm_fwd_cluster_pair_kernel<S, C_, T_>), dim3(128), dim3(512), smem, st, a, steps, (int*)scratch, ntiles)
   if (sigm) {
-    if (coop) DJ_PAIR_LAUNCH(true, true); else DJ_PAIR_LAUNCH(true, false);
+    if (tagged) DJ_PAIR_LAUNCH(true, true, true); else if (coop) DJ_PAIR_LAUNCH(true, true, false); else DJ_PAIR_LAUNCH(true, false, false);
   } else {
-    if (coop) DJ_PAIR_LAUNCH(false, true); else DJ_PAIR_LAUNCH(false, false);
+    if (tagged) DJ_PAIR_LAUNCH(false, true, true); else if (coop) DJ_PAIR_LAUNCH(false, true, false); else DJ_PAIR_LAUNCH(false, false, false);
   }
 #undef DJ_PAIR_LAUNCH
   return (int)hipGetLastError();

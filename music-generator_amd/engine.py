@@ -134,6 +134,7 @@ CENSUS = {"engines": 0, "stalled_waits": 0, "max_poll_gap_cycles": 0}
 
 _WAIT_KINDS = {1: "bf16 sweep", 2: "bf16 cooperative body", 3: "fp32 inference sweep",
                4: "bf16 sweep, tagged h fragments (counter = fragments that had arrived)", 5: "pair BPTT (tools)",
+               7: "bf16 cooperative body, tagged h fragments (counter = fragments that had arrived)",
                6: "two-tile BPTT (tools)"}
 
 

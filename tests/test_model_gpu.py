@@ -303,6 +303,13 @@ def test_time_axis_pair_launch_matches_layer_by_layer(gpu_device, djenv, G, T, N
     seq_env = eng.time_model_predict(flat, d(notes), d(beat), d(style)).float().cpu().numpy()
     djenv.unset("DEEPJ_CLUSTER_PAIR")
     np.testing.assert_array_equal(seq, seq_env)
+    # the cooperative pair's members exchange tagged h slices by default; the counted protocol gives the same bits
+    from music_generator_amd._lib import KF_COUNTED_EXCHANGE
+    djenv.unset("DEEPJ_TAGGED_EXCHANGE")
+    eng.set_kernel_flags(KF_COUNTED_EXCHANGE)
+    counted = eng.time_model_predict(flat, d(notes), d(beat), d(style)).float().cpu().numpy()
+    eng.set_kernel_flags(0)
+    np.testing.assert_array_equal(pair, counted)
     assert eng.cluster_faults() == 0
     assert np.isfinite(pair).all()
     np.testing.assert_array_equal(pair, pair2)
