@@ -73,8 +73,9 @@ typedef struct dj_config {
                                      /*   bound runs out, once (tests of the expiry path and its cost)                */
 #define DJ_KF_NO_STEP_EPILOGUE 256   /* generic-width layers (scaled model) in bf16: one GEMM + one gate launch per step   */
                                      /*   instead of the cell as the GEMM's epilogue                                      */
-#define DJ_KF_COUNTED_EXCHANGE 512   /* H = 256 cluster sweep: members close a step through the cluster's counter (store  */
-                                     /*   acknowledgement, barrier, atomic, poll) instead of tags inside the h slices        */
+#define DJ_KF_COUNTED_EXCHANGE 512   /* H = 256 cluster sweeps (training sweep, cooperative inference pair): members close */
+                                     /*   a step through the cluster's counter (store acknowledgement, barrier, atomic,     */
+                                     /*   poll) instead of tags inside the h slices                                          */
 #define DJ_KF_DEBUG_CLUSTER_MUTE 1024 /* tagged sweep: the last member of every cluster stops publishing at step 2 (tests)  */
 /* (ABI 3 had two opt-in re-decompositions of the H = 256 BPTT sweep, DJ_KF_BWD_PAIR / _DUAL; they were slower and now
  * live in tools/bwd_decompositions/, outside this library) */
@@ -316,8 +317,8 @@ int32_t dj_workspace_cluster_faults(const dj_config* cfg, void* workspace, int64
  *   [8] != 0: [9..17] describe the first expired wait since the last census: [9] kind << 24 | cluster << 12 |
  *       member << 8 | wave (bit 28: the wait was for the producing layer's counter), [10] recurrence step (-1: round
  *       0), [11] counter value seen last, [12] target, [13] polls made, [14..15] shader cycles between first and last
- *       poll (lo, hi), [16] longest poll-to-poll gap in cycles, [17] hardware XCC id + 1.  Kind 4 = a wait of the
- *       training sweep for TAGGED h fragments (the members' slices announce themselves, no counter): [11] = fragments
+ *       poll (lo, hi), [16] longest poll-to-poll gap in cycles, [17] hardware XCC id + 1.  Kind 4 / 7 = a wait of the
+ *       training sweep / the cooperative inference pair for TAGGED h fragments (the members' slices announce themselves, no counter): [11] = fragments
  *       that had arrived, [12] = 16. */
 #define DJ_FAULT_REPORT_WORDS 32
 int32_t dj_workspace_cluster_fault_report(const dj_config* cfg, void* workspace, int64_t workspace_bytes,

@@ -497,6 +497,34 @@ def test_muted_member_expires_the_tagged_waits_once(gpu_device, djenv):
 
 
 @pytest.mark.fault_injection
+def test_muted_member_in_the_inference_pair_raises_described(gpu_device, djenv):
+    """The same hook on the cooperative inference pair (generation's time axis: both layers in one launch, tagged
+    exchange): the gate waves of every member run out of polls on the muted member's fragments, the output is NaN, the
+    census counts it and describes a wait of kind 'cooperative body, tagged' at step 3 with 14 of 16 fragments."""
+    from music_generator_amd.engine import Engine
+    for name in ("DEEPJ_TAGGED_EXCHANGE", "DEEPJ_CLUSTER", "DEEPJ_CLUSTER_PAIR", "DEEPJ_CLUSTER_COOP"):
+        djenv.unset(name)
+    djenv.set("DEEPJ_DEBUG_CLUSTER_MUTE", "1")
+    G, T, N = 3, 16, 48
+    ocfg, dcfg = _cfgs(time_steps=T, num_notes=N, dtype="bf16")
+    flat = torch.from_numpy(O.flatten_params(ocfg, O.init_params(ocfg, seed=11))).to(gpu_device)
+    notes, chosen, beat, style, target = O.synthetic_batch(ocfg, G, seed=4, T=T)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(gpu_device)
+    eng = Engine(dcfg, G, T, device=gpu_device)
+    out = eng.time_model_predict(flat, d(notes), d(beat), d(style)).float().cpu().numpy()
+    rep = eng.cluster_fault_report()
+    print("muted pair:", rep)
+    assert np.isnan(out).any() and rep["expired"] >= 4 and rep["misplaced"] == 0
+    f = rep["first_expired"]
+    assert f is not None and f["kernel"].startswith("bf16 cooperative body, tagged") and f["step"] == 3
+    assert f["counter_seen"] == 14 and f["target"] == 16 and f["polls"] == 2 ** 17
+    assert eng.cluster_faults("muted pair (test)") == rep["expired"]
+    djenv.unset("DEEPJ_DEBUG_CLUSTER_MUTE")
+    out = eng.time_model_predict(flat, d(notes), d(beat), d(style)).float().cpu().numpy()
+    assert np.isfinite(out).all() and eng.cluster_faults() == 0
+
+
+@pytest.mark.fault_injection
 def test_injected_cluster_fault_is_never_silent(gpu_device, djenv, capsys):
     """DEEPJ_DEBUG_CLUSTER_FAULT makes the bf16 cluster kernels fail their placement check on the device (rows
     poisoned with NaN, the event counted in the workspace).  What the host side must make of it: train_on_batch
