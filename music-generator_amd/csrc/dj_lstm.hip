@@ -666,10 +666,19 @@ constexpr int CL_CNT_INTS = 64 * 2 * CL_CNT_STRIDE;
 constexpr size_t CL_OFF_FAULT = (size_t)CL_CNT_INTS * sizeof(int);
 constexpr size_t CL_OFF_HX = CL_OFF_FAULT + 128;
 constexpr size_t CL_BYTES = CL_OFF_HX + (size_t)256 * 2 * 16 * 64 * 16;
-__device__ __forceinline__ uint4 ld_sc1(const uint4* p) {
-  uint4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
+// h fragments of the exchange: loads past the non-coherent L1 (sc1).  A BUFFER-load builtin, not inline assembly: until
+// round 4 these were assembly statements, whose destination registers the compiler considers written as soon as the
+// statement is issued and whose s_waitcnt -- another assembly statement -- orders memory operations only; nothing but the
+// scheduler's habits kept the uses behind the wait (an fp32 experiment of round 4 lost that bet: tag checks in front of
+// the wait, late data over reassigned registers, a memory fault).  The builtin is tracked by the compiler's own vmcnt
+// bookkeeping.  `rs` = the exchange region as a buffer resource (wave-uniform), `off` = byte offset of the lane's piece.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cl_hx_rsrc(const void* hxb) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)hxb, 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ uint4 ld_sc1(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);      // aux 16 = sc1
+  return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 template <int NR> struct ClXRegs { uint4 v[NR][4]; };
@@ -821,8 +830,8 @@ __device__ __forceinline__ unsigned cl_tag_of(int t) { return (unsigned)(((t + 2
 __device__ __forceinline__ unsigned cl_piece_stale(const uint4& v, unsigned e) { return ((v.x ^ e) | (v.z ^ e)) & CL_TAG; }
 // slow path of a tagged read: some piece of `ah` was stale.  true = the bound ran out (counted, described; `dead` set)
 template <int NKC>
-__device__ __forceinline__ bool cl_wait_tagged(const uint4* hx, uint4 (&ah)[NKC], unsigned e, int* cnt, int* fault, int who,
-                                               int t, int lane, bool& dead) {
+__device__ __forceinline__ bool cl_wait_tagged(__amdgpu_buffer_rsrc_t hxr, unsigned hoff, uint4 (&ah)[NKC], unsigned e, int* cnt,
+                                               int* fault, int who, int t, int lane, bool& dead) {
   const unsigned long long t0 = __builtin_readcyclecounter();
   unsigned last = (unsigned)t0, maxgap = 0, polls = 0;
   int nstale;
@@ -831,8 +840,7 @@ __device__ __forceinline__ bool cl_wait_tagged(const uint4* hx, uint4 (&ah)[NKC]
     __builtin_amdgcn_s_sleep(2);
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc)
-      if (__any(cl_piece_stale(ah[kc], e) != 0)) ah[kc] = ld_sc1(hx + kc * 64);     // wave-uniform
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (__any(cl_piece_stale(ah[kc], e) != 0)) ah[kc] = ld_sc1(hxr, hoff + kc * 1024);     // wave-uniform
     nstale = 0;
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) nstale += __any(cl_piece_stale(ah[kc], e) != 0) ? 1 : 0;
@@ -891,6 +899,7 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
   int* xccs = cnt + CL_CNT_STRIDE;
   int* fault = cl + CL_CNT_INTS;
   uint4* hxb = (uint4*)((unsigned char*)cl + CL_OFF_HX);
+  const __amdgpu_buffer_rsrc_t hxr = cl_hx_rsrc(hxb);
   constexpr int ARRIVALS = CL_M;
 
   // stationary operand slices -> LDS (contiguous in the packed streams)
@@ -1063,10 +1072,10 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
       }
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
-      const uint4* hx = hxb + ((hx_tile * 2 + ((t + 1) & 1)) * 16) * 64 + lane;
+      const unsigned hoff = (unsigned)((((hx_tile * 2 + ((t + 1) & 1)) * 16) * 64 + lane) * 16);   // bytes into the hx region
       uint4 ah[R::NKC];
 #pragma unroll
-      for (int kc = 0; kc < R::NKC; ++kc) ah[kc] = ld_sc1(hx + kc * 64);
+      for (int kc = 0; kc < R::NKC; ++kc) ah[kc] = ld_sc1(hxr, hoff + kc * 1024);
       asm volatile("" ::: "memory");
       // the first rounds of x_{t+1} go out right behind the h fragments, always 4*NRA requests, so the wait below
       // is a constant (tagged exchange: behind the tag check, whose slow path then has their registers to itself)
@@ -1074,13 +1083,12 @@ __device__ __forceinline__ void lstm_fwd_cluster_body(const bf16_t* __restrict__
         cl_load_x<NR, 0, NRA>(xq, xnext, DP, xc);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NRA) : "memory");
       } else {                     // the fragments whose tags match are h_{t-1}; the others are asked for again
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned e = cl_tag_of(t - 1);
         unsigned stale = 0;
 #pragma unroll
         for (int kc = 0; kc < R::NKC; ++kc) stale |= cl_piece_stale(ah[kc], e);
         if (!dead && __any(stale != 0))
-          bad = cl_wait_tagged<R::NKC>(hx, ah, e, cnt, fault, cl_who(4, cid, s, w), t, lane, dead);
+          bad = cl_wait_tagged<R::NKC>(hxr, hoff, ah, e, cnt, fault, cl_who(4, cid, s, w), t, lane, dead);
         if (bad) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) c[r] = __builtin_nanf("");
@@ -1233,6 +1241,7 @@ __device__ __forceinline__ void lstm_fwd_cluster_coop_body(const bf16_t* __restr
   int* xccs = cnt + CL_CNT_STRIDE;
   int* fault = cl + CL_CNT_INTS;
   uint4* hxb = (uint4*)((unsigned char*)cl + CL_OFF_HX);
+  const __amdgpu_buffer_rsrc_t hxr = cl_hx_rsrc(hxb);
   constexpr int ARRIVALS = CL_M;
   {
     const uint4* gw = (const uint4*)((const Frag*)Wpack + (int64_t)s * 4 * NKX * 64);
@@ -1353,22 +1362,21 @@ __device__ __forceinline__ void lstm_fwd_cluster_coop_body(const bf16_t* __restr
         bad |= cl_wait_step(gate, ARRIVALS * (t + 4), fault, who | CLW_GATE, t, lane, dead, &seen);
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
-      const uint4* hx = hxb + ((hx_tile * 2 + ((t + 1) & 1)) * 16) * 64 + lane;
+      const unsigned hoff = (unsigned)((((hx_tile * 2 + ((t + 1) & 1)) * 16) * 64 + lane) * 16);   // bytes into the hx region
       uint4 ah[R::NKC];
 #pragma unroll
-      for (int kc = 0; kc < R::NKC; ++kc) ah[kc] = ld_sc1(hx + kc * 64);
+      for (int kc = 0; kc < R::NKC; ++kc) ah[kc] = ld_sc1(hxr, hoff + kc * 1024);
       asm volatile("" ::: "memory");
       if constexpr (!TAGGED) {
         cl_load_x<NR, 0, NRA>(xq, xnext, DP, xc);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NRA) : "memory");
       } else {                     // the fragments whose tags match are h_{t-1}; the others are asked for again
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned e = cl_tag_of(t - 1);
         unsigned stale = 0;
 #pragma unroll
         for (int kc = 0; kc < R::NKC; ++kc) stale |= cl_piece_stale(ah[kc], e);
         if (!dead && __any(stale != 0))
-          bad |= cl_wait_tagged<R::NKC>(hx, ah, e, cnt, fault, cl_who(7, cid, s, w), t, lane, dead);
+          bad |= cl_wait_tagged<R::NKC>(hxr, hoff, ah, e, cnt, fault, cl_who(7, cid, s, w), t, lane, dead);
 #pragma unroll
         for (int kc = 0; kc < R::NKC; ++kc) {
           ah[kc].x &= ~CL_TAG;
@@ -1492,6 +1500,7 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_f32_kernel(const float* 
   int* xccs = cnt + CL_CNT_STRIDE;
   int* fault = cl + CL_CNT_INTS;
   uint4* hxb = (uint4*)((unsigned char*)cl + CL_OFF_HX);   // [tile][parity][32 chunks][64 lanes] x 16 bytes
+  const __amdgpu_buffer_rsrc_t hxr = cl_hx_rsrc(hxb);
   constexpr int ARRIVALS = CL_M;
   {
     const uint4* gu = (const uint4*)((const Frag*)Upack + (int64_t)s * 4 * R::NKC * 64);
@@ -1552,10 +1561,10 @@ __global__ __launch_bounds__(512) void lstm_fwd_cluster_f32_kernel(const float* 
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
     {
-      const uint4* hx = hxb + ((tile * 2 + ((t + 1) & 1)) * 32) * 64 + lane;
+      const unsigned hoff = (unsigned)((((tile * 2 + ((t + 1) & 1)) * 32) * 64 + lane) * 16);
       uint4 ah[R::NKC];
 #pragma unroll
-      for (int kc = 0; kc < R::NKC; ++kc) ah[kc] = ld_sc1(hx + kc * 64);
+      for (int kc = 0; kc < R::NKC; ++kc) ah[kc] = ld_sc1(hxr, hoff + kc * 1024);
       asm volatile("" ::: "memory");
       // next step's x W + b behind the h fragments (loads return in order): 4 requests, so the wait is a constant
       const float4* zn = (const float4*)zxaddr(t + 1 < steps ? rb + 1 : rb);

@@ -500,7 +500,8 @@ def test_muted_member_expires_the_tagged_waits_once(gpu_device, djenv):
 def test_muted_member_in_the_inference_pair_raises_described(gpu_device, djenv):
     """The same hook on the cooperative inference pair (generation's time axis: both layers in one launch, tagged
     exchange): the gate waves of every member run out of polls on the muted member's fragments, the output is NaN, the
-    census counts it and describes a wait of kind 'cooperative body, tagged' at step 3 with 14 of 16 fragments."""
+    census counts it and describes the first wait to run out: a gate wave on the muted member's fragments (kind
+    'cooperative body, tagged', step 3, 14 of 16) or the upper layer on the stalled lower layer's counter."""
     from music_generator_amd.engine import Engine
     for name in ("DEEPJ_TAGGED_EXCHANGE", "DEEPJ_CLUSTER", "DEEPJ_CLUSTER_PAIR", "DEEPJ_CLUSTER_COOP"):
         djenv.unset(name)
@@ -516,8 +517,11 @@ def test_muted_member_in_the_inference_pair_raises_described(gpu_device, djenv):
     print("muted pair:", rep)
     assert np.isnan(out).any() and rep["expired"] >= 4 and rep["misplaced"] == 0
     f = rep["first_expired"]
-    assert f is not None and f["kernel"].startswith("bf16 cooperative body, tagged") and f["step"] == 3
-    assert f["counter_seen"] == 14 and f["target"] == 16 and f["polls"] == 2 ** 17
+    assert f is not None and f["kernel"].startswith("bf16 cooperative body")
+    if "tagged" in f["kernel"]:          # a gate wave of the lower or the upper layer, on the muted member's fragments
+        assert f["step"] == 3 and f["counter_seen"] == 14 and f["target"] == 16 and f["polls"] == 2 ** 17
+    else:                                # or the upper layer first, on the counter of the (stalled) producing layer
+        assert f["producer_counter"] and f["polls"] == 2 ** 19
     assert eng.cluster_faults("muted pair (test)") == rep["expired"]
     djenv.unset("DEEPJ_DEBUG_CLUSTER_MUTE")
     out = eng.time_model_predict(flat, d(notes), d(beat), d(style)).float().cpu().numpy()
