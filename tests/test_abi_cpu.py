@@ -24,6 +24,18 @@ def test_library_exports_every_declared_symbol():
     assert bound <= set(names), bound - set(names)
 
 
+def test_kernel_flag_constants_match_the_header():
+    """Every DJ_KF_* bit of include/deepj_hip.h has the same value in the Python binding (music_generator_amd/_lib.py KF_*),
+    and no two flags share a bit."""
+    from music_generator_amd import _lib
+    header = open(os.path.join(ROOT, "include", "deepj_hip.h")).read()
+    flags = {n: int(v) for n, v in re.findall(r"#define DJ_KF_(\w+) (\d+)", header)}
+    assert len(flags) >= 10 and len(set(flags.values())) == len(flags)
+    for n, v in flags.items():
+        assert v & (v - 1) == 0, n
+        assert getattr(_lib, "KF_" + n) == v, n
+
+
 def test_no_kernel_of_the_library_uses_scratch_memory(tmp_path):
     """Code-object metadata of the built library: no kernel has a private segment (register spills, or a local array that
     ended up on the stack) except the two fp32 H = 256 BPTT instantiations, which are known and not
