@@ -248,7 +248,9 @@ int32_t dj_lstm_pack(int32_t dtype, int32_t H, const float* U, void* upack_fwd, 
  * (block (rb, cb) at element ((rb*(4H/32) + cb)*64 + lane)*16).  DJ_DTYPE_F32: the pre-activations z as fp32
  * (BPTT recomputes the activations).  DJ_DTYPE_BF16: the ACTIVATED gates as 8-bit codes, one byte per element --
  * i, f, o: code = clamp(ceil(254 y), 0, 255), decoded (code - 0.5)/254 clamped to [0,1], codes 0 / 255 reserved for
- * the saturated hard_sigmoid so that its derivative mask is exact; g: code = round(127 g) + 128 -- half the bytes of a
+ * the saturated hard_sigmoid so that its derivative mask is exact (computed as the saturating round-to-nearest
+ * conversion of 254 y + 0.49997: equal to the clamped ceil except for 254 y within 3e-5 above an integer);
+ * g: code = round(127 g) + 128 -- half the bytes of a
  * bf16 z stash on kernels that are HBM-bound on them.  dj_lstm_stash_bytes gives the buffer size for `rows` rows
  * (-1 for an unsupported dtype / H). */
 int64_t dj_lstm_stash_bytes(int32_t dtype, int32_t H, int64_t rows);

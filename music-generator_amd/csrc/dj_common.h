@@ -125,11 +125,18 @@ template <bool SIGM> __device__ __forceinline__ float dj_ract_grad(float x, floa
 // SATURATED hard_sigmoid, so its derivative mask (0.2 inside, 0 outside) is exact; g = tanh: code = round(127 g) + 128
 // (|error| <= 1/254).  (dj_lstm.hip GateEnc / GateDec are the persistent kernels' forms of the same code; these serve the
 // generic-width path: the cell epilogue of dj_gemm.hip writes, the gate kernel of dj_step.hip reads.)
+// What goes INTO v_cvt_pk_u8_f32, which saturates to [0, 255] and rounds to nearest-even (probed on the device): the code
+// ceil(v), v = 254 y, is cvt(v + 0.49997) -- no clamp, no ceil (round 4: 112 of the ~770 vector instructions of a forward
+// sweep step, and the sweep is issue-bound).  It differs from ceil(v) only for v within 3e-5 above an integer (the code is
+// then one less: the decoded value is 1.5 instead of at most 0.5 code steps off, once in ~30,000 gates) and, at the knees
+// of hard_sigmoid, for |z -+ 2.5| < 6e-7 (derivative mask of the neighbouring branch).  g: round(127 g) + 128 with ties to
+// even instead of up.
+constexpr float DJ_CODE_ROUND = 0.49997f;
 template <bool SIGM> __device__ __forceinline__ float dj_gate_code01(float z, float y) {
-  if constexpr (SIGM) return ceilf(y * 254.f);
-  return ceilf(__builtin_amdgcn_fmed3f(fmaf(z, 50.8f, 127.f), 0.f, 255.f));          // 254 (0.2 z + 0.5)
+  if constexpr (SIGM) return fmaf(y, 254.f, DJ_CODE_ROUND);
+  return fmaf(z, 50.8f, 127.f + DJ_CODE_ROUND);                                       // 254 (0.2 z + 0.5)
 }
-__device__ __forceinline__ float dj_gate_code_g(float g) { return floorf(fmaf(g, 127.f, 128.5f)); }
+__device__ __forceinline__ float dj_gate_code_g(float g) { return fmaf(g, 127.f, 128.f); }
 template <bool SIGM> __device__ __forceinline__ void dj_gate_dec01(float code, float& y, float& dy) {
   y = __builtin_amdgcn_fmed3f(fmaf(code, 1.f / 254.f, -0.5f / 254.f), 0.f, 1.f);
   if constexpr (SIGM) dy = y * (1.f - y);

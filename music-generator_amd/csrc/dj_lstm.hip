@@ -161,6 +161,8 @@ __device__ __forceinline__ void dj_lds_put2(bf16_t* p0, bf16_t* p1, float a, flo
 //               SATURATED hard_sigmoid, so its derivative mask (0.2 inside, 0 outside) is exact.  g = tanh in
 //               (-1,1): code = round(127 g) + 128 (|error| <= 1/254).  The forward values themselves are not
 //               quantised -- only what BPTT reads back.
+//               (The codes are produced by v_cvt_pk_u8_f32 itself -- saturating, round-to-nearest -- from 254 y + 0.49997:
+//               dj_common.h dj_gate_code01; equal to the clamped ceil except in a band of 3e-5 above every integer.)
 template <typename T> struct StashT { using type = float; };
 template <> struct StashT<bf16_t> { using type = uint8_t; };
 template <typename T> using StashElem = typename StashT<T>::type;
@@ -177,16 +179,13 @@ template <bool SIGM> struct GateEnc<float, SIGM> {
 template <bool SIGM> struct GateEnc<bf16_t, SIGM> {
   static constexpr int STORES = 1;
   uint32_t w[4][4] = {};
-  static __device__ __forceinline__ float code01(float z, float y) {
-    if constexpr (SIGM) return ceilf(y * 254.f);                                          // y in [0,1]
-    return ceilf(__builtin_amdgcn_fmed3f(fmaf(z, 50.8f, 127.f), 0.f, 255.f));              // 254 (0.2 z + 0.5)
-  }
+  static __device__ __forceinline__ float code01(float z, float y) { return dj_gate_code01<SIGM>(z, y); }   // dj_common.h
   __device__ __forceinline__ void put(int r, float zi, float zf, float, float zo, float ig, float fg, float gg,
                                       float og) {
     const int d = r >> 2, b = r & 3;
     w[0][d] = __builtin_amdgcn_cvt_pk_u8_f32(code01(zi, ig), b, w[0][d]);
     w[1][d] = __builtin_amdgcn_cvt_pk_u8_f32(code01(zf, fg), b, w[1][d]);
-    w[2][d] = __builtin_amdgcn_cvt_pk_u8_f32(floorf(fmaf(gg, 127.f, 128.5f)), b, w[2][d]);
+    w[2][d] = __builtin_amdgcn_cvt_pk_u8_f32(dj_gate_code_g(gg), b, w[2][d]);
     w[3][d] = __builtin_amdgcn_cvt_pk_u8_f32(code01(zo, og), b, w[3][d]);
   }
   __device__ __forceinline__ void store(int g, uint8_t* p) const { *(uint4*)p = make_uint4(w[g][0], w[g][1], w[g][2], w[g][3]); }
