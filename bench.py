@@ -440,6 +440,35 @@ def pmc_category(name):
     return None
 
 
+def device_identity(dev):
+    """A number that differs between two physical GPUs of this node: the device's UUID where torch exposes it, else
+    its PCI address (domain : bus : device)."""
+    import hashlib
+    p = torch.cuda.get_device_properties(dev)
+    ident = getattr(p, "uuid", None)
+    ident = str(ident) if ident is not None else ""
+    if not ident.strip("0-"):
+        ident = "pci %s:%s:%s" % (getattr(p, "pci_domain_id", "?"), getattr(p, "pci_bus_id", "?"),
+                                  getattr(p, "pci_device_id", "?"))
+    return int.from_bytes(hashlib.sha256(ident.encode()).digest()[:7], "little"), ident
+
+
+def multi_gpu_evidence(dist, dev, world, elapsed_local, steps):
+    """What lets the reader of an N > 1 line check that the collective really spanned N GPUs: the number of
+    DISTINCT physical devices among the ranks (all-gathered device identities; N in a real run, 1 in the one-GPU rehearsal)
+    and every rank's own time per step before the closing barrier (the timed region ends at the slowest rank)."""
+    ident, _ = device_identity(dev)
+    mine = torch.tensor([float(ident & 0xFFFFFF), float((ident >> 24) & 0xFFFFFF), float(ident >> 48),
+                         elapsed_local / steps * 1e3], dtype=torch.float64, device=dev)
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    rows = [p.cpu().tolist() for p in parts]
+    ms = [r[3] for r in rows]
+    return {"devices_distinct": len({tuple(r[:3]) for r in rows}),
+            "rank_ms_per_step": {"min": round(min(ms), 3), "max": round(max(ms), 3),
+                                 "all": [round(v, 3) for v in ms]}}
+
+
 def self_launch(argv, gpus):
     """`python bench.py --gpus N` without a launcher: start the ranks ourselves.  The parent has not touched the GPU
     (nothing above calls into HIP), so the ranks are fresh CHILD processes of `python -m torch.distributed.run`
@@ -560,6 +589,7 @@ def main():
         for i in range(args.steps):
             loss = step(args.warmup + i)
         torch.cuda.synchronize()
+        elapsed_local = time.perf_counter() - t0         # this rank's own K steps (its last collective included)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -575,29 +605,31 @@ def main():
             torch.cuda.synchronize()
             post = read_profile(lib, post_steps)
             lib.dj_profile_enable(0)
-        faults = eng.cluster_faults()
+        faults = local_faults = eng.cluster_faults()
         if world > 1:
             f = torch.tensor([float(faults)], dtype=torch.float64, device=dev)
             dist.all_reduce(f)
             faults = int(f.cpu()[0])
+        # describe a fault only when THIS rank's census of THIS run saw one (an older `last_fault` is not this run's)
+        from music_generator_amd.engine import describe_fault_report
+        what = describe_fault_report(eng.last_fault) if local_faults and eng.last_fault else "reported by another rank"
         if not faults or attempt == 1:
             break
         fallback_faults = faults
         if rank == 0:
-            from music_generator_amd.engine import describe_fault_report
-            what = describe_fault_report(eng.last_fault) if getattr(eng, "last_fault", None) else "reported by another rank"
             print(f"[bench] {faults} cluster faults in the timed run ({what}): repeating it on the per-tile kernels "
                   "(DJ_KF_NO_CLUSTER)", file=sys.stderr, flush=True)
+        eng.close()
         del eng, step
     if faults or not np.isfinite(final_loss):
-        from music_generator_amd.engine import describe_fault_report
-        what = describe_fault_report(eng.last_fault) if getattr(eng, "last_fault", None) else "no description"
         raise SystemExit(f"invalid run: {faults} cluster faults ({what}), final loss {final_loss} -- no number is "
                          "reported (DEEPJ_CLUSTER=0 selects the per-tile kernel)")
+    multi = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.cpu()[0])
+        multi = multi_gpu_evidence(dist, dev, world, elapsed_local, args.steps)
 
     kernels = {}
     roof = roof_all = None
@@ -676,12 +708,14 @@ def main():
                                       "faults in a first timed run"} if fallback_faults else {})},
             "model_tflops_per_s": round(flops_step * world * args.steps / elapsed / 1e12, 2),
             "final_loss": round(final_loss, 5),
+            **(multi or {}),
             "roofline": roof, "kernel_ms_per_step": kernels, "kernel_rates": roof_all,
             "kernel_ms_source": (None if args.no_profile else
                                  f"HIP events (dj_profile_*): '{dom_cat}' over the {args.steps} timed steps (the only "
                                  f"launches that carry events there: events around every launch cost ~0.2 ms per "
                                  f"step); the other categories over {post_steps} untimed steps behind the timed region"),
         }
+        eng.close()
         del eng
         torch.cuda.empty_cache()
         def leg(fn):

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define DJ_ABI_VERSION 4
+#define DJ_ABI_VERSION 5
 #define DJ_DTYPE_F32 0  /* fp32 operands, v_mfma_f32_32x32x2_f32 (parity mode)            */
 #define DJ_DTYPE_BF16 1 /* bf16 operands/stash, fp32 accumulate + cell state (throughput) */
 
@@ -316,6 +316,8 @@ int32_t dj_workspace_cluster_faults(const dj_config* cfg, void* workspace, int64
  *   [4] waits that saw two consecutive polls > 2^20 shader cycles apart, [5] the longest poll-to-poll gap seen in units
  *       of 1024 cycles -- the STALL CENSUS: cumulative over the life of the workspace, filled in healthy runs too; a
  *       gap of milliseconds between two polls of a wave means the wave was off the device
+ *   [6] polls at which the shader clock read LOWER than at the poll before (the clock is per XCC: the wave was saved
+ *       and restored on another one in the middle of a wait); such differences never enter [4] / [5] (ABI 5)
  *   [8] != 0: [9..17] describe the first expired wait since the last census: [9] kind << 24 | cluster << 12 |
  *       member << 8 | wave (bit 28: the wait was for the producing layer's counter), [10] recurrence step (-1: round
  *       0), [11] counter value seen last, [12] target, [13] polls made, [14..15] shader cycles between first and last
@@ -325,6 +327,12 @@ int32_t dj_workspace_cluster_faults(const dj_config* cfg, void* workspace, int64
 #define DJ_FAULT_REPORT_WORDS 32
 int32_t dj_workspace_cluster_fault_report(const dj_config* cfg, void* workspace, int64_t workspace_bytes,
                                           int32_t* words_host, void* stream);
+/* Census and report in ONE blocking round trip (ABI 5): words_host receives the fault line as dj_workspace_cluster_fault_report
+ * returns it, the counts and the description are reset by a kernel queued on `stream` behind the copy (nothing waits
+ * for it), and the number of events is returned (0 in a healthy run, -1 on a HIP or argument error).  What
+ * engine.Engine.cluster_faults() calls after every predict / generation chunk (Model.predict of generate.py:108,114). */
+int32_t dj_workspace_cluster_faults_take(const dj_config* cfg, void* workspace, int64_t workspace_bytes,
+                                         int32_t* words_host, void* stream);
 /* The same census without a host round trip: a one-thread kernel on `stream` ADDS (as floats) the event count to
  * out_dev[0], the expired waits to out_dev[1] and the misplaced workgroups to out_dev[2], and resets the counts (not
  * the description of the first expired wait) -- put out_dev next to the loss and one device-to-host copy per training

@@ -41,6 +41,7 @@ _SIGS = {
     "dj_style_embedding": (C.c_int32, [C.POINTER(DjConfig), _P, _P, C.c_int32, _P, _P]),
     "dj_workspace_cluster_fault_report": (C.c_int32, [C.POINTER(DjConfig), _P, C.c_int64, C.POINTER(C.c_int32), _P]),
     "dj_workspace_faults_async": (C.c_int32, [C.POINTER(DjConfig), _P, C.c_int64, _P, _P]),
+    "dj_workspace_cluster_faults_take": (C.c_int32, [C.POINTER(DjConfig), _P, C.c_int64, C.POINTER(C.c_int32), _P]),
     "dj_param_count": (C.c_int64, [C.POINTER(DjConfig)]),
     "dj_param_info": (C.c_int32, [C.POINTER(DjConfig), C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64),
                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -117,7 +118,7 @@ def load():
             raise DeepJError(f"{LIB_PATH} does not export {name}")
         fn.restype = res
         fn.argtypes = args
-    if lib.dj_abi_version() != 4:
+    if lib.dj_abi_version() != 5:
         raise DeepJError("libdeepj_hip.so ABI version mismatch")
     if lib.dj_config_size() != C.sizeof(DjConfig):
         raise DeepJError("dj_config layout mismatch: library %d bytes, binding %d" % (lib.dj_config_size(), C.sizeof(DjConfig)))

@@ -1042,6 +1042,14 @@ int32_t dj_workspace_cluster_fault_report(const dj_config* cfg, void* ws, int64_
   if (!(p.Ht == 256 || p.Hn == 256)) return 0;
   return dj_lstm_cluster_fault_line((char*)ws + p.w_cluster, words_host, (hipStream_t)stream);
 }
+int32_t dj_workspace_cluster_faults_take(const dj_config* cfg, void* ws, int64_t ws_bytes, int32_t* words_host,
+                                         void* stream) {
+  Plan p;
+  if (!words_host || make_plan(cfg, p) || check_ws(p, ws, ws_bytes)) return -1;
+  memset(words_host, 0, DJ_FAULT_REPORT_WORDS * sizeof(int32_t));
+  if (!(p.Ht == 256 || p.Hn == 256)) return 0;
+  return dj_lstm_cluster_faults_take((char*)ws + p.w_cluster, words_host, (hipStream_t)stream);
+}
 int32_t dj_lstm_pack_wt(int32_t dtype, int32_t H, const float* W, int32_t D, void* out, void* stream) {
   return dj_launch_lstm_pack_wt(dtype, H, W, D, out, (hipStream_t)stream);
 }

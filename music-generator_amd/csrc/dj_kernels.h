@@ -138,6 +138,7 @@ int64_t dj_lstm_cluster_scratch_bytes_impl();
 // tiles carry NaN), -1 on a HIP error; drains `st` (asynchronous copy on the caller's stream + synchronise: a blocking
 // copy on the null stream does not order against a non-blocking stream)
 int dj_lstm_cluster_faults_impl(void* cluster_scratch, hipStream_t st);
+int dj_lstm_cluster_faults_take(void* cluster_scratch, int32_t* words_host, hipStream_t st);
 // device address of the fault line inside a cluster scratch (32 ints; layout in dj_lstm.hip, "bounded exchange waits")
 void* dj_lstm_cluster_fault_words(void* cluster_scratch);
 // copy of that line as it stands once `st` has drained; resets nothing

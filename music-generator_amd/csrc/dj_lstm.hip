@@ -721,6 +721,7 @@ __device__ __forceinline__ void cl_load_x(ClXRegs<NR>& q, const bf16_t* xb, int 
 //   [2] test hook (DJ_KF_DEBUG_CLUSTER_FAULT)
 //   [4] waits that saw two consecutive polls more than CL_GAP_STALL cycles apart   } stall census: cumulative, never
 //   [5] the longest poll-to-poll gap seen, in units of 1024 shader cycles          } reset by the fault census
+//   [6] polls at which the shader clock had gone BACKWARDS since the poll before (wave restored on another XCC)
 //   [8] 1 = words 9..20 describe the FIRST expired wait since the host last took the census:
 //       [9] who (kind << 24 | cluster << 12 | member << 8 | wave; kind 1 = bf16 sweep, 2 = cooperative body, 3 = fp32, 4 / 7 = bf16 sweep / cooperative body waiting for
 //       TAGGED h fragments ([11] = fragments that had arrived, [12] = 16),
@@ -745,16 +746,28 @@ constexpr unsigned CL_WAIT_POLLS = 1u << 19;
 constexpr unsigned CL_WAIT_POLLS_TAGGED = 1u << 17;    // a tagged poll (up to 16 fragment loads, every wave of the cluster
                                                        // at it) measured 1,660 cycles: again ~0.1 s of polling
 constexpr unsigned CL_GAP_NOTE = 1u << 17, CL_GAP_STALL = 1u << 20;   // ~60 us / ~0.5 ms at 2.1 GHz
-enum { CLF_EXPIRED = 0, CLF_MISPLACED = 1, CLF_HOOK = 2, CLF_STALLS = 4, CLF_MAXGAP = 5, CLF_DIAG = 8, CLF_WORDS = 32 };
+enum { CLF_EXPIRED = 0, CLF_MISPLACED = 1, CLF_HOOK = 2, CLF_STALLS = 4, CLF_MAXGAP = 5, CLF_BACK = 6, CLF_DIAG = 8, CLF_WORDS = 32 };
 constexpr int CLW_GATE = 1 << 28;
 __device__ __forceinline__ int cl_who(int kind, int cid, int member, int wave) {
   return kind << 24 | (cid & 0xfff) << 12 | (member & 15) << 8 | (wave & 255);
 }
-// stall census of a finished wait (rare: a healthy poll returns within microseconds)
-__device__ __forceinline__ void cl_note_gap(int* fault, unsigned maxgap, int lane) {
-  if (maxgap > CL_GAP_NOTE && lane == 0) {
-    atomicMax(fault + CLF_MAXGAP, (int)(maxgap >> 10));
+// stall census of a finished wait (rare: a healthy poll returns within microseconds).  `back` = polls of this wait at
+// which the shader clock read LOWER than at the poll before: s_memtime is per XCC, and a wave that was saved and restored
+// on another XCC in the middle of a wait continues on that XCC's counter.  Such a difference says "the wave was moved",
+// not how long it was away, so it is counted in a word of its own (CLF_BACK) and never enters the longest gap (until
+// round 5 the unsigned difference turned it into a "gap" of ~2^32 cycles; a true gap beyond 2^31 cycles -- a second --
+// is counted here as well).
+__device__ __forceinline__ void cl_gap_step(unsigned now, unsigned& last, unsigned& maxgap, unsigned& back) {
+  const int d = (int)(now - last);
+  last = now;
+  if (d < 0) ++back;
+  else maxgap = (unsigned)d > maxgap ? (unsigned)d : maxgap;
+}
+__device__ __forceinline__ void cl_note_gap(int* fault, unsigned maxgap, unsigned back, int lane) {
+  if ((maxgap > CL_GAP_NOTE || back) && lane == 0) {
+    if (maxgap > CL_GAP_NOTE) atomicMax(fault + CLF_MAXGAP, (int)(maxgap >> 10));
     if (maxgap > CL_GAP_STALL) atomicAdd(fault + CLF_STALLS, 1);
+    if (back) atomicAdd(fault + CLF_BACK, (int)back);
   }
 }
 // an expired wait: counted, and the first one since the last census described (words CLF_DIAG ..)
@@ -782,17 +795,14 @@ __device__ __forceinline__ int cl_wait(int* cnt, int target, int* fault, int who
   int v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   if (v >= target) return v;
   const unsigned long long t0 = __builtin_readcyclecounter();
-  unsigned last = (unsigned)t0, maxgap = 0, polls = 0;
+  unsigned last = (unsigned)t0, maxgap = 0, polls = 0, back = 0;
 #pragma nounroll
   do {
     __builtin_amdgcn_s_sleep(2);
     v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const unsigned now = (unsigned)__builtin_readcyclecounter();
-    const unsigned gap = now - last;
-    last = now;
-    maxgap = gap > maxgap ? gap : maxgap;
+    cl_gap_step((unsigned)__builtin_readcyclecounter(), last, maxgap, back);
   } while (v < target && ++polls < CL_WAIT_POLLS);     // the last poll is always looked at before giving up
-  cl_note_gap(fault, maxgap, lane);
+  cl_note_gap(fault, maxgap, back, lane);
   if (v >= target) return v;
   cl_note_expired(fault, who, t, v, target, polls, t0, maxgap, lane);
   return -1;
@@ -832,7 +842,7 @@ template <int NKC>
 __device__ __forceinline__ bool cl_wait_tagged(__amdgpu_buffer_rsrc_t hxr, unsigned hoff, uint4 (&ah)[NKC], unsigned e, int* cnt,
                                                int* fault, int who, int t, int lane, bool& dead) {
   const unsigned long long t0 = __builtin_readcyclecounter();
-  unsigned last = (unsigned)t0, maxgap = 0, polls = 0;
+  unsigned last = (unsigned)t0, maxgap = 0, polls = 0, back = 0;
   int nstale;
 #pragma nounroll
   do {
@@ -843,12 +853,9 @@ __device__ __forceinline__ bool cl_wait_tagged(__amdgpu_buffer_rsrc_t hxr, unsig
     nstale = 0;
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) nstale += __any(cl_piece_stale(ah[kc], e) != 0) ? 1 : 0;
-    const unsigned now = (unsigned)__builtin_readcyclecounter();
-    const unsigned gap = now - last;
-    last = now;
-    maxgap = gap > maxgap ? gap : maxgap;
+    cl_gap_step((unsigned)__builtin_readcyclecounter(), last, maxgap, back);
   } while (nstale && ++polls < CL_WAIT_POLLS_TAGGED);
-  cl_note_gap(fault, maxgap, lane);
+  cl_note_gap(fault, maxgap, back, lane);
   if (!nstale) return false;
   cl_note_expired(fault, who, t, NKC - nstale, NKC, polls, t0, maxgap, lane);     // "counter" = fragments that did arrive
   if (lane == 0) __hip_atomic_fetch_or(cnt, CL_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2197,38 +2204,27 @@ int cluster_cus() {
 // replay a memset node followed by the cluster kernel was observed to take effect AFTER the kernel's round-0 arrivals
 // in some replay histories (ROCm 7.2; every wait of that launch then expires: DESIGN.md section 8, round 3) -- kernel ->
 // kernel edges do not have that problem.
-__global__ void cl_reset_kernel(uint4* p) { p[blockIdx.x * 256 + threadIdx.x] = make_uint4(0, 0, 0, 0); }
-int cluster_reset(void* scratch, hipStream_t st) {
-  static_assert(CL_OFF_FAULT % (256 * 16) == 0, "reset grid");
-  hipLaunchKernelGGL(cl_reset_kernel, dim3(CL_OFF_FAULT / (256 * 16)), dim3(256), 0, st, (uint4*)scratch);
-  return (int)hipGetLastError();
+// The same launch writes the TEST HOOK word of the fault line (word 2), from the caller's DJ_KF_DEBUG_* bits, so that the
+// fault handling can be exercised on hardware, deterministically: DJ_KF_DEBUG_CLUSTER_FAULT (bit 0 of the word): the
+// launch fails its placement check (fallback in fit, errors in predict / generation); DJ_KF_DEBUG_CLUSTER_LATE (bit 1):
+// the last member of every cluster never arrives in round 0, so every other wave's bound really runs out -- once
+// (poison bit, sticky), which the launch duration shows; DJ_KF_DEBUG_CLUSTER_MUTE (bit 2): the last member of every
+// cluster stops publishing its h slices at step 2 of a tagged sweep, so every wave's bound runs out on the fragments of
+// step 2 -- all at once, and no poisoned wave waits again.  The word is (re)written in front of EVERY cluster launch:
+// no host-side memory of which scratch is armed (until round 5 a process-static table of 16 scratch addresses mirrored
+// the word and could disagree with it -- after dj_workspace_init had zeroed the line, after an armed engine had died,
+// under graph capture).
+__global__ void cl_reset_kernel(uint4* p, int* hook, int v) {
+  p[blockIdx.x * 256 + threadIdx.x] = make_uint4(0, 0, 0, 0);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *hook = v;
 }
-// Test hooks (word 2 of the fault line), so that the fault handling can be exercised on hardware, deterministically:
-// DJ_KF_DEBUG_CLUSTER_FAULT (bit 0 of the word): the next launches fail their placement check (fallback in fit, errors
-// in predict / generation); DJ_KF_DEBUG_CLUSTER_LATE (bit 1): the last member of every cluster never arrives in round 0,
-// so every other wave's bound really runs out -- once (poison bit, sticky), which the launch duration shows;
-// DJ_KF_DEBUG_CLUSTER_MUTE (bit 2): the last member of every cluster stops publishing its h slices at step 2 of a tagged
-// sweep, so every wave's bound runs out on the fragments of step 2 -- all at once, and no poisoned wave waits again.
-__global__ void cl_hook_kernel(int* f, int v) { f[CLF_HOOK] = v; }
-int cluster_fault_hook(void* scratch, uint32_t kf, hipStream_t st) {
-  static void* armed[16] = {};                        // scratches whose hook word is set (a handful of engines at most)
-  static int armed_v[16] = {};
+int cluster_reset(void* scratch, uint32_t kf, hipStream_t st) {
+  static_assert(CL_OFF_FAULT % (256 * 16) == 0, "reset grid");
   const int want = ((kf & DJ_KF_DEBUG_CLUSTER_FAULT) ? 1 : 0) | ((kf & DJ_KF_DEBUG_CLUSTER_LATE) ? 2 : 0) |
                    ((kf & DJ_KF_DEBUG_CLUSTER_MUTE) ? 4 : 0);
-  int slot = -1, free_slot = -1;
-  for (int i = 0; i < 16; ++i) {
-    if (armed[i] == scratch) slot = i;
-    if (!armed[i] && free_slot < 0) free_slot = i;
-  }
-  if (slot < 0 && !want) return 0;
-  if (slot >= 0 && armed_v[slot] == want) return 0;
-  if (slot < 0) slot = free_slot;
-  if (slot < 0) return 1018;
-  hipLaunchKernelGGL(cl_hook_kernel, dim3(1), dim3(1), 0, st, (int*)((char*)scratch + CL_OFF_FAULT), want);
-  if (hipGetLastError() != hipSuccess) return 1018;
-  armed[slot] = want ? scratch : nullptr;
-  armed_v[slot] = want;
-  return 0;
+  hipLaunchKernelGGL(cl_reset_kernel, dim3(CL_OFF_FAULT / (256 * 16)), dim3(256), 0, st, (uint4*)scratch,
+                     (int*)((char*)scratch + CL_OFF_FAULT) + CLF_HOOK, want);
+  return (int)hipGetLastError();
 }
 int launch_fwd_cluster(int ntiles, int steps, const void* X, int DP, int NKX, const void* Wpack, const float* bias,
                        void* Zst, const void* Upack, void* Hout, void* Cout, int sigm, void* scratch, uint32_t kf,
@@ -2238,8 +2234,7 @@ int launch_fwd_cluster(int ntiles, int steps, const void* X, int DP, int NKX, co
     return 1016;
   const size_t smem = (size_t)(4 * NKX * 64 + 4 * R::NKC * 64) * 16 + (size_t)8 * 4096;
   // counters and XCC ids of every cluster start at zero in every launch (cl_reset_kernel: a kernel node under graph capture)
-  if (int rc = cluster_reset(scratch, st)) return rc;
-  if (int rc = cluster_fault_hook(scratch, kf, st)) return rc;
+  if (int rc = cluster_reset(scratch, kf, st)) return rc;
   // the h slices announce themselves by their tags ("TAGGED exchange" above) unless the caller asks for the counted protocol
   if (kf & DJ_KF_COUNTED_EXCHANGE)
     return sigm ? launch_fwd_cluster_s<true, false>(ntiles, steps, X, DP, NKX, Wpack, bias, Zst, Upack, Hout, Cout, smem, scratch, st)
@@ -2268,8 +2263,7 @@ int launch_fwd_cluster_pair(int ntiles, int steps, const ClPairArgs& a, int sigm
     }
     attr_done = true;
   }
-  if (int rc = cluster_reset(scratch, st)) return rc;
-  if (int rc = cluster_fault_hook(scratch, kf, st)) return rc;
+  if (int rc = cluster_reset(scratch, kf, st)) return rc;
   // at most one tile per cluster (8 clusters per layer): the cooperative body, four waves per tile
   const bool coop_off = (kf & DJ_KF_NO_CLUSTER_COOP) != 0;
   const bool coop = ntiles <= 8 && !coop_off;
@@ -2307,8 +2301,7 @@ int dj_launch_lstm_fwd_cluster_f32(int ntiles, int steps, const void* Zx, const 
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  if (int rc = cluster_reset(scratch, st)) return rc;
-  if (int rc = cluster_fault_hook(scratch, kf, st)) return rc;
+  if (int rc = cluster_reset(scratch, kf, st)) return rc;
   if (sigm)
     hipLaunchKernelGGL((lstm_fwd_cluster_f32_kernel<true>), dim3(64), dim3(512), smem, st, (const float*)Zx,
                        (const float*)Upack, (float*)Hout, steps, (int*)scratch, ntiles);
@@ -2399,15 +2392,23 @@ int dj_lstm_cluster_fault_line(void* scratch, int32_t* words_host, hipStream_t s
                                     hipMemcpyDeviceToHost, st); e != hipSuccess) return (int)e;
   return (int)hipStreamSynchronize(st);
 }
+// One blocking round trip: the fault line as it stands once `st` has drained (into words_host), and -- when it holds
+// counts or a description -- a clear kernel queued behind it on the same stream (nothing waits for it: later work on
+// `st` is ordered behind it anyway).  Returns the number of events, -1 on a HIP error.
+int dj_lstm_cluster_faults_take(void* scratch, int32_t* words_host, hipStream_t st) {
+  if (!scratch || !words_host) return -1;
+  if (dj_lstm_cluster_fault_line(scratch, words_host, st)) return -1;
+  const int32_t* w = words_host;
+  if (w[CLF_EXPIRED] || w[CLF_MISPLACED] || w[CLF_DIAG]) {
+    hipLaunchKernelGGL(cl_fault_clear_kernel, dim3(1), dim3(64), 0, st, (int*)((char*)scratch + CL_OFF_FAULT));
+    if (hipGetLastError() != hipSuccess) return -1;
+  }
+  return w[CLF_EXPIRED] + w[CLF_MISPLACED];
+}
 int dj_lstm_cluster_faults_impl(void* scratch, hipStream_t st) {
   if (!scratch) return 0;
   int32_t w[CLF_WORDS];
-  if (dj_lstm_cluster_fault_line(scratch, w, st)) return -1;
-  if (w[CLF_EXPIRED] || w[CLF_MISPLACED] || w[CLF_DIAG]) {
-    hipLaunchKernelGGL(cl_fault_clear_kernel, dim3(1), dim3(64), 0, st, (int*)((char*)scratch + CL_OFF_FAULT));
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
-  }
-  return w[CLF_EXPIRED] + w[CLF_MISPLACED];
+  return dj_lstm_cluster_faults_take(scratch, w, st);
 }
 int dj_launch_lstm_fwd_fused(int dtype, int H, int ntiles, int steps, const void* X, int DP, int NKX,
                              const void* Wpack, const float* bias, void* Zst, const void* Upack, void* Hout,

@@ -128,9 +128,58 @@ def _stream_ptr():
 # not inject (tests/conftest.py), so a recurrence on the driver's box cannot hide behind a fallback.
 FAULT_LOG: list = []
 _LIVE = weakref.WeakSet()          # engines alive in this process
-# Stall census of the engines that have been destroyed (Engine.__del__ reads the fault line once more): how many there
+# Stall census of the engines that have been released (Engine.close(), or drain_pending() for those that died unclosed,
+# read the fault line once more): how many there
 # were, the most waits any of them saw with polls > 2^20 cycles apart, the longest gap between two polls of a wait.
-CENSUS = {"engines": 0, "stalled_waits": 0, "max_poll_gap_cycles": 0}
+CENSUS = {"engines": 0, "stalled_waits": 0, "max_poll_gap_cycles": 0, "backward_clock_polls": 0}
+
+# Workspaces of engines that were garbage-collected without close(): (lib, cfg, tensor, pointer, bytes, device, meta).
+# Engine.__del__ only appends here (no HIP work in a finalizer); drain_pending() takes their census at a safe point.
+_PENDING: list = []
+
+
+def _census_of_workspace(lib, c, ws_ptr, ws_bytes, device, log):
+    """Stall census -> CENSUS, unread fault counts -> FAULT_LOG (through `log(what, report, events)`), for a workspace
+    that is about to be released.  Blocking (one copy of the fault line on the current stream)."""
+    words = (C.c_int32 * _lib.FAULT_REPORT_WORDS)()
+    try:
+        with torch.cuda.device(device):
+            rc = lib.dj_workspace_cluster_fault_report(C.byref(c), ws_ptr, ws_bytes, words, _stream_ptr())
+    except Exception:
+        return
+    if rc != 0:
+        return
+    rep = decode_fault_report(words)
+    CENSUS["engines"] += 1
+    CENSUS["stalled_waits"] = max(CENSUS["stalled_waits"], rep["stalled_waits"])
+    CENSUS["max_poll_gap_cycles"] = max(CENSUS["max_poll_gap_cycles"], rep["max_poll_gap_cycles"])
+    CENSUS["backward_clock_polls"] = max(CENSUS["backward_clock_polls"], rep["backward_clock_polls"])
+    if rep["expired"] or rep["misplaced"]:
+        log("unread when the engine was destroyed", rep, rep["expired"] + rep["misplaced"])
+
+
+def drain_pending():
+    """Census of the engines that died without close() (see Engine.__del__), then their workspaces are freed.  Called
+    from Engine(), Engine.close(), the test fixture and bench.py; does nothing while the current stream is being
+    captured into a graph (the copy would invalidate the capture) -- the entries wait for the next call."""
+    if not _PENDING:
+        return 0
+    try:
+        if torch.cuda.is_current_stream_capturing():
+            return 0
+    except Exception:
+        return 0
+    n = 0
+    while _PENDING:
+        lib, c, ws, ws_ptr, ws_bytes, device, meta = _PENDING.pop()
+
+        def log(what, rep, events, meta=meta):
+            FAULT_LOG.append(dict(rep, what=what, events=int(events), **meta))
+        _census_of_workspace(lib, c, ws_ptr, ws_bytes, device, log)
+        del ws
+        n += 1
+    return n
+
 
 _WAIT_KINDS = {1: "bf16 sweep", 2: "bf16 cooperative body", 3: "fp32 inference sweep",
                4: "bf16 sweep, tagged h fragments (counter = fragments that had arrived)", 5: "pair BPTT (tools)",
@@ -141,7 +190,7 @@ _WAIT_KINDS = {1: "bf16 sweep", 2: "bf16 cooperative body", 3: "fp32 inference s
 def decode_fault_report(words):
     """dj_workspace_cluster_fault_report words -> dict (include/deepj_hip.h DJ_FAULT_REPORT_WORDS)."""
     w = [int(v) for v in words]
-    rep = {"expired": w[0], "misplaced": w[1], "hook": w[2], "stalled_waits": w[4], "max_poll_gap_cycles": w[5] << 10,
+    rep = {"expired": w[0], "misplaced": w[1], "hook": w[2], "stalled_waits": w[4], "max_poll_gap_cycles": w[5] << 10, "backward_clock_polls": w[6],
            "first_expired": None}
     if w[8]:
         who = w[9] & 0xFFFFFFFF
@@ -164,9 +213,10 @@ def describe_fault_report(rep):
                 % (f["kernel"], f["cluster"], f["member"], f["wave"], f["xcc"], f["step"],
                    " on the producing layer's counter" if f["producer_counter"] else "", f["counter_seen"], f["target"],
                    f["polls"], f["elapsed_cycles"], f["max_poll_gap_cycles"]))
-    if rep.get("stalled_waits"):
-        txt += "; stall census of this workspace: %d waits with polls > 2^20 cycles apart, longest gap %d cycles" % (
-            rep["stalled_waits"], rep["max_poll_gap_cycles"])
+    if rep.get("stalled_waits") or rep.get("backward_clock_polls"):
+        txt += ("; stall census of this workspace: %d waits with polls > 2^20 cycles apart, longest gap %d cycles, %d polls "
+                "behind a shader clock that had gone backwards (wave restored on another XCC)"
+                % (rep["stalled_waits"], rep["max_poll_gap_cycles"], rep.get("backward_clock_polls", 0)))
     return txt
 
 
@@ -175,8 +225,11 @@ class Engine:
 
     def __init__(self, cfg: DeepJConfig, batch: int, time_steps: int | None = None, device="cuda:0",
                  input_dropout: float = 0.0, dropout: float = 0.0, kernel_flags: int = 0, fuse_xw_min_tiles: int = 0):
+        self._closed = True                              # until the workspace exists (see __del__)
+        self.ws = None
         if not torch.cuda.is_available():
             raise _lib.DeepJError("no HIP device visible: the DeepJ engine has no CPU path")
+        drain_pending()                                  # workspaces of engines that died unclosed: census, then free
         self.lib = _lib.load()
         self.cfg = cfg
         self.device = torch.device(device)
@@ -199,22 +252,38 @@ class Engine:
         # all of it (dj_workspace_faults_async)
         self.loss = torch.zeros(4, dtype=torch.float32, device=self.device)
         self.last_fault = None                           # the newest FAULT_LOG entry of this engine
+        self.fault_of_last_take = None                   # ... and the one the last take_async_faults() made, if any
+        self._closed = False
         _LIVE.add(self)
 
+    def close(self):
+        """Last look at the fault line, then release the workspace: the stall census goes to the module's CENSUS, counts
+        nobody read to FAULT_LOG.  Idempotent.  This is the only place where a dying engine does HIP work -- call it
+        from the owner (Model.close, bench.py, the test fixture), never from a finalizer."""
+        if self._closed:
+            return
+        self._closed = True
+        _LIVE.discard(self)
+        _census_of_workspace(self.lib, self.c, self.ws_ptr, self.ws_bytes, self.device, self._log_faults)
+        self.ws = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def __del__(self):
-        # last look at the fault line: the stall census goes to the module's CENSUS, counts nobody read to FAULT_LOG
-        # (not while the interpreter is shutting down: no HIP calls from a finalizer then)
+        # NO HIP call here: a finalizer runs wherever the collector does -- on another thread, inside somebody's
+        # torch.cuda.graph capture (a synchronise there invalidates the capture).  An engine that dies unclosed only
+        # hands its workspace to _PENDING; drain_pending() reads the fault line at the next safe point (Engine(),
+        # close(), the test fixture, bench.py).
         try:
-            import sys
-            if sys is None or sys.is_finalizing():
-                return
-            rep = self.cluster_fault_report()
-            CENSUS["engines"] += 1
-            CENSUS["stalled_waits"] = max(CENSUS["stalled_waits"], rep["stalled_waits"])
-            CENSUS["max_poll_gap_cycles"] = max(CENSUS["max_poll_gap_cycles"], rep["max_poll_gap_cycles"])
-            if rep["expired"] or rep["misplaced"]:
-                self._log_faults("unread when the engine was destroyed", rep, rep["expired"] + rep["misplaced"])
-        except Exception:                                # interpreter / HIP runtime shutting down
+            if not getattr(self, "_closed", True) and self.ws is not None:
+                self._closed = True
+                _PENDING.append((self.lib, self.c, self.ws, self.ws_ptr, self.ws_bytes, self.device, self._fault_meta()))
+        except Exception:                                # interpreter shutting down
             pass
 
     def set_kernel_flags(self, flags: int):
@@ -233,38 +302,48 @@ class Engine:
                                                                   _stream_ptr()), "dj_workspace_cluster_fault_report")
         return decode_fault_report(words)
 
+    def _fault_meta(self):
+        return dict(kernel_flags=int(self.c.kernel_flags), batch=self.batch, time_steps=self.time_steps, dtype=self.cfg.dtype)
+
     def _log_faults(self, what, rep, n):
-        entry = dict(rep, what=what, events=int(n), kernel_flags=int(self.c.kernel_flags), batch=self.batch,
-                     time_steps=self.time_steps, dtype=self.cfg.dtype)
+        entry = dict(rep, what=what, events=int(n), **self._fault_meta())
         self.last_fault = entry
         FAULT_LOG.append(entry)
+        return entry
 
     def cluster_faults(self, what="census") -> int:
         """Events recorded by the weight-stationary cluster kernels in THIS engine's workspace since the last
-        call (expired waits, clusters spread over several XCDs; include/deepj_hip.h dj_lstm_cluster_faults).  Zero
-        in a healthy run; non-zero means the affected tiles -- and the loss -- are NaN, and the observation is
-        appended to FAULT_LOG with the description of the first expired wait.  Drains the current stream."""
-        rep = self.cluster_fault_report()
+        call (expired waits, clusters spread over several XCDs; include/deepj_hip.h dj_workspace_cluster_faults_take).
+        Zero in a healthy run; non-zero means the affected tiles -- and the loss -- are NaN, and the observation is
+        appended to FAULT_LOG with the description of the first expired wait.  ONE blocking round trip: the fault line
+        comes back with the count, the reset is queued behind it on the stream.  Drains the current stream."""
+        words = (C.c_int32 * _lib.FAULT_REPORT_WORDS)()
         with torch.cuda.device(self.device):
-            n = int(self.lib.dj_workspace_cluster_faults(C.byref(self.c), self.ws_ptr, self.ws_bytes, _stream_ptr()))
+            n = int(self.lib.dj_workspace_cluster_faults_take(C.byref(self.c), self.ws_ptr, self.ws_bytes, words,
+                                                              _stream_ptr()))
         if n < 0:
-            raise _lib.DeepJError("dj_workspace_cluster_faults failed")
+            raise _lib.DeepJError("dj_workspace_cluster_faults_take failed")
         if n:
-            self._log_faults(what, rep, n)
+            self._log_faults(what, decode_fault_report(words), n)
         return n + self.take_async_faults(what=what)
 
     def take_async_faults(self, value=None, what="training step") -> int:
         """Faults that train_fwd_bwd calls have added to loss[1:4] (dj_workspace_faults_async) since the last take;
-        `value`: the number if the caller has already read loss[1] with the loss."""
+        `value`: the number if the caller has already read loss[1] with the loss.  `self.fault_of_last_take` is the
+        FAULT_LOG entry this call made, or None when THIS call saw nothing (so that nobody describes a stale
+        `last_fault` as this step's)."""
         m = int(self.loss[1].item()) if value is None else int(value)
+        self.fault_of_last_take = None
         if m:
             host = self.loss.cpu().numpy()
-            rep = self.cluster_fault_report()            # the async census leaves the first wait's description in place
+            words = (C.c_int32 * _lib.FAULT_REPORT_WORDS)()
+            with torch.cuda.device(self.device):         # the async census left the first wait's description in place:
+                self.lib.dj_workspace_cluster_faults_take(C.byref(self.c), self.ws_ptr, self.ws_bytes, words,
+                                                          _stream_ptr())     # ... the host takes (and resets) it here
+            rep = decode_fault_report(words)
             rep["expired"], rep["misplaced"] = int(host[2]), int(host[3])
             self.loss[1:].zero_()
-            with torch.cuda.device(self.device):         # ... until the host takes it here
-                self.lib.dj_workspace_cluster_faults(C.byref(self.c), self.ws_ptr, self.ws_bytes, _stream_ptr())
-            self._log_faults(what, rep, m)
+            self.fault_of_last_take = self._log_faults(what, rep, m)
         return m
 
     def raise_on_cluster_faults(self, what):

@@ -175,10 +175,19 @@ class _Shared:
             pin, pdr = (self.input_dropout, self.dropout) if train else (0.0, 0.0)
             # keep at most a handful of workspaces alive (each can be GBs)
             if len(self.engines) >= 6:
-                self.engines.pop(next(iter(self.engines)))
+                old = self.engines.pop(next(iter(self.engines)))
+                if hasattr(old, "close"):
+                    old.close()                     # its fault census, then its workspace: here, not in a finalizer
             kw = {"kernel_flags": self.kernel_flags} if self.kernel_flags else {}
             self.engines[key] = self.backend.engine(self.cfg, batch, time_steps, pin, pdr, **kw)
         return self.engines[key]
+
+    def close(self):
+        """Release every engine (workspace) of these models; each takes its last fault census on the way (Engine.close)."""
+        for e in list(self.engines.values()):
+            if hasattr(e, "close"):
+                e.close()
+        self.engines.clear()
 
     def add_kernel_flags(self, flags):
         """OR `flags` (DJ_KF_*) into every present and future engine of these models -- and nowhere else."""
@@ -223,6 +232,12 @@ class Model:
         self.stop_training = False
 
     # ------------------------------------------------------------------ weights
+    def close(self):
+        """Not part of the Keras protocol: releases the HIP workspaces of these models (shared by model / time_model /
+        note_model) after their last fault census.  Optional -- an engine that is simply dropped hands its workspace to
+        engine.drain_pending() -- but it is the deterministic way."""
+        self._s.close()
+
     def count_params(self):
         return self._s.nparams
 
@@ -462,10 +477,14 @@ class TrainableModel(Model):
                 raise RuntimeError("cluster faults reported with the cluster kernel disabled")
             if hasattr(eng, "take_async_faults"):
                 eng.take_async_faults(local_faults)       # reset the device-side census; the event goes to engine.FAULT_LOG
-            what = ""
-            if getattr(eng, "last_fault", None) and hasattr(eng, "cluster_fault_report"):
+            # describe only what THIS call's census took from THIS rank's engine; a rank whose own count was zero got
+            # the number through the all-reduce (an older `last_fault` would blame a wait that did not expire now)
+            mine = getattr(eng, "fault_of_last_take", None)
+            if mine is not None:
                 from .engine import describe_fault_report
-                what = " (this rank: %s)" % describe_fault_report(eng.last_fault)
+                what = " (this rank: %s)" % describe_fault_report(mine)
+            else:
+                what = " (reported by another rank)" if dist else ""
             print("[deepj] rank %d: %d cluster faults in the recurrent forward kernel%s: falling back to the per-tile "
                   "kernel for this model (DJ_KF_NO_CLUSTER) and repeating the step" % (rank, int(faults), what),
                   flush=True)

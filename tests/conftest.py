@@ -71,14 +71,18 @@ def djenv(monkeypatch):
 # step-wise generation repeated a step, or a live engine holds fault counts nobody read.  The stall census (the longest
 # gap between two polls of any exchange wait: a wave that was off the device) is collected from every engine and
 # printed at the end of the session -- evidence about the box even when nothing expired.
-_CENSUS = {"live_readings": 0, "stalled_waits": 0, "max_poll_gap_cycles": 0, "faults_in_injection_tests": 0, "worst": None}
+_CENSUS = {"live_readings": 0, "stalled_waits": 0, "max_poll_gap_cycles": 0, "backward_clock_polls": 0,
+           "faults_in_injection_tests": 0, "worst": None}
 
 
 def _census_live_engines():
-    """Engines still alive after a test (most die with the test's locals: Engine.__del__ files theirs under E.CENSUS)."""
+    """Engines still alive after a test.  Most die with the test's locals: Engine.__del__ does NO HIP work (round 5) and
+    hands their workspaces to engine.drain_pending(), which files their census under E.CENSUS -- and any count nobody
+    read under E.FAULT_LOG -- here, at a safe point."""
     import gc
     from music_generator_amd import engine as E
     gc.collect()
+    E.drain_pending()
     unread = []
     for eng in list(E._LIVE):
         try:
@@ -87,6 +91,7 @@ def _census_live_engines():
             continue
         _CENSUS["live_readings"] += 1
         _CENSUS["stalled_waits"] = max(_CENSUS["stalled_waits"], rep["stalled_waits"])
+        _CENSUS["backward_clock_polls"] = max(_CENSUS["backward_clock_polls"], rep["backward_clock_polls"])
         if rep["max_poll_gap_cycles"] > _CENSUS["max_poll_gap_cycles"]:
             _CENSUS["max_poll_gap_cycles"] = rep["max_poll_gap_cycles"]
         if rep["expired"] or rep["misplaced"]:
@@ -134,14 +139,17 @@ def pytest_terminal_summary(terminalreporter):
     engines = E.CENSUS["engines"] + _CENSUS["live_readings"]
     if not engines:
         return
+    E.drain_pending()
     stalled = max(E.CENSUS["stalled_waits"], _CENSUS["stalled_waits"])
+    back = max(E.CENSUS["backward_clock_polls"], _CENSUS["backward_clock_polls"])
     gap = max(E.CENSUS["max_poll_gap_cycles"], _CENSUS["max_poll_gap_cycles"])
-    rec = {"engines": engines, "stalled_waits": stalled, "max_poll_gap_cycles": gap,
+    rec = {"engines": engines, "stalled_waits": stalled, "max_poll_gap_cycles": gap, "backward_clock_polls": back,
            "faults_in_injection_tests": _CENSUS["faults_in_injection_tests"], "faults_elsewhere": _CENSUS["worst"]}
     terminalreporter.write_line(
         "cluster exchange census: %d engines, waits with polls > 2^20 cycles apart: %d, longest gap between two polls of a "
-        "wait: %d shader cycles (~%.0f us at 2.1 GHz; 0 = below the 2^17-cycle recording threshold), faults in injection "
-        "tests: %d, faults elsewhere: %s" % (engines, stalled, gap, gap / 2100.0, rec["faults_in_injection_tests"],
+        "wait: %d shader cycles (~%.0f us at 2.1 GHz; 0 = below the 2^17-cycle recording threshold), polls behind a shader "
+        "clock that had gone backwards (wave restored on another XCC; most in one workspace): %d, faults in injection "
+        "tests: %d, faults elsewhere: %s" % (engines, stalled, gap, gap / 2100.0, back, rec["faults_in_injection_tests"],
                                             "NONE" if rec["faults_elsewhere"] is None else repr(rec["faults_elsewhere"])))
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):

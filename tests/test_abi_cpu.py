@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), "libdeepj_hip.so does not export " + n
-    assert lib.dj_abi_version() == 4
+    assert lib.dj_abi_version() == 5
     bound = {n for n in _lib._SIGS if n not in _lib.OPTIONAL}
     assert bound <= set(names), bound - set(names)
 
@@ -64,6 +64,120 @@ def test_no_kernel_of_the_library_uses_scratch_memory(tmp_path):
     known = [n for n in scratch if "lstm_bwd_kernelIfLi256E" in n]
     assert sorted(scratch) == sorted(known), {n: b for n, b in scratch.items() if n not in known}
     assert len(known) <= 2
+
+
+def _asm_statements(text):
+    """Every `asm [volatile] ( ... );` statement of a source text as (line, template string, outputs, inputs, clobbers)."""
+    text = re.sub(r"//[^\n]*", "", text)                 # line comments talk about asm too
+    out = []
+    for m in re.finditer(r"\basm\s+(?:volatile\s*)?\(|\basm\s*\(", text):
+        i, depth, in_str = m.end(), 1, False
+        start = i
+        while i < len(text) and depth:
+            c = text[i]
+            if in_str:
+                if c == "\\":
+                    i += 1
+                elif c == '"':
+                    in_str = False
+            elif c == '"':
+                in_str = True
+            elif c == "(":
+                depth += 1
+            elif c == ")":
+                depth -= 1
+            i += 1
+        body = text[start:i - 1]
+        # split at top-level ':' (outside strings and parentheses)
+        parts, cur, depth, in_str, j = [], "", 0, False, 0
+        while j < len(body):
+            c = body[j]
+            if in_str:
+                cur += c
+                if c == "\\":
+                    j += 1
+                    cur += body[j]
+                elif c == '"':
+                    in_str = False
+            elif c == '"':
+                in_str = True
+                cur += c
+            elif c in "([":
+                depth += 1
+                cur += c
+            elif c in ")]":
+                depth -= 1
+                cur += c
+            elif c == ":" and depth == 0:
+                if body[j:j + 2] == "::":
+                    parts += [cur, ""]
+                    cur = ""
+                    j += 1
+                else:
+                    parts.append(cur)
+                    cur = ""
+            else:
+                cur += c
+            j += 1
+        parts.append(cur)
+        parts += [""] * (4 - len(parts))
+        template = "".join(re.findall(r'"((?:[^"\\]|\\.)*)"', parts[0]))
+        out.append((text.count("\n", 0, m.start()) + 1, template, parts[1], parts[2], parts[3]))
+    return out
+
+
+_LOAD_TO_REGISTER = re.compile(r"\b(global_load|buffer_load|flat_load|scratch_load|ds_read|ds_load|s_load|s_buffer_load)\w*")
+
+
+def _asm_hazards(text):
+    """Inline-assembly statements that LOAD INTO A REGISTER OUTPUT: the compiler considers such a destination written as
+    soon as the statement has been issued, and an `s_waitcnt` in another assembly statement orders memory operations
+    only -- uses and copies of the register may be scheduled in front of the wait (the round-4 hazard: three rounds of
+    h-fragment loads were correct by the scheduler's grace, then a tag check read garbage and a late load overwrote an
+    address register -> memory fault).  A load whose destination is LDS (`... lds`) has no
+    register output and is fine; so is a statement that carries its own wait for every output (form (i) of the guide's
+    section 5.7: loads and `s_waitcnt vmcnt(0)` / `lgkmcnt(0)` in ONE statement with early-clobber outputs)."""
+    bad = []
+    for line, template, outs, ins, clob in _asm_statements(text):
+        has_reg_out = re.search(r'"[=+]&?[vas]"', outs) is not None
+        loads = [mm.group(0) for mm in _LOAD_TO_REGISTER.finditer(template)
+                 if not re.search(r"\blds\b", template[mm.start():].split("\\n")[0])]
+        if not (has_reg_out and loads):
+            continue
+        self_waited = re.search(r"s_waitcnt\s+(vmcnt\(0\)|lgkmcnt\(0\))", template.split(loads[-1])[-1]) and \
+            '"=&' in outs and '"=v"' not in outs and '"+v"' not in outs
+        if not self_waited:
+            bad.append((line, loads[0]))
+    return bad
+
+
+def test_no_inline_assembly_load_into_a_register_output():
+    """The class of the round-4 hazard, as a source guard over csrc/: no `asm` statement may have a register OUTPUT operand
+    and a load mnemonic whose destination is a register.  Loads the compiler must see go through builtins
+    (`__builtin_amdgcn_raw_buffer_load_b128(..., sc1)`: tracked by its own vmcnt bookkeeping); LDS-DMA
+    (`global_load_lds_dwordx4`: no register destination) and wait / barrier / pin statements stay allowed."""
+    csrc = os.path.join(ROOT, "music-generator_amd", "csrc")
+    n_stmt, bad = 0, {}
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        text = open(os.path.join(csrc, f)).read()
+        n_stmt += len(_asm_statements(text))
+        hz = _asm_hazards(text)
+        if hz:
+            bad[f] = hz
+    assert n_stmt > 50, n_stmt                            # the scanner sees the statements that are there
+    assert not bad, bad
+    # ... and the scanner itself: the round-4 form is caught, its safe neighbours are not
+    hazard = 'asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(d) : "v"(p) : "memory");'
+    assert _asm_hazards(hazard) == [(1, "global_load_dwordx4")]
+    assert _asm_hazards('asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(d) : "v"(o), "s"(r));')
+    assert _asm_hazards('asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(d) : "v"(a));')
+    assert not _asm_hazards('asm volatile("s_mov_b32 m0, %1\\n\\tglobal_load_lds_dwordx4 %0, off" :: "v"(p), "s"(m) : "memory");')
+    assert not _asm_hazards('asm volatile("s_mov_b32 %0, m0\\n\\tglobal_load_lds_dwordx4 %1, off" : "=&s"(k) : "v"(p));')
+    assert not _asm_hazards('asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  asm volatile("" : "+v"(x));')
+    assert not _asm_hazards('asm volatile("global_load_dwordx4 %0, %1, off\\n\\ts_waitcnt vmcnt(0)" : "=&v"(d) : "v"(p) : "memory");')
+    assert not _asm_hazards('// asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p));')
 
 
 def test_param_layout_matches_oracle_and_reference_count():

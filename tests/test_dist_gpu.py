@@ -274,6 +274,12 @@ def test_bench_two_rank_flow_on_one_gpu(gpu_device):
     assert d["config"]["global_batch"] == 128 and d["config"]["parallelism"] == "dp2" and "rehearsal" in d["config"]
     assert d["value"] > 0 and abs(d["value"] - 2 * 64 * 128 * 128 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-3 * d["value"]
     assert np.isfinite(d["final_loss"]) and d["cpu_baseline"] is None and "scaled" not in d
+    # multi-GPU evidence of the line: the ranks' device identities were all-gathered -- both ranks of this
+    # REHEARSAL sit on the one test GPU, so exactly 1 distinct device (a real N-GPU run prints N) -- and every rank's own
+    # time per step is there, none of them above the job's (the timed region ends at the slowest rank's barrier)
+    assert d["devices_distinct"] == 1, d.get("devices_distinct")
+    rk = d["rank_ms_per_step"]
+    assert len(rk["all"]) == 2 and 0 < rk["min"] <= rk["max"] <= d["ms_per_step"] * 1.001, (rk, d["ms_per_step"])
 
 
 WORKER3 = r'''

@@ -578,8 +578,7 @@ int launch_bwd_pair(int ntiles, int steps, const void* Z, const void* UTpack, co
     const int n = ntiles < cap ? ntiles : cap;
     // counter lines of the pairs start at zero in every launch (a kernel, not a memset node: cluster_reset above)
     hipLaunchKernelGGL(cl_reset_kernel, dim3(BP_BYTES / (256 * 16)), dim3(256), 0, st,
-                       (uint4*)((unsigned char*)scratch + BP_OFF_CNT));
-    if (int rc = cluster_fault_hook(scratch, 0, st)) return rc;
+                       (uint4*)((unsigned char*)scratch + BP_OFF_CNT), (int*)((char*)scratch + CL_OFF_FAULT) + CLF_HOOK, 0);
     const dim3 grid((n + 7) / 8 * 16);
     const int mate = 8;      // neighbours in dispatch order; (half the grid apart: all 256 pairs on ONE compute unit each, +5 %)
     if (sigm)
@@ -632,8 +631,7 @@ int launch_bwd_dual(int ntiles, int steps, const void* Z, const void* UTpack, co
   while (left > 0) {
     const int n = left < cap ? left : cap;
     hipLaunchKernelGGL(cl_reset_kernel, dim3(BP_BYTES / (256 * 16)), dim3(256), 0, st,
-                       (uint4*)((unsigned char*)scratch + BP_OFF_CNT));
-    if (int rc = cluster_fault_hook(scratch, 0, st)) return rc;
+                       (uint4*)((unsigned char*)scratch + BP_OFF_CNT), (int*)((char*)scratch + CL_OFF_FAULT) + CLF_HOOK, 0);
     const dim3 grid((n / 2 + 7) / 8 * 16);
     if (sigm)
       hipLaunchKernelGGL((lstm_bwd_dual_kernel<true>), grid, dim3(256), smem, st, z, (const bf16_t*)UTpack, c, dh, dz, dbias,
