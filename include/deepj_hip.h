@@ -77,6 +77,7 @@ typedef struct dj_config {
                                      /*   a step through the cluster's counter (store acknowledgement, barrier, atomic,     */
                                      /*   poll) instead of tags inside the h slices                                          */
 #define DJ_KF_DEBUG_CLUSTER_MUTE 1024 /* tagged sweep: the last member of every cluster stops publishing at step 2 (tests)  */
+#define DJ_KF_BWD_PLAIN 2048          /* bf16 H = 256 BPTT sweep on the round-4 kernel (all gate math behind the product)   */
 /* (ABI 3 had two opt-in re-decompositions of the H = 256 BPTT sweep, DJ_KF_BWD_PAIR / _DUAL; they were slower and now
  * live in tools/bwd_decompositions/, outside this library) */
 int32_t dj_env_reload(void);

@@ -234,6 +234,7 @@ EnvDefaults read_env() {
   if (off("DEEPJ_GEN_KSPLIT")) d.flags |= DJ_KF_NO_GEN_KSPLIT;
   if (off("DEEPJ_STEP_EPILOGUE")) d.flags |= DJ_KF_NO_STEP_EPILOGUE;
   if (off("DEEPJ_TAGGED_EXCHANGE")) d.flags |= DJ_KF_COUNTED_EXCHANGE;
+  if (off("DEEPJ_BWD_SPLIT")) d.flags |= DJ_KF_BWD_PLAIN;
   if (on("DEEPJ_DEBUG_CLUSTER_FAULT")) d.flags |= DJ_KF_DEBUG_CLUSTER_FAULT;
   if (on("DEEPJ_DEBUG_CLUSTER_LATE")) d.flags |= DJ_KF_DEBUG_CLUSTER_LATE;
   if (on("DEEPJ_DEBUG_CLUSTER_MUTE")) d.flags |= DJ_KF_DEBUG_CLUSTER_MUTE;
@@ -496,7 +497,8 @@ int lstm_layer_bwd(const Ctx& c, const LstmP& L, float* G, int64_t tiles, int st
     ProfScope ps(is_note ? PC_LSTM_BWD_NOTE : PC_LSTM_BWD_TIME, c.st);
     if (rec_persistent(L.H)) {
       RUN(dj_launch_lstm_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), c.at(wUb), c.at(wC), c.at(wdH), c.at(wdZ), cts, G + L.b,
-                             c.p.c.recurrent_sigmoid, fdx ? c.at(wWp) : nullptr, L.D, fdx ? c.at(wdX) : nullptr, L.DP, c.st));
+                             c.p.c.recurrent_sigmoid, fdx ? c.at(wWp) : nullptr, L.D, fdx ? c.at(wdX) : nullptr, L.DP,
+                             kflags(c.p.c), c.st));
     } else {
       const void* Uc = dt == DJ_F32 ? (const void*)(c.P + L.U) : (const void*)c.at(wUb);
       RUN(dj_launch_lstm_step_bwd(dt, L.H, (int)tiles, steps, c.at(wZ), Uc, c.at(wC), c.at(wdH), c.at(wdZ), cts, G + L.b,
@@ -1014,14 +1016,14 @@ int32_t dj_lstm_bwd(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, con
                     const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias, int32_t sigm,
                     void* stream) {
   return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dz_tile_stride, dbias, sigm, nullptr, 0, nullptr,
-                            0, (hipStream_t)stream);
+                            0, env_defaults().flags, (hipStream_t)stream);
 }
 int32_t dj_lstm_bwd_dx(int32_t dtype, int32_t H, int32_t ntiles, int32_t steps, const void* Z, const void* upack,
                        const void* C, const void* dH, void* dZ, int64_t dz_tile_stride, float* dbias, int32_t sigm,
                        const void* wtpack, int32_t D, void* dX, int32_t DP, void* stream) {
   if (!wtpack) return 1013;
   return dj_launch_lstm_bwd(dtype, H, ntiles, steps, Z, upack, C, dH, dZ, dz_tile_stride, dbias, sigm, wtpack, D, dX, DP,
-                            (hipStream_t)stream);
+                            env_defaults().flags, (hipStream_t)stream);
 }
 int32_t dj_lstm_cluster_faults(void* cluster_scratch, void* stream) {
   return dj_lstm_cluster_faults_impl(cluster_scratch, (hipStream_t)stream);

@@ -115,9 +115,10 @@ int64_t dj_lstm_stash_row_bytes(int dtype, int H);
 // WTpack/D/dX/DP: optional fused input gradient dX = dz W^T (WTpack from dj_launch_lstm_pack_wt; null = off;
 // available where dj_lstm_bwd_has_dx says so)
 // dz_cts: layout of the dZ output, as for dj_launch_lstm_wgrad (0 = row-major [rows, 4H])
+// kf: DJ_KF_* bits (DJ_KF_BWD_PLAIN: bf16 H = 256 on lstm_bwd_kernel instead of the split-gate-math sweep)
 int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* UTpack, const void* C,
                        const void* dH, void* dZ, int64_t dz_cts, float* dbias, int sigm, const void* WTpack, int D, void* dX,
-                       int DP, hipStream_t st);
+                       int DP, uint32_t kf, hipStream_t st);
 int dj_lstm_bwd_has_dx(int dtype, int H, int D);
 int dj_launch_lstm_pack_wt(int dtype, int H, const float* W, int D, void* out, hipStream_t st);
 int dj_lstm_fused_nkx(int dtype, int H, int D);

@@ -88,6 +88,15 @@ template <typename T, int H> struct RecCfg {
 // struct with UW = 64, NJ = 2, NW = 4 selects that geometry.)
 template <typename T, int H> struct BwdCfg : RecCfg<T, H> {};
 
+// f(integral_constant<int, I>) for I = I0 .. N-1, every call inlined: a loop whose index is a compile-time constant in
+// the body by construction (static register-array indices, `if constexpr` on the index)
+template <int I, int N, typename Fn> __device__ __forceinline__ void dj_static_for(Fn&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    dj_static_for<I + 1, N>(f);
+  }
+}
+
 // raw workgroup barrier: waits for this wave's LDS traffic only, so global prefetches
 // and stores stay in flight across it (cdna_hip_programming.md "Pipelining across barriers")
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -2031,6 +2040,358 @@ __global__ __launch_bounds__((BwdCfg<T, H>::NT)) void lstm_bwd_kernel(const Stas
 
 #undef DJ_DH_LOAD
 
+// ---------------------------------------------------------------- backward (BPTT), bf16 H = 256: SPLIT gate math (round 5)
+// The time-axis BPTT sweep (model.py:84 under TF autodiff; the dominant kernel of the training step).  lstm_bwd_kernel above
+// runs a step of a tile as a strict chain -- stash loads, gate math, dz tile, dz U^T product -- in which the product
+// (46 % of the step) is bound by the compute unit's vector-memory path streaming U^T from L2 with the vector ALUs idle,
+// and the gate math (28 %) is bound by vector-instruction issue with the memory path idle (phase stamps, DESIGN.md
+// section 8 round 4).  Only SIX operations per cell depend on dh_t, the thing the product delivers:
+//     dzo = dh A          dc = dcc + dh B       dzi = dc Ci      dzf = dc Cf      dzg = dc Cg      dcc' = dc fg
+// with A = tanh(c_t) o',  B = o (1 - tanh(c_t)^2),  Ci = g i',  Cf = c_{t-1} f',  Cg = i (1 - g^2)  -- all of which come
+// from the forward stash alone (gate codes, c_t, c_{t-1}).  So this kernel computes the FACTORS of step t-1 -- code
+// decoding, the tanh, two thirds of the vector instructions of a step -- INSIDE the product loop of step t, one cell
+// per group of k-chunks, in the issue slots the fragment stream leaves empty, and the part of a step that nothing
+// overlaps shrinks to the six operations above, the dz tile and its barriers.  Order of a step t (tile = 32 sequences):
+//   top       dH_t registers -> LDS; REQUEST the stash of step t-1 (gate codes, c_{t-2}; dH_{t-1}) and the first ring of
+//             U^T fragments -- nothing in the step waits for them before the product
+//   barrier   (dH tile visible; every wave is done reading the dz tile of step t+1)
+//   finish    dh_t = dH_t + acc;  the six operations per cell with the factors of step t;  dz_t -> LDS;  bias sums
+//   barrier   (dz tile complete)
+//   product   acc = dz_t U^T (A operand from LDS; U^T: KL chunks per column block resident in LDS, KS stationary in
+//             registers, the rest through the ring), with the factors of step t-1 computed in between
+//   store     dz_t tile LDS -> HBM, coalesced, BEHIND the product: vector memory is acknowledged in order, so stores in
+//             front of the product would hold back every ring refill issued behind them by their HBM acknowledgement
+// NJ = 32-unit column blocks per wave: 1 = eight waves (two per SIMD, 256 registers each), 2 = four waves (one per SIMD,
+// 512 registers: room for KS stationary chunks of U^T per column block next to the LDS-resident ones).
+struct Bwd256 {
+  static constexpr int H = 256, KC = 16, NKCB = 64, NCB = 32, NCBH = 8;
+  static constexpr int KL = 8;                                     // k-chunks per column block resident in LDS
+  // LDS: the dz tile K-MAJOR -- [1024 k][32 rows] bf16, 64 bytes per k, the 8-byte piece of rows 4c .. 4c+3 stored at
+  // piece c ^ (k & 7) -- then TWO dH tiles [32][256] (filled by LDS-DMA, unpadded; step t reads tile t & 1 while the DMA of
+  // step t-1 fills the other), then the resident U^T chunks: all 160 KiB of the compute unit
+  static constexpr size_t off_dh = (size_t)4 * H * 64;
+  static constexpr size_t dh_bytes = (size_t)32 * H * sizeof(bf16_t);
+  static constexpr size_t off_u = off_dh + 2 * dh_bytes;
+  static constexpr size_t smem = off_u + (size_t)8 * KL * 64 * 16;   // 65,536 + 2 x 16,384 + 65,536 = 163,840 bytes
+};
+// The dh-independent factors of the 16 cells a lane holds of one column block, packed in PAIRS as fp16 (48 registers
+// instead of 96: the eight-wave form has 256 registers per wave and spilled 132 of them with fp32 factors).  fp16, not
+// bf16: v_fma_mix_f32 takes either half of a packed register as an fp16 operand of an fp32 fma, so the finish phase
+// pays nothing for the packing; 11 significant bits are 8x finer than the 8-bit gate codes the factors are made from
+// (A, Ci <= 1/4, B, Cg, fg <= 1, |Cf| = |c_{t-1}| f' <= 0.25 |c|: all far inside fp16's range; a NaN stays a NaN).
+typedef _Float16 dj_h2 __attribute__((ext_vector_type(2)));
+struct BwdFac {
+  dj_h2 ab[16], cc[16], gf[16];                 // (A, B), (Ci, Cf), (Cg, fg)
+};
+__device__ __forceinline__ dj_h2 dj_pack_h2(float lo, float hi) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_convertvector(v, dj_h2);     // v_cvt_pk_f16_f32 (round to nearest even)
+}
+// x * (fp16 half of p) [+ c] as ONE v_fma_mix_f32 (HI: the upper half).  Assembly, register-only: written as
+// fmaf(x, (float)p[i], c) the SLP vectorizer paired the operations of two cells into v_pk_fma_f32 behind two
+// v_cvt_f32_f16_sdwa each -- three instructions per product instead of one, and the packed zero addends were spilled and
+// reloaded behind a vmcnt(0) inside the sweep.
+template <bool HI> __device__ __forceinline__ float dj_mix_mul(float x, dj_h2 p) {
+  float d;
+  if constexpr (HI) asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(x), "v"(p));
+  else asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(d) : "v"(x), "v"(p));
+  return d;
+}
+template <bool HI> __device__ __forceinline__ float dj_mix_fma(float x, dj_h2 p, float c) {
+  float d;
+  if constexpr (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(d) : "v"(x), "v"(p), "v"(c));
+  else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(d) : "v"(x), "v"(p), "v"(c));
+  return d;
+}
+template <bool SIGM>
+__device__ __forceinline__ void bwd_factors(const GateDec<bf16_t, SIGM>& gd, const Frag16<bf16_t>& ct,
+                                            const Frag16<bf16_t>& cp, float cpm, int r, BwdFac& F) {
+  float ig, fg, gg, og, di, df, dO;
+  gd.get(r, ig, fg, gg, og, di, df, dO);
+  const float tc = dj_tanh(ct.get(r));
+  F.ab[r] = dj_pack_h2(tc * dO, og * (1.f - tc * tc));
+  F.cc[r] = dj_pack_h2(gg * di, cp.get(r) * cpm * df);            // cpm = 0 for step 0: c_{-1} = 0
+  F.gf[r] = dj_pack_h2(ig * (1.f - gg * gg), fg);
+}
+// LDS-DMA of 16 bytes per lane from (scalar base + 32-bit lane offset): destination = lds_base (wave-uniform, via M0) +
+// 16 * lane.  Inline assembly so that hipcc neither drains it at the next barrier nor makes every later register load
+// wait vmcnt(0) for it (cdna_hip_programming.md section 5, "Pipelining across barriers"): it has no register destination
+// (the round-4 hazard does not apply), and an operation hipcc does not count can only make its own counted waits wait
+// for MORE than they need, never for less.  Its completion is waited for by hand (the counted wait at the top of a step).
+typedef short dj_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dj_glds16_s(const void* sbase, unsigned voff, unsigned lds_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_base)
+               : "memory");
+}
+__device__ __forceinline__ unsigned dj_lds_addr(const void* p) {
+  return (unsigned)(unsigned long)(const __attribute__((address_space(3))) void*)p;
+}
+// ds_read_b64_tr_b16: per group of 16 lanes a 4 x 16 block of 16-bit elements, delivered column-major -- lane 4q + p of
+// the group supplies the address of 4 elements (8 bytes), lane i receives element (i & 3) of the pieces of lanes
+// (i >> 2), 4 + (i >> 2), 8 + (i >> 2), 12 + (i >> 2)
+__device__ __forceinline__ dj_s16x4 dj_lds_tr(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((dj_s16x4 __attribute__((address_space(3)))*)p);
+}
+union DjTrFrag {
+  dj_s16x4 h[2];
+  bf16x8 v;
+  uint4 q;
+};
+template <bool SIGM, int NJ, int KS, int PD>
+__global__ __launch_bounds__(512 / NJ) void lstm_bwd256_kernel(const uint8_t* __restrict__ Z, const bf16_t* __restrict__ UTpack,
+                                                               const bf16_t* __restrict__ C, const bf16_t* __restrict__ dH,
+                                                               bf16_t* __restrict__ dZ, float* __restrict__ dbias, int steps,
+                                                               int64_t dz_cts, int ldz) {
+  using B = Bwd256;
+  using Frag = bf16x8;
+  constexpr int NW = 8 / NJ, NT = 64 * NW, H = B::H;
+  constexpr int NS = B::NKCB - B::KL - KS;                         // streamed k-chunks per column block
+  static_assert(NS >= PD && (NJ == 1 || NJ == 2), "geometry");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* dzk = smem_raw;                                    // dz tile, k-major (Bwd256)
+  const bf16_t* dhs = (const bf16_t*)(smem_raw + B::off_dh);        // [2][32][256]
+  Frag* uls = (Frag*)(smem_raw + B::off_u);                         // [8 column blocks][KL][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t tile = blockIdx.x;
+
+  // Every global access is a BUFFER access: a descriptor per operand whose base is this tile's part of it (wave-uniform),
+  // the lane's bytes as a 32-bit vector offset computed once, the step / chunk as a scalar offset -- one instruction per
+  // request and no 64-bit vector address anywhere (the plain kernel spends 25 v_lshl_add_u64 per step on them, and this
+  // one has no registers to keep such addresses in).
+  auto rsrc = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, -1, 0x00020000); };
+  const __amdgpu_buffer_rsrc_t ur = rsrc(UTpack);
+  const __amdgpu_buffer_rsrc_t zr = rsrc(Z + tile * steps * (B::NCB * 1024));               // [step][32 blocks][1 KiB]
+  const __amdgpu_buffer_rsrc_t cr = rsrc(C + tile * steps * (B::NCBH * 1024));              // [step][8 blocks][2 KiB]
+  const __amdgpu_buffer_rsrc_t dr = rsrc(dZ + tile * steps * 32 * (int64_t)ldz);            // rows of this tile
+  const bf16_t* dHt = dH + tile * steps * (32 * H);                                         // [step][32 rows][512 B]
+  auto ldb = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+  };
+  const int lane16 = lane * 16;
+  auto ldu = [&](int j, int kc) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ur, lane16, ((w * NJ + j) * B::NKCB + kc) * 1024, 0);
+    return __builtin_bit_cast(Frag, v);
+  };
+  // resident parts of U^T: KL chunks per column block in LDS, KS in registers
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int kc = 0; kc < B::KL; ++kc) uls[((w * NJ + j) * B::KL + kc) * 64 + lane] = ldu(j, kc);
+  Frag us[NJ][KS > 0 ? KS : 1];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int kc = 0; kc < KS; ++kc) us[j][kc] = ldu(j, B::KL + kc);
+
+  f32x16 acc[NJ];
+  float dcc[NJ][16], dbs[4][NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[j][r] = 0.f;
+      dcc[j][r] = 0.f;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dbs[g][j] = 0.f;
+  }
+  GateDec<bf16_t, SIGM> gd[NJ];
+  Frag16<bf16_t> cA[NJ], cB[NJ];          // entering step t: cA = c_{t-1}; cB receives c_{t-2}
+  BwdFac F[NJ];
+  // stash of step `st` of this tile: gate codes and c
+  auto ld_codes = [&](int st) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gd[j].q[g] = ldb(zr, lane16, (st * B::NCB + g * 8 + w * NJ + j) * 1024);
+  };
+  auto ld_c = [&](Frag16<bf16_t>(&c)[NJ], int st) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int so = (st * B::NCBH + w * NJ + j) * 2048;
+      c[j].v[0] = ldb(cr, lane * 32, so);
+      c[j].v[1] = ldb(cr, lane * 32, so + 16);
+    }
+  };
+  // dH tile of step `st` (32 x 256 bf16, row-major: 16 contiguous KiB) -> LDS by DMA, NI pieces of 1 KiB per wave
+  constexpr int NI = 16 / NW;
+  const unsigned dhs_lds = __builtin_amdgcn_readfirstlane(dj_lds_addr(dhs));
+  auto dh_dma = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int piece = w * NI + i;
+      dj_glds16_s(dHt + (int64_t)st * (32 * H) + piece * 512, lane16,
+                  dhs_lds + (unsigned)(st & 1) * (unsigned)B::dh_bytes + piece * 1024);
+    }
+  };
+  // ---- the dz tile in LDS, K-MAJOR: element (row m, column k) at byte k * 64 + (((m >> 2) ^ (k & 7)) << 3) + 2 (m & 3).
+  // A lane of the finish phase holds, per gate, rows 8 rg + 4 h + (0..3) of ONE column for rg = 0..3: four 8-byte
+  // stores per gate (ds_write_b64) instead of sixteen 2-byte ones into a row-major tile -- that phase was bound by its
+  // 512 LDS store instructions per step and compute unit.  The product's A operand (a lane: 8 consecutive k of one row)
+  // and the rows that go to HBM (16 bytes = 8 consecutive k of one row) come back out through ds_read_b64_tr_b16.
+  // The XOR keeps all three patterns off each other's banks (stores: 16 consecutive k per lane group; operand reads: 4
+  // consecutive k x 8 pieces per half wave -- every bank once).
+  const int q4 = (lane & 15) >> 2, p4 = lane & 3, g16 = lane >> 4;
+  int wadr[NJ];                              // finish-phase store address for rg = 0 and gate 0 (rg: ^ 16 rg; gate: + 16 KiB)
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) wadr[j] = (((w * NJ + j) * 32 + l31) << 6) | ((h ^ (l31 & 7)) << 3);
+  // operand reads of k-chunk kc: k = 16 kc + 8 h + 4 rd + q4, rows 16 (g16 & 1) + 4 p4 .. (piece 4 (g16 & 1) + p4)
+  const int ra0 = ((8 * h + q4) << 6) | ((((4 * (g16 & 1) + p4) ^ q4) & 7) << 3);
+  const int ra1 = ((8 * h + 4 + q4) << 6) | ((((4 * (g16 & 1) + p4) ^ (4 + q4)) & 7) << 3);
+  // rows to HBM: instruction i of wave w covers region i + NR w of the tile's 64 regions (4 rows x 128 columns each):
+  // piece c = region & 7, columns 128 (region >> 3) ...; the lane loads k = 128 kr + 32 g16 + 8 p4 + 4 rd + q4 of that
+  // piece and receives row 4 c + (lane & 3), columns 128 kr + 32 g16 + 8 q4 + (0..7)
+  constexpr int NR = 64 / NW;
+  const int rs0 = ((32 * g16 + 8 * p4 + q4) << 6) | (q4 << 3);
+  const int rs1 = ((32 * g16 + 8 * p4 + 4 + q4) << 6) | ((4 + q4) << 3);
+  const int dzv_off = ((lane & 3) * ldz + (4 * g16 + q4) * 8) * 2;
+  // (the two lane addresses are made opaque per step, `rs0v` / `rs1v` below: as loop invariants the compiler computed all
+  // 2 NR variants before the sweep and then spilled them -- one v_xor + one v_add per read is cheaper than a reload)
+  auto dz_store = [&](int t, int i, int rs0v, int rs1v) {
+    const int region = w * NR + i, c = region & 7, kr = region >> 3;
+    DjTrFrag v;
+    v.h[0] = dj_lds_tr(dzk + (rs0v ^ (c << 3)) + kr * 8192);
+    v.h[1] = dj_lds_tr(dzk + (rs1v ^ (c << 3)) + kr * 8192);
+    const u32x4 o = {v.q.x, v.q.y, v.q.z, v.q.w};
+    const unsigned so = (unsigned)(((kr >> 1) * dz_cts + (int64_t)(t * 32 + 4 * c) * ldz + (kr & 1) * 128) * 2);
+    __builtin_amdgcn_raw_buffer_store_b128(o, dr, dzv_off, (int)so, 0);
+  };
+
+  // prologue: the factors of the last step, with nothing to hide behind
+  {
+    const int sl = steps - 1;
+    dh_dma(sl);
+    ld_codes(sl);
+    ld_c(cA, sl);
+    ld_c(cB, sl > 0 ? sl - 1 : sl);
+    const float cpm = steps > 1 ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bwd_factors<SIGM>(gd[j], cA[j], cB[j], cpm, r, F[j]);
+      cA[j].copy_from(cB[j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the first dH tile has landed (this wave's pieces)
+  }
+
+  for (int t = steps - 1; t >= 0; --t) {
+    // ---- top: requests of step t-1 (clamped at the tile's first rows: step 0 re-requests its own and ignores them --
+    // unconditional requests keep the compiler's vmcnt bookkeeping exact).  The dH tile of step t was requested by DMA
+    // at the top of the step before; the only operations of this wave younger than it that may still be in flight are
+    // the NR row stores of that step: vector memory completes in order, so all but the NR youngest done means the DMA
+    // has landed (first step: the prologue's vmcnt(0)).  The DMA of step t-1 goes into the OTHER dH tile, here and not
+    // behind the second barrier: requests return in order, and in front of the product's ring it held the first
+    // fragments back by a whole HBM latency (measured: +3.4 k cycles per step).
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NR) : "memory");
+    const int t1 = t > 0 ? t - 1 : t, t2 = t > 1 ? t - 2 : t1;
+    dh_dma(t1);
+    ld_codes(t1);
+    ld_c(cB, t2);
+    lds_barrier();
+    // ---- finish step t: the six dh-dependent operations per cell
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int u = (w * NJ + j) * 32 + l31;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        float dz[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * rg + e, row = dj_crow(r, lane);
+          const float dh = dj_to_f32(dhs[(t & 1) * (32 * H) + row * H + u]) + acc[j][r];
+          // every factor enters as the fp16 operand of a v_fma_mix_f32, either half of its pair
+          const float dc = dj_mix_fma<true>(dh, F[j].ab[r], dcc[j][r]);
+          dz[0][e] = dj_mix_mul<false>(dc, F[j].cc[r]);
+          dz[1][e] = dj_mix_mul<true>(dc, F[j].cc[r]);
+          dz[2][e] = dj_mix_mul<false>(dc, F[j].gf[r]);
+          dz[3][e] = dj_mix_mul<false>(dh, F[j].ab[r]);
+          dcc[j][r] = dj_mix_mul<true>(dc, F[j].gf[r]);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          *(uint2*)(dzk + g * (H * 64) + (wadr[j] ^ (rg << 4))) =
+              make_uint2(pack_bf16x2(dz[g][0], dz[g][1]), pack_bf16x2(dz[g][2], dz[g][3]));
+          dbs[g][j] += (dz[g][0] + dz[g][1]) + (dz[g][2] + dz[g][3]);
+        }
+      }
+    }
+    lds_barrier();
+    int rs0v = rs0, rs1v = rs1;
+    asm volatile("" : "+v"(rs0v), "+v"(rs1v));
+    // ---- product of step t with the factors of step t-1 -- and the rows of dz_t on their way to HBM -- in its gaps
+    if (t > 0) {
+      const float cpm = t > 1 ? 1.f : 0.f;
+      // the ring's first fragments: requested here, not at the top of the step (32 registers the finish phase needs);
+      // the resident chunks and the first cells of factors are their head start, and no store is in front of them
+      Frag bq[PD][NJ];
+#pragma unroll
+      for (int p = 0; p < PD; ++p)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bq[p][j] = ldu(j, B::KL + KS + p);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      constexpr int CPE = 4 / NJ;                                  // k-chunks per cell of factors (16 NJ cells, 64 chunks)
+      // every index below is a compile-time constant (dj_static_for: a `#pragma unroll` of 64 such iterations was only
+      // unrolled 8-fold, and the run-time chunk index put the gate codes and the factors on the stack)
+      dj_static_for<0, B::NKCB>([&](auto kcc) {
+        constexpr int kc = decltype(kcc)::value;
+        DjTrFrag a;
+        a.h[0] = dj_lds_tr(dzk + ra0 + kc * 1024);
+        a.h[1] = dj_lds_tr(dzk + ra1 + kc * 1024);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if constexpr (kc < B::KL) {
+            dj_mfma(acc[j], a.v, uls[((w * NJ + j) * B::KL + kc) * 64 + lane]);
+          } else if constexpr (kc < B::KL + KS) {
+            dj_mfma(acc[j], a.v, us[j][kc - B::KL]);
+          } else {
+            constexpr int sl = (kc - B::KL - KS) % PD;
+            dj_mfma(acc[j], a.v, bq[sl][j]);
+            if constexpr (kc + PD < B::NKCB) bq[sl][j] = ldu(j, kc + PD);
+          }
+        }
+        if constexpr ((kc + 1) % CPE == 0) {
+          constexpr int e = (kc + 1) / CPE - 1;
+          bwd_factors<SIGM>(gd[e / 16], cA[e / 16], cB[e / 16], cpm, e % 16, F[e / 16]);
+          // one of the NR row-store instructions of this wave per 64 / NR chunks (the tile is complete since the second
+          // barrier and only read from here on).  Behind the product they were a phase of their own -- two conflicting
+          // LDS reads, a wait and a store, NR times in a row: 3 k cycles of a 22 k step; here they cost issue slots
+          if constexpr ((kc + 1) % (B::NKCB / NR) == 0) dz_store(t, (kc + 1) / (B::NKCB / NR) - 1, rs0v, rs1v);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) cA[j].copy_from(cB[j]);
+    } else {
+      // ---- step 0 has no product: dz_0 -> global in one go.  Per instruction 4 rows x 256 bytes (two whole lines per
+      // row); element (m, k) at dZ + (k >> 8) * dz_cts + m * ldz + (k & 255) (row-major: dz_cts 256, ldz 4H;
+      // column-tile-major [4H/256][rows][256]: dz_cts rows * 256, ldz 256)
+#pragma unroll
+      for (int i = 0; i < NR; ++i) dz_store(t, i, rs0v, rs1v);
+    }
+  }
+  if (dbias) {
+    // the lane id afresh (mbcnt): nothing derived from threadIdx has to survive the sweep for this (it was spilled)
+    const int le = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        float v = dbs[g][j];
+        v += __shfl_xor(v, 32);
+        if (le < 32) atomicAdd(dbias + g * H + (w * NJ + j) * 32 + le, v);
+      }
+  }
+}
+
 
 template <typename T, int H> int launch_pack(const float* U, void* fwd, void* bwd, hipStream_t st) {
   int n = H * 4 * H;
@@ -2080,9 +2441,43 @@ int launch_bwd_x(int ntiles, int steps, const void* Z, const void* UTpack, const
                        dz_cts, ldz);
   return (int)hipGetLastError();
 }
+// bf16 H = 256: the split-gate-math sweep (lstm_bwd256_kernel)
+template <int NJ, int KS, int PD>
+int launch_bwd256(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
+                  int64_t dz_cts_in, float* dbias, int sigm, hipStream_t st) {
+  const int64_t dz_cts = dz_cts_in ? dz_cts_in : 256;
+  const int ldz = dz_cts_in ? 256 : 4 * 256;
+  if (dz_cts_in && dz_cts_in < (int64_t)ntiles * steps * 32 * 256) return 1018;
+  static bool attr_done_dev[DJ_MAX_DEVICES] = {};
+  bool& attr_done = attr_done_dev[dj_current_device()];
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)lstm_bwd256_kernel<false, NJ, KS, PD>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)Bwd256::smem);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)lstm_bwd256_kernel<true, NJ, KS, PD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)Bwd256::smem);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  if (sigm)
+    hipLaunchKernelGGL((lstm_bwd256_kernel<true, NJ, KS, PD>), dim3(ntiles), dim3(512 / NJ), Bwd256::smem, st, (const uint8_t*)Z,
+                       (const bf16_t*)UTpack, (const bf16_t*)C, (const bf16_t*)dH, (bf16_t*)dZ, dbias, steps, dz_cts, ldz);
+  else
+    hipLaunchKernelGGL((lstm_bwd256_kernel<false, NJ, KS, PD>), dim3(ntiles), dim3(512 / NJ), Bwd256::smem, st, (const uint8_t*)Z,
+                       (const bf16_t*)UTpack, (const bf16_t*)C, (const bf16_t*)dH, (bf16_t*)dZ, dbias, steps, dz_cts, ldz);
+  return (int)hipGetLastError();
+}
 template <typename T, int H>
 int launch_bwd(int ntiles, int steps, const void* Z, const void* UTpack, const void* C, const void* dH, void* dZ,
-               int64_t dz_cts, float* dbias, int sigm, const void* WTpack, int NQ, void* dX, int DP, hipStream_t st) {
+               int64_t dz_cts, float* dbias, int sigm, const void* WTpack, int NQ, void* dX, int DP, uint32_t kf,
+               hipStream_t st) {
+  if constexpr (sizeof(T) == 2 && H == 256) {
+    // eight waves, 4 k-chunks per column block stationary in registers next to the 8 in LDS, ring of 8 (round 5 A/B in
+    // one call, lstm_bwd_time per training step: <1,4,8> 2.76 ms, <1,0,8> 2.86, <1,0,12> 2.85, lstm_bwd_kernel 2.89; the
+    // four-wave forms <2,0,8> 3.34 and <2,8,8> 3.19: DESIGN.md section 8 round 5 -- they instantiate from this template)
+    if (!WTpack && !(kf & DJ_KF_BWD_PLAIN))
+      return launch_bwd256<1, 4, 8>(ntiles, steps, Z, UTpack, C, dH, dZ, dz_cts, dbias, sigm, st);
+  }
   if (WTpack) {
     if constexpr (RecCfg<T, H>::STATB) {
       if (NQ <= RecCfg<T, H>::NW)                  // one stationary 32-column block per wave: D <= H
@@ -2345,11 +2740,11 @@ int64_t dj_lstm_stash_row_bytes(int dtype, int H) { return (int64_t)4 * H * (dty
 int64_t dj_lstm_cluster_scratch_bytes_impl() { return (int64_t)CL_BYTES; }
 int dj_launch_lstm_bwd(int dtype, int H, int ntiles, int steps, const void* Z, const void* UTpack, const void* C,
                        const void* dH, void* dZ, int64_t dz_cts, float* dbias, int sigm, const void* WTpack, int D, void* dX,
-                       int DP, hipStream_t st) {
+                       int DP, uint32_t kf, hipStream_t st) {
   if (ntiles <= 0 || steps <= 0) return 0;
   const int NQ = (D + 31) / 32;
   if (WTpack && (!dX || D < 1 || DP < 8 || (DP % 8) || NQ * 32 < DP)) return 1013;
-  DJ_DISPATCH_TH(launch_bwd, ntiles, steps, Z, UTpack, C, dH, dZ, dz_cts, dbias, sigm, WTpack, NQ, dX, DP, st)
+  DJ_DISPATCH_TH(launch_bwd, ntiles, steps, Z, UTpack, C, dH, dZ, dz_cts, dbias, sigm, WTpack, NQ, dX, DP, kf, st)
 }
 // does the BPTT kernel of this (dtype, H) offer the fused input gradient?
 // 1: the whole dX (D <= H); 2: only the last 32-column block, for inputs whose width is 1..4 columns past a
