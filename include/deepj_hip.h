@@ -78,6 +78,7 @@ typedef struct dj_config {
                                      /*   poll) instead of tags inside the h slices                                          */
 #define DJ_KF_DEBUG_CLUSTER_MUTE 1024 /* tagged sweep: the last member of every cluster stops publishing at step 2 (tests)  */
 #define DJ_KF_BWD_PLAIN 2048          /* bf16 H = 256 BPTT sweep on the round-4 kernel (all gate math behind the product)   */
+#define DJ_KF_NO_GEN_MFMA 4096        /* bf16 note sampler on the vector ALUs against the fp32 weights (the fp32 mode's kernel)  */
 /* (ABI 3 had two opt-in re-decompositions of the H = 256 BPTT sweep, DJ_KF_BWD_PAIR / _DUAL; they were slower and now
  * live in tools/bwd_decompositions/, outside this library) */
 int32_t dj_env_reload(void);

@@ -23,7 +23,7 @@ class DjConfig(C.Structure):
 # dj_config.kernel_flags (include/deepj_hip.h DJ_KF_*)
 KF_NO_CLUSTER, KF_NO_CLUSTER_PAIR, KF_NO_CLUSTER_F32, KF_NO_CLUSTER_COOP = 1, 2, 4, 8
 KF_NO_FUSE_DX, KF_NO_GEN_KSPLIT, KF_DEBUG_CLUSTER_FAULT, KF_DEBUG_CLUSTER_LATE, KF_NO_STEP_EPILOGUE = 16, 32, 64, 128, 256
-KF_COUNTED_EXCHANGE, KF_DEBUG_CLUSTER_MUTE, KF_BWD_PLAIN = 512, 1024, 2048
+KF_COUNTED_EXCHANGE, KF_DEBUG_CLUSTER_MUTE, KF_BWD_PLAIN, KF_NO_GEN_MFMA = 512, 1024, 2048, 4096
 FAULT_REPORT_WORDS = 32                      # DJ_FAULT_REPORT_WORDS
 
 

@@ -232,6 +232,7 @@ EnvDefaults read_env() {
   if (off("DEEPJ_CLUSTER_COOP")) d.flags |= DJ_KF_NO_CLUSTER_COOP;
   if (off("DEEPJ_FUSE_DX")) d.flags |= DJ_KF_NO_FUSE_DX;
   if (off("DEEPJ_GEN_KSPLIT")) d.flags |= DJ_KF_NO_GEN_KSPLIT;
+  if (off("DEEPJ_GEN_MFMA")) d.flags |= DJ_KF_NO_GEN_MFMA;
   if (off("DEEPJ_STEP_EPILOGUE")) d.flags |= DJ_KF_NO_STEP_EPILOGUE;
   if (off("DEEPJ_TAGGED_EXCHANGE")) d.flags |= DJ_KF_COUNTED_EXCHANGE;
   if (off("DEEPJ_BWD_SPLIT")) d.flags |= DJ_KF_BWD_PLAIN;
@@ -841,7 +842,8 @@ int32_t dj_generate_step(const dj_config* cfg, const float* params, const float*
   if (!params || !notes_win || !beat_win || !style_win || !uniforms || !temperature || !next_notes || !draws_used)
     return 1210;
   if (p.B > 8) return 1301;
-  const int64_t need = (int64_t)(8 * 64 + 4 * 8 * 512 + (int64_t)p.B * p.N * 4 * p.Hn) * 4;
+  const int64_t gen_floats = (8 * 64 + 4 * 8 * 512 + (int64_t)p.B * p.N * 4 * p.Hn + 63) / 64 * 64;   // the sampler's float scratch ...
+  const int64_t need = gen_floats * 4 + dj_gen_wpack_bytes();            // ... and its bf16 weight fragments (bf16 mode)
   if (need > p.Mn * (int64_t)p.nl[0].DP * p.esz) return 1302;       // scratch lives in the (unused) dX_n area
   Ctx c{p, params, (char*)ws, (hipStream_t)stream, false, 0};
   for (int l = 0; l < p.Lt; ++l) RUN(prep_layer(c, p.tl[l], p.w_Wt_t[l], p.w_Wc_t[l], p.w_Uf_t[l], p.w_Ub_t[l], p.w_Wp_t[l], false));
@@ -857,7 +859,7 @@ int32_t dj_generate_step(const dj_config* cfg, const float* params, const float*
   return dj_launch_generate_notes(p.c.dtype, p.B, p.T, p.N, p.Ht, p.Hn, p.Ln, p.S, p.SU, params, offs,
                                   c.at(p.w_H_t[p.Lt - 1]), style_win + (int64_t)(p.T - 1) * p.S, (int64_t)p.T * p.S,
                                   c.at<float>(p.w_dX_n), uniforms, temperature, next_notes, draws_used, nullptr,
-                                  nullptr, p.c.recurrent_sigmoid, 0, kflags(p.c), c.st);
+                                  nullptr, p.c.recurrent_sigmoid, 0, c.at<float>(p.w_dX_n) + gen_floats, kflags(p.c), c.st);
 }
 
 int32_t dj_gen_state_size(void) { return dj_gen_state_bytes(); }
@@ -888,7 +890,8 @@ int generate_resident(const dj_config* cfg, const float* params, void* state, fl
   if (!params || !state || !results || !uniform_pool || !notes_src || !notes_dst || !beat_src || !beat_dst || !style_win)
     return 1210;
   if (p.B > 8) return 1301;
-  const int64_t need = (int64_t)(8 * 64 + 4 * 8 * 512 + (int64_t)p.B * p.N * 4 * p.Hn) * 4;
+  const int64_t gen_floats = (8 * 64 + 4 * 8 * 512 + (int64_t)p.B * p.N * 4 * p.Hn + 63) / 64 * 64;   // the sampler's float scratch ...
+  const int64_t need = gen_floats * 4 + dj_gen_wpack_bytes();            // ... and its bf16 weight fragments (bf16 mode)
   if (need > p.Mn * (int64_t)p.nl[0].DP * p.esz) return 1302;
   Ctx c{p, params, (char*)ws, (hipStream_t)stream, false, 0};
   c.static_ready = static_ready;
@@ -899,7 +902,8 @@ int generate_resident(const dj_config* cfg, const float* params, void* state, fl
   RUN(dj_launch_generate_notes(p.c.dtype, p.B, p.T, p.N, p.Ht, p.Hn, p.Ln, p.S, p.SU, params, offs,
                                c.at(p.w_H_t[p.Lt - 1]), style_win + (int64_t)(p.T - 1) * p.S, (int64_t)p.T * p.S,
                                c.at<float>(p.w_dX_n), uniform_pool, nullptr, nullptr, nullptr, state, results,
-                               p.c.recurrent_sigmoid, static_ready ? 1 : 0, kflags(p.c), c.st));
+                               p.c.recurrent_sigmoid, static_ready ? 1 : 0, c.at<float>(p.w_dX_n) + gen_floats, kflags(p.c),
+                               c.st));
   return dj_launch_gen_advance(state, results, notes_src, notes_dst, beat_src, beat_dst, p.B, p.T, p.N, p.NB, c.st);
 }
 }  // namespace
@@ -927,7 +931,8 @@ int32_t dj_generate_prepare(const dj_config* cfg, const float* params, const flo
   RUN(check_ws(p, ws, ws_bytes));
   if (!params || !style_win) return 1210;
   if (p.B > 8) return 1301;
-  const int64_t need = (int64_t)(8 * 64 + 4 * 8 * 512 + (int64_t)p.B * p.N * 4 * p.Hn) * 4;
+  const int64_t gen_floats = (8 * 64 + 4 * 8 * 512 + (int64_t)p.B * p.N * 4 * p.Hn + 63) / 64 * 64;   // the sampler's float scratch ...
+  const int64_t need = gen_floats * 4 + dj_gen_wpack_bytes();            // ... and its bf16 weight fragments (bf16 mode)
   if (need > p.Mn * (int64_t)p.nl[0].DP * p.esz) return 1302;
   Ctx c{p, params, (char*)ws, (hipStream_t)stream, false, 0};
   int64_t offs[6 + 5 * MAXL];
@@ -935,6 +940,8 @@ int32_t dj_generate_prepare(const dj_config* cfg, const float* params, const flo
   RUN(generate_static(c, style_win, offs));
   RUN(style_proj_all(c, p.tl, p.w_sp_t, p.Lt));
   RUN(dj_launch_cvt_transpose(p.c.dtype, c.P + p.p_conv_W, 72, 64, c.at(p.w_WcT), 80, c.st));
+  // the matrix-core sampler's bf16 weight fragments depend on the parameters only: packed here, once per run
+  RUN(dj_launch_generate_pack(p.c.dtype, p.Hn, p.Ln, params, offs, c.at<float>(p.w_dX_n) + gen_floats, kflags(p.c), c.st));
   return dj_launch_generate_prep(p.B, p.T, p.N, p.Ht, p.Hn, p.Ln, p.S, p.SU, params, offs,
                                  style_win + (int64_t)(p.T - 1) * p.S, (int64_t)p.T * p.S, c.at<float>(p.w_dX_n), c.st);
 }

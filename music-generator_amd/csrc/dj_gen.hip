@@ -14,11 +14,19 @@
 #include <cstdint>
 #include <cstring>
 #include <cstdlib>
+#include <type_traits>
 #include "dj_kernels.h"
 
 namespace {
 
 constexpr int GEN_MAXG = 8;
+// f(integral_constant<int, I>) for I = I0 .. N-1, every call inlined (compile-time loop index)
+template <int I, int N, typename Fn> __device__ __forceinline__ void dj_gen_static_for(Fn&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    dj_gen_static_for<I + 1, N>(f);
+  }
+}
 // A Bernoulli decision u <= p is reproduced by ANY implementation whose p agrees with this one's to better than
 // |u - p|.  Draws closer than this band are counted (dj_gen_state.near_ties / draws_used[1]): a run with a count of
 // zero is certified bit-identical to every model within 1e-5 of these probabilities (the fp32 oracle is within
@@ -513,6 +521,231 @@ __global__ __launch_bounds__(512) void gen_sample_ks_kernel(GenArgs a) {
 }
 
 
+// ---------------------------------------------------------------- the same walk on the matrix cores (bf16 mode, round 5)
+// The samplers above multiply on the vector ALUs against the fp32 master weights -- right for the fp32 mode, whose sampled
+// notes are certified against the oracle (probabilities within ~1e-6), and 10 us per note: 0.48 of the 0.84 ms of a
+// generated time step.  In bf16 mode the time axis already runs on bf16 operands, so the note axis may too (as it does
+// in training): here every note's products are MFMAs on bf16 weight fragments -- M = 32 rows of which G are pieces,
+// the rest a zero row -- with fp32 accumulation, cell state, heads and draws.  The 384 KB of fragments a note needs
+// (U0, [W1 ; U1]; packed once per run by gen_pack_bf16_kernel) do not depend on the note chain, so each wave keeps a ring
+// of RD fragments in flight that simply runs on from note to note: the stream costs its bytes (2.9 us per note at the
+// compute unit's 64 B/clk) and no latency.  Wave w = (unit group w & 3 of 32 units, K half w >> 2) owns the four gate
+// tiles of its units, so a unit's four gates meet in one thread's reach; the two K halves meet in LDS.
+constexpr int GM_NT = 16, GM_KC0 = 8, GM_KC1 = 16;              // 32-column tiles of 4 Hn = 512; k-chunks of 16: layer 0 / 1
+constexpr int GM_FRAGS = GM_NT * (GM_KC0 + GM_KC1);             // 384 fragments of 1 KiB
+// wpk[(f * 64 + lane) * 8 + e], f = layer offset + nt * NKC + kc: B fragment (column nt * 32 + l31, k = kc * 16 + 8 h + e)
+__global__ void gen_pack_bf16_kernel(const float* __restrict__ P, int64_t U0, int64_t W1, int64_t U1, bf16_t* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= GM_FRAGS * 512) return;
+  const int e = idx & 7, lane = (idx >> 3) & 63, f = idx >> 9;
+  const int col_in = lane & 31, kin = 8 * (lane >> 5) + e;
+  float v;
+  if (f < GM_NT * GM_KC0) {
+    const int nt = f / GM_KC0, kc = f % GM_KC0;
+    v = P[U0 + (int64_t)(kc * 16 + kin) * 512 + nt * 32 + col_in];
+  } else {
+    const int f1 = f - GM_NT * GM_KC0, nt = f1 / GM_KC1, kc = f1 % GM_KC1, k = kc * 16 + kin;
+    v = k < 128 ? P[W1 + (int64_t)k * 512 + nt * 32 + col_in] : P[U1 + (int64_t)(k - 128) * 512 + nt * 32 + col_in];
+  }
+  out[idx] = (bf16_t)v;
+}
+template <bool SIGM>
+__global__ __launch_bounds__(512) void gen_sample_mfma_kernel(GenArgs a, const bf16_t* __restrict__ wpk) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int Hn = 128, C4 = 512, RD = 16;
+  const int G = a.G, N = a.N;
+  float* zp = sm;                          // [2 K halves][4][512] partial pre-activations
+  float* hs1 = zp + 2 * 4 * C4;            // [4][128] fp32 h of layer 1 (heads)
+  float* spl = hs1 + 4 * Hn;               // [4][128] style term of layer 1
+  float* hw = spl + 4 * Hn;                // [3][128] + [4]
+  float* res = hw + 3 * Hn + 4;            // [4][N][3]
+  float* chosen = res + 4 * N * 3;         // [4][4]
+  float* logit = chosen + 16;              // [4][4]
+  float* temps = logit + 16;               // [8]
+  bf16_t* xb = (bf16_t*)(temps + 8);       // [3 vectors: h0, x1, h1][5 rows: 4 pieces + a zero row][128] bf16 A operand source
+  double* ul = (double*)(((uintptr_t)(xb + 3 * 5 * Hn) + 7) & ~(uintptr_t)7);   // [2 N G]
+  __shared__ int kdraw, knear;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), ug = w & 3, kh = w >> 2;
+  const int cu_g = tid >> 7, cu_u = tid & 127;          // cell role: unit (g, u), valid while tid < 128 G
+  const bool cell = tid < G * Hn;
+  const int draw0 = a.state ? a.state->draw_off : 0;
+  for (int i = tid; i < 3 * 5 * Hn / 2; i += 512) ((unsigned*)xb)[i] = 0u;
+  for (int i = tid; i < G * Hn; i += 512) spl[i] = a.svec[GEN_MAXG * 64 + (int64_t)GEN_MAXG * 512 + (i / Hn) * 512 + i % Hn];
+  for (int i = tid; i < Hn; i += 512) {
+    hw[i] = a.P[a.p_nd_W + (int64_t)i * 2];
+    hw[Hn + i] = a.P[a.p_nd_W + (int64_t)i * 2 + 1];
+    hw[2 * Hn + i] = a.P[a.p_vd_W + i];
+  }
+  if (tid < 2) hw[3 * Hn + tid] = a.P[a.p_nd_b + tid];
+  if (tid == 2) hw[3 * Hn + 2] = a.P[a.p_vd_b];
+  for (int i = tid; i < 2 * N * G; i += 512) ul[i] = a.uniforms[draw0 + i];
+  if (tid < G) temps[tid] = a.state ? (float)a.state->temperature[tid] : a.temperature[tid];
+  if (tid < 16) chosen[tid] = 0.f;
+  if (tid == 0) {
+    kdraw = 0;
+    knear = 0;
+  }
+  float wch[3][4], b1[4], zx[4], c0 = 0.f, c1 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) wch[c][q] = cell ? a.P[a.W[0] + (int64_t)(a.Ht + c) * C4 + q * Hn + cu_u] : 0.f;
+    b1[q] = cell ? a.P[a.b[1] + q * Hn + cu_u] : 0.f;
+    zx[q] = cell ? a.zx0[((int64_t)cu_g * N + 0) * C4 + q * Hn + cu_u] : 0.f;
+  }
+  // this wave's fragment stream of one note: 16 of layer 0 (k-chunk kh * 4 + i / 4, gate i % 4), then 32 of layer 1
+  // (k-chunk kh * 8 + i / 4, gate i % 4); gate q of unit group ug is column tile q * 4 + ug
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)wpk, 0, GM_FRAGS * 1024, 0x00020000);
+  auto frag_off = [&](int i) {              // i in [0, 48)
+    return i < 16 ? (((i & 3) * 4 + ug) * GM_KC0 + kh * 4 + (i >> 2)) * 1024
+                  : (GM_NT * GM_KC0 + ((i & 3) * 4 + ug) * GM_KC1 + kh * 8 + ((i - 16) >> 2)) * 1024;
+  };
+  typedef unsigned gm_u32x4 __attribute__((ext_vector_type(4)));
+  auto ldw = [&](int i) {
+    const gm_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wr, lane * 16, frag_off(i), 0);
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  bf16x8 rq[RD];
+#pragma unroll
+  for (int i = 0; i < RD; ++i) rq[i] = ldw(i);
+  // A operand rows: pieces for l31 < G, the zero row (index 4) for the other lanes
+  const int arow = l31 < G ? l31 : 4;
+  const bf16_t* a_h0 = xb + arow * Hn + 8 * h;
+  const bf16_t* a_x1 = a_h0 + 5 * Hn;
+  const bf16_t* a_h1 = a_h0 + 10 * Hn;
+  auto lds_barrier = [&]() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);    // lgkmcnt(0): weight fragments and the next note's x W + b stay in flight
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  __syncthreads();
+
+  for (int n = 0; n < N; ++n) {
+    // ---- both layers; every ring index below is a compile-time constant (48 % RD == 0)
+    dj_gen_static_for<0, 2>([&](auto lc) {
+      constexpr int l = decltype(lc)::value;
+      constexpr int I0 = l == 0 ? 0 : 16, NI = l == 0 ? 16 : 32;
+      f32x16 acc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+      dj_gen_static_for<0, NI>([&](auto ic) {
+        constexpr int i = I0 + decltype(ic)::value, kcl = (i - I0) >> 2, q = i & 3;
+        bf16x8 av;
+        if constexpr (l == 0) {
+          av = *(const bf16x8*)(a_h0 + (kh * 4 + kcl) * 16);
+        } else {
+          // k-chunks 0..7 of [x1 | h1] are x1, 8..15 h1: K half kh is exactly one of the two vectors
+          av = *(const bf16x8*)((kh == 0 ? a_x1 : a_h1) + kcl * 16);
+        }
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, rq[i % RD], acc[q], 0, 0, 0);
+        rq[i % RD] = ldw((i + RD) % 48);
+      });
+      // rows 0 .. G-1 of the accumulators (registers 0..2(3) of lanes 0..31) are the pieces
+      if (h == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            if (g < G) zp[(kh * 4 + g) * C4 + q * Hn + ug * 32 + l31] = acc[q][g];
+      }
+      lds_barrier();
+      // ---- cell update of unit (cu_g, cu_u) (Keras gate order i, f, c, o)
+      if (cell) {
+        float z[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float b;
+          if constexpr (l == 0)
+            b = zx[q] + chosen[cu_g * 4] * wch[0][q] + chosen[cu_g * 4 + 1] * wch[1][q] + chosen[cu_g * 4 + 2] * wch[2][q];
+          else
+            b = b1[q];
+          z[q] = b + (zp[cu_g * C4 + q * Hn + cu_u] + zp[(4 + cu_g) * C4 + q * Hn + cu_u]);
+        }
+        if (l == 0 && n + 1 < N) {         // next note's x W + b: in flight for a whole note
+#pragma unroll
+          for (int q = 0; q < 4; ++q) zx[q] = a.zx0[((int64_t)cu_g * N + n + 1) * C4 + q * Hn + cu_u];
+        }
+        const float ig = dj_ract<SIGM>(z[0]), fg = dj_ract<SIGM>(z[1]), gg = dj_tanh(z[2]), og = dj_ract<SIGM>(z[3]);
+        float& cc = l == 0 ? c0 : c1;
+        cc = fg * cc + ig * gg;
+        const float hv = og * dj_tanh(cc);
+        if constexpr (l == 0) {
+          xb[cu_g * Hn + cu_u] = (bf16_t)hv;                                     // h0: next note's recurrent operand
+          xb[5 * Hn + cu_g * Hn + cu_u] = (bf16_t)(hv + spl[cu_g * Hn + cu_u]);  // x1: layer 1's input
+        } else {
+          xb[10 * Hn + cu_g * Hn + cu_u] = (bf16_t)hv;
+          hs1[cu_g * Hn + cu_u] = hv;
+        }
+      }
+      lds_barrier();
+    });
+    // ---- heads: (play, replay) = sigmoid(h Wn + bn), volume = h Wv + bv   (model.py:94-95)
+    {
+      const int half = tid >> 5, l32 = tid & 31;
+      if (half < G * 3) {
+        const int g = half / 3, o = half - g * 3;
+        const float* ht = hs1 + g * Hn;
+        float s0 = 0.f;
+        for (int k = l32; k < Hn; k += 32) s0 += ht[k] * hw[o * Hn + k];
+        s0 = dj_row16_sum(s0);
+        s0 += __shfl_xor(s0, 16);
+        if (l32 == 0) logit[g * 4 + o] = s0 + hw[3 * Hn + o];
+      }
+    }
+    lds_barrier();
+    // ---- sampling, reference draw order (generate.py:47-58,116-118)
+    if (tid == 0) {
+      int k = kdraw;
+      for (int g = 0; g < G; ++g) {
+        float pp = dj_sigmoid(logit[g * 4]), pr = dj_sigmoid(logit[g * 4 + 1]);
+        const float vol = logit[g * 4 + 2];
+        const float temp = temps[g];
+        if (temp != 1.0f) {                       // apply_temperature, float32 like the reference (generate.py:81-91)
+          float x0 = -logf(1.0f / pp - 1.0f), x1 = -logf(1.0f / pr - 1.0f);
+          pp = 1.0f / (1.0f + expf(-x0 / temp));
+          pr = 1.0f / (1.0f + expf(-x1 / temp));
+        }
+        float play = 0.f, rep = 0.f, v = 0.f;
+        const double u0 = ul[k++];
+        knear += fabs(u0 - (double)pp) < DJ_GEN_TIE_BAND;
+        if (u0 <= (double)pp) {
+          play = 1.f;
+          v = vol;
+          const double u1 = ul[k++];
+          knear += fabs(u1 - (double)pr) < DJ_GEN_TIE_BAND;
+          if (u1 <= (double)pr) rep = 1.f;
+        }
+        chosen[g * 4] = play;
+        chosen[g * 4 + 1] = rep;
+        chosen[g * 4 + 2] = v;
+        float* o = res + ((int64_t)g * N + n) * 3;
+        o[0] = play;
+        o[1] = rep;
+        o[2] = v;
+      }
+      kdraw = k;
+    }
+    // no barrier: `chosen` is read behind the next note's first barrier (cell update of layer 0)
+  }
+  __syncthreads();
+  float* out_notes = a.state ? a.results + (int64_t)a.state->step * G * N * 3 : a.next_notes;
+  for (int i = tid; i < G * N * 3; i += 512) out_notes[i] = res[i];
+  if (tid == 0) {
+    if (a.state) {
+      a.state->draw_off = draw0 + kdraw;
+      if (knear && a.state->near_ties == 0) a.state->first_near_step = a.state->step;
+      a.state->near_ties += knear;
+    } else {
+      a.draws_used[0] = kdraw;
+      a.draws_used[1] = knear;
+    }
+  }
+}
+
 // end_time() of the reference on the device (generate.py:60-79): silence / temperature schedule,
 // then the windows slide by one step: dst[:, t] = src[:, t+1], dst[:, T-1] = new notes / beat(t).
 __global__ void gen_advance_kernel(DjGenState* st, const float* __restrict__ results, const float* __restrict__ nsrc,
@@ -560,6 +793,16 @@ int dj_launch_gen_advance(void* state, const float* results, const float* nsrc, 
   return (int)hipGetLastError();
 }
 int dj_gen_state_bytes() { return (int)sizeof(DjGenState); }
+// bytes of the bf16 weight fragments of the matrix-core sampler (U0, [W1 ; U1] of a 2 x 128 note axis), behind the
+// sampler's float scratch
+int dj_gen_wpack_bytes() { return GM_FRAGS * 1024; }
+int dj_launch_generate_pack(int dtype, int Hn, int Ln, const float* P, const int64_t* offs, void* wpack, uint32_t kf,
+                            hipStream_t st) {
+  if (!(dtype == DJ_BF16 && !(kf & DJ_KF_NO_GEN_MFMA) && wpack && Hn == 128 && Ln == 2)) return 0;
+  hipLaunchKernelGGL(gen_pack_bf16_kernel, dim3((GM_FRAGS * 512 + 255) / 256), dim3(256), 0, st, P, offs[9], offs[8 + 5],
+                     offs[9 + 5], (bf16_t*)wpack);
+  return (int)hipGetLastError();
+}
 
 // the sampler's style terms alone (gen_prep_kernel into the scratch): dj_generate_prepare
 int dj_launch_generate_prep(int G, int T, int N, int Ht, int Hn, int Ln, int S, int SU, const float* P, const int64_t* offs,
@@ -587,7 +830,7 @@ int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int
                              int64_t style_stride,
                              float* scratch, const double* uniforms, const float* temperature, float* next_notes,
                              int* draws_used, void* state, float* results, int sigm, int static_ready,
-                             uint32_t kf, hipStream_t st) {
+                             void* wpack, uint32_t kf, hipStream_t st) {
   if (G < 1 || G > GEN_MAXG || Ln < 1 || Ln > 4 || 4 * Hn > 1024 || (Hn % 32) || Ht + 3 > 512 || SU > 64 || S > 64) return 1300;
   GenArgs a;
   a.G = G; a.N = N; a.Hn = Hn; a.Ht = Ht; a.Ln = Ln; a.S = S; a.SU = SU; a.T = T; a.P = P;
@@ -614,6 +857,22 @@ int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int
   const size_t smem = ((size_t)3 * Ln * G * Hn + (size_t)G * 4 * Hn + (size_t)G * Hn + 3 * Hn + 4 + (size_t)G * N * 3 + 9 * G + 8) *
                           sizeof(float) + (size_t)2 * N * G * sizeof(double) + 16;
   if (smem > 64 * 1024) return 1301;
+  // bf16 mode, the reference's note axis (2 x 128 units), up to 4 pieces: the walk on the matrix cores against bf16
+  // weight fragments (gen_sample_mfma_kernel); the fragments depend on the parameters only (static_ready: packed already)
+  if (dtype == DJ_BF16 && !(kf & DJ_KF_NO_GEN_MFMA) && wpack && Hn == 128 && Ln == 2 && G <= 4) {
+    const size_t smem_m = ((size_t)2 * 4 * 512 + 4 * 128 + 4 * 128 + 3 * 128 + 4 + (size_t)4 * N * 3 + 16 + 16 + 8) * sizeof(float) +
+                          (size_t)3 * 5 * 128 * sizeof(bf16_t) + (size_t)2 * N * G * sizeof(double) + 16;
+    if (smem_m <= 64 * 1024) {
+      if (!static_ready)
+        hipLaunchKernelGGL(gen_pack_bf16_kernel, dim3((GM_FRAGS * 512 + 255) / 256), dim3(256), 0, st, P, a.U[0], a.W[1],
+                           a.U[1], (bf16_t*)wpack);
+      if (sigm)
+        hipLaunchKernelGGL((gen_sample_mfma_kernel<true>), dim3(1), dim3(512), smem_m, st, a, (const bf16_t*)wpack);
+      else
+        hipLaunchKernelGGL((gen_sample_mfma_kernel<false>), dim3(1), dim3(512), smem_m, st, a, (const bf16_t*)wpack);
+      return (int)hipGetLastError();
+    }
+  }
   const bool ks_off = (kf & DJ_KF_NO_GEN_KSPLIT) != 0;
   if (!ks_off && G <= 4 && 4 * Hn <= 512 && smem + (size_t)3 * G * 4 * Hn * sizeof(float) <= 64 * 1024) {
     const size_t smem_ks = smem + (size_t)3 * G * 4 * Hn * sizeof(float);      // zp is 4 x the size of zb

@@ -192,7 +192,13 @@ int dj_launch_generate_notes(int dtype, int G, int T, int N, int Ht, int Hn, int
                              const int64_t* offs /* [6 + 5*Ln] */, const void* Htime, const float* style_last,
                              int64_t style_stride, float* scratch, const double* uniforms, const float* temperature,
                              float* next_notes, int* draws_used, void* state, float* results, int sigm,
-                             int static_ready, uint32_t kf, hipStream_t st);
+                             int static_ready, void* wpack, uint32_t kf, hipStream_t st);
+// wpack: dj_gen_wpack_bytes() bytes for the bf16 weight fragments of the matrix-core sampler (bf16 mode; null = the
+// vector-ALU samplers); packed by the call unless static_ready
+int dj_gen_wpack_bytes();
+// packs them (a no-op where the matrix-core sampler does not apply: fp32, other widths, DJ_KF_NO_GEN_MFMA)
+int dj_launch_generate_pack(int dtype, int Hn, int Ln, const float* P, const int64_t* offs, void* wpack, uint32_t kf,
+                            hipStream_t st);
 int dj_launch_gen_advance(void* state, const float* results, const float* nsrc, float* ndst, const float* bsrc,
                           float* bdst, int G, int T, int N, int NB, hipStream_t st);
 int dj_gen_state_bytes();

@@ -182,3 +182,51 @@ def test_fused_generation_piece_counts(gpu_device, monkeypatch, G):
     np.testing.assert_array_equal(res[:sure, :, :, :2], slow[:, :, :, :2])
     np.testing.assert_allclose(res[:sure, :, :, 2], slow[:, :, :, 2], rtol=1e-3, atol=1e-5)
     assert pos_res == pos_slow
+
+
+def test_matrix_core_sampler_matches_vector_sampler_bf16(gpu_device, djenv):
+    """bf16 mode: the note walk of a generated step on the matrix cores (gen_sample_mfma_kernel: bf16 weight fragments,
+    fp32 accumulation, round 5) against the same walk on the vector ALUs with the fp32 master weights
+    (DJ_KF_NO_GEN_MFMA / DEEPJ_GEN_MFMA=0: the kernel the fp32 mode keeps), through dj_generate_step on ONE engine and one
+    window.  Uniforms of 1e-9 make every draw a success whatever the probability, so both walks feed the same `chosen`
+    (play = 1, replay = 1, the sampled volume) back into the note axis and consume 2 draws per note and piece; the
+    VOLUMES -- a linear read-out of the top hidden state at every note, i.e. of the whole 48-note x 2-layer recurrence --
+    then agree to bf16 operand rounding.  Uniforms of 1 - 1e-9 make every draw a failure: all-zero notes, one draw each."""
+    import torch
+    from music_generator_amd.engine import DeepJConfig, Engine, init_params_numpy
+    dev = gpu_device
+    G, T, N = 3, 128, 48
+    cfg = DeepJConfig(num_notes=N, time_steps=T, dtype="bf16")
+    rs = np.random.RandomState(5)
+    P = init_params_numpy(cfg, seed=21)
+    P = torch.from_numpy(P).to(dev)
+    notes = torch.from_numpy((rs.rand(G, T, N, 3) < 0.1).astype(np.float32)).to(dev)
+    beat = torch.zeros(G, T, 16, device=dev)
+    beat[:, torch.arange(T), torch.arange(T) % 16] = 1
+    style = torch.zeros(G, T, 23, device=dev)
+    style[torch.arange(G), :, torch.arange(G) * 7 % 23] = 1
+    temp = torch.ones(G, dtype=torch.float32, device=dev)
+
+    def run(mfma, uniforms):
+        djenv.set("DEEPJ_GEN_MFMA", "1" if mfma else "0")
+        eng = Engine(cfg, G, T, device=dev)
+        u = torch.from_numpy(uniforms).to(dev)
+        out, used = eng.generate_step(P, notes, beat, style, u, temp)
+        torch.cuda.synchronize()
+        r = out.cpu().numpy(), used.cpu().numpy().copy()
+        eng.close()
+        return r
+
+    lo = np.full(2 * N * G, 1e-9)
+    a, ua = run(True, lo)
+    b, ub = run(False, lo)
+    assert ua[0] == ub[0] == 2 * N * G
+    assert np.all(a[..., :2] == 1.0) and np.all(b[..., :2] == 1.0)
+    assert np.isfinite(a).all() and np.abs(b[..., 2]).max() > 1e-3
+    err = np.abs(a[..., 2] - b[..., 2]).max() / max(np.abs(b[..., 2]).max(), 1e-6)
+    print("matrix-core vs vector sampler, volumes over 48 notes x 3 pieces: max |diff| / max |v| = %.2e" % err)
+    assert err < 3e-2, err                                 # bf16 operands (tolerance of the bf16 forward, DESIGN section 2)
+    hi = np.full(2 * N * G, 1.0 - 1e-9)
+    a, ua = run(True, hi)
+    b, ub = run(False, hi)
+    assert ua[0] == ub[0] == N * G and not a.any() and not b.any()
