@@ -429,6 +429,8 @@ def pmc_traffic_from_dir(pmc_dir, category_of):
 
 def pmc_category(name):
     """Kernel name -> bench category for the PMC summary (as tools/pmc_summary.py)."""
+    if "lstm_bwd256_kernel" in name:                 # bf16 H = 256: the split-gate-math sweep (round 5)
+        return "lstm_bwd_time"
     if "lstm_bwd_kernel" in name:
         return "lstm_bwd_time" if "Li256" in name else "lstm_bwd_note"
     if "lstm_fwd_cluster" in name:

@@ -25,6 +25,8 @@ def load(d, counter):
 
 def category(name):
     n = name
+    if "lstm_bwd256_kernel" in n:
+        return "lstm_bwd_time"
     if "lstm_bwd_kernel" in n:
         return "lstm_bwd_time" if "Li256" in n else "lstm_bwd_note"
     if "lstm_fwd_cluster" in n:

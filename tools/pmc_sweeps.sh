@@ -10,7 +10,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTI
 done
 python - <<'PY' | tee gpurun_out/pmc_sweeps.txt
 import csv, glob, collections
-names = {"lstm_fwd_cluster_kernelILb0ELi16": "fwd cluster (time L1)", "lstm_bwd_kernelIDF16bLi256": "BPTT H=256", "lstm_fwd_fused_kernelIDF16bLi128ELb0ELb1": "fwd note L1", "lstm_bwd_kernelIDF16bLi128ELb0ELi1": "BPTT note L1", "lstm_wgrad_bf16": "wgrad"}
+names = {"lstm_fwd_cluster_kernelILb0ELi16": "fwd cluster (time L1)", "lstm_bwd256_kernel": "BPTT H=256 (split gate math)", "lstm_bwd_kernelIDF16bLi256": "BPTT H=256 (plain)", "lstm_fwd_fused_kernelIDF16bLi128ELb0ELb1": "fwd note L1", "lstm_bwd_kernelIDF16bLi128ELb0ELi1": "BPTT note L1", "lstm_wgrad_bf16": "wgrad"}
 for d in sorted(glob.glob("gpurun_out/pmc_sw_*/")):
     fs = glob.glob(d + "*/*counter_collection.csv")
     if not fs: continue
