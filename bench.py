@@ -365,6 +365,13 @@ def scaled_record(dtype, micro, steps, warmup, dropout, dev, rank, world, dist, 
     rates = {k_: round(fl[k_] / (kernels[k_] * 1e-3) / 1e12, 1) for k_ in fl if kernels.get(k_)}
     # HBM bytes per launch of the dominant category's kernel from rocprofv3 PMC passes of THIS build (tools/profile_scaled.sh)
     traffic = tsrc = None
+    try:        # committed passes of an earlier run of this shape (labelled as such), so that the driver's line is not null
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_scaled.json")))
+        if dtype == "bf16" and (B, T, N, micro) == (128, 256, 128, 2) and dom in pm:
+            traffic = pm[dom]
+            tsrc = "profiles/pmc_traffic_scaled.json (committed passes of an earlier run): " + pm["source"]
+    except Exception:
+        pass
     if pmc_dir:
         live = pmc_traffic_from_dir(pmc_dir, pmc_category)
         if dom in live:
