@@ -546,3 +546,58 @@ def test_gate_stash_quantiser_bounds_dz(gpu_device, H, S, Ls):
     print("stash quantiser H=%d: max|ddz|/max|dz| %.2e clear of the knees (%.2e with them), rms ratio %.2e, dbias %.2e"
           % (H, err, err_all, rms, dberr))
     assert err < 1.5e-2 and rms < 1.5e-2 and dberr < 2.5e-2, (err, err_all, rms, dberr)
+
+
+@pytest.mark.parametrize("S,Ls,sigm", [(96, 9, 0), (40, 4, 1)])
+def test_lstm_bwd256_split_vs_plain_kernel(gpu_device, djenv, S, Ls, sigm):
+    """bf16 H = 256 BPTT: the split-gate-math sweep (lstm_bwd256_kernel, the default since round 5: dh-independent factors
+    computed inside the product loop and kept as fp16 pairs, k-major dz tile, dH by LDS-DMA) against the round-4 kernel it
+    replaces (DJ_KF_BWD_PLAIN / DEEPJ_BWD_SPLIT=0), on ONE forward stash, upstream gradient and packed U^T: the same dZ
+    (row-major and column-tile-major) and bias gradient up to the rounding of the fp16 factors and of bf16 dz -- and the
+    fallback kernel stays exercised now that it is no longer the default.  S = 40 leaves 24 padded sequences in the last
+    tile: exactly zero dz there in both."""
+    L, lib = _lib()
+    H, D = 256, 24
+    x, W, U, b = _lstm_setup(S, Ls, D, H, H + S + 1)
+    zx = (x @ W + b).to(torch.bfloat16).float()
+    zrows, tiles = to_rows(zx)
+    R = zrows.shape[0]
+    Zd = _op(to_frag(zrows), "bf16").to(gpu_device)
+    Ud = U.to(gpu_device)
+    upf = torch.empty(H * 4 * H * 2, dtype=torch.uint8, device=gpu_device)
+    upb = torch.empty_like(upf)
+    L.check(lib.dj_lstm_pack(1, H, L.ptr(Ud), L.ptr(upf), L.ptr(upb), _st()), "pack")
+    Hd = torch.zeros(tiles * Ls * 32, H, dtype=Zd.dtype, device=gpu_device)
+    Cd = torch.zeros(R * H, dtype=Zd.dtype, device=gpu_device)
+    Gd = stash_buffer(R, H, "bf16", gpu_device)
+    L.check(lib.dj_lstm_fwd(1, H, tiles, Ls, L.ptr(Zd), L.ptr(Gd), L.ptr(upf), L.ptr(Hd), L.ptr(Cd), sigm, _st()), "fwd")
+    dH = torch.randn(S, Ls, H, generator=torch.Generator().manual_seed(9)) * 0.1
+    dHd = _op(to_rows(dH)[0], "bf16").to(gpu_device)
+    cts = R * 256 + 256
+
+    def run(split):
+        djenv.set("DEEPJ_BWD_SPLIT", "1" if split else "0")
+        dZ = torch.zeros(R, 4 * H, dtype=Zd.dtype, device=gpu_device)
+        db = torch.zeros(4 * H, dtype=torch.float32, device=gpu_device)
+        L.check(lib.dj_lstm_bwd(1, H, tiles, Ls, L.ptr(Gd), L.ptr(upb), L.ptr(Cd), L.ptr(dHd), L.ptr(dZ), 0, L.ptr(db), sigm,
+                                _st()), "bwd")
+        dZt = torch.zeros(4 * cts, dtype=Zd.dtype, device=gpu_device)
+        db2 = torch.zeros_like(db)
+        L.check(lib.dj_lstm_bwd(1, H, tiles, Ls, L.ptr(Gd), L.ptr(upb), L.ptr(Cd), L.ptr(dHd), L.ptr(dZt), cts, L.ptr(db2),
+                                sigm, _st()), "bwd tiled")
+        torch.cuda.synchronize()
+        back = dZt.reshape(4, cts)[:, :R * 256].reshape(4, R, 256).permute(1, 0, 2).reshape(R, 4 * H)
+        assert torch.equal(back, dZ)                  # both dZ layouts of one kernel: the same numbers
+        return dZ.float().cpu(), db.cpu()
+
+    dz_s, db_s = run(True)
+    dz_p, db_p = run(False)
+    scale = float(dz_p.abs().max())
+    assert scale > 1e-3
+    err = float((dz_s - dz_p).abs().max()) / scale
+    dberr = float((db_s - db_p).abs().max()) / float(db_p.abs().max())
+    print("split vs plain BPTT sweep: max |d dz| / max |dz| = %.2e, bias gradient %.2e" % (err, dberr))
+    assert err < 1.5e-2 and dberr < 5e-3, (err, dberr)
+    if S % 32:
+        for dz in (dz_s, dz_p):
+            assert float(dz.reshape(tiles, Ls, 32, 4 * H)[-1, :, S % 32:, :].abs().max()) == 0.0
