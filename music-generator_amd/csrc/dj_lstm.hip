@@ -2052,17 +2052,22 @@ __global__ __launch_bounds__((BwdCfg<T, H>::NT)) void lstm_bwd_kernel(const Stas
 // decoding, the tanh, two thirds of the vector instructions of a step -- INSIDE the product loop of step t, one cell
 // per group of k-chunks, in the issue slots the fragment stream leaves empty, and the part of a step that nothing
 // overlaps shrinks to the six operations above, the dz tile and its barriers.  Order of a step t (tile = 32 sequences):
-//   top       dH_t registers -> LDS; REQUEST the stash of step t-1 (gate codes, c_{t-2}; dH_{t-1}) and the first ring of
-//             U^T fragments -- nothing in the step waits for them before the product
+//   top       wait for the dH tile of step t (LDS-DMA, requested a step earlier); REQUEST dH_{t-1} (DMA into the other
+//             dH tile) and the stash of step t-1 (gate codes, c_{t-2}) -- nothing waits for them before the product
 //   barrier   (dH tile visible; every wave is done reading the dz tile of step t+1)
-//   finish    dh_t = dH_t + acc;  the six operations per cell with the factors of step t;  dz_t -> LDS;  bias sums
+//   finish    dh_t = dH_t + acc;  the six operations per cell with the factors of step t (fp16 pairs, v_fma_mix_f32);
+//             dz_t -> LDS, k-major: 16 ds_write_b64 per wave instead of 64 ds_write_b16;  bias sums
 //   barrier   (dz tile complete)
-//   product   acc = dz_t U^T (A operand from LDS; U^T: KL chunks per column block resident in LDS, KS stationary in
-//             registers, the rest through the ring), with the factors of step t-1 computed in between
-//   store     dz_t tile LDS -> HBM, coalesced, BEHIND the product: vector memory is acknowledged in order, so stores in
-//             front of the product would hold back every ring refill issued behind them by their HBM acknowledgement
-// NJ = 32-unit column blocks per wave: 1 = eight waves (two per SIMD, 256 registers each), 2 = four waves (one per SIMD,
-// 512 registers: room for KS stationary chunks of U^T per column block next to the LDS-resident ones).
+//   product   acc = dz_t U^T (A operand out of the k-major tile by ds_read_b64_tr_b16; U^T: KL chunks per column block
+//             resident in LDS, KS stationary in registers, the rest through a ring of PD), with the factors of step t-1
+//             and the rows of dz_t on their way to HBM (4 rows x 256 bytes per store instruction) between its chunks
+// What the measurements say about it: 2.91 -> 2.78 ms per training step; the vector work
+// moved into the product is NOT hidden at two waves per SIMD (ablations: the step is the sum of MFMA + finish, U^T stream,
+// factor math and row stores), and a wave's vector memory returns in order, so an HBM request in front of the ring costs
+// the ring its latency.
+// NJ = 32-unit column blocks per wave: 1 = eight waves (two per SIMD, 256 registers each; the product form <1, 4, 8>),
+// 2 = four waves (one per SIMD, 512 registers: measured 3.19 - 3.34 ms, hipcc fills 430 - 470 registers before the first
+// stationary fragment).
 struct Bwd256 {
   static constexpr int H = 256, KC = 16, NKCB = 64, NCB = 32, NCBH = 8;
   static constexpr int KL = 8;                                     // k-chunks per column block resident in LDS
