@@ -99,3 +99,40 @@ def test_visualize_main_on_hip_models(gpu_device, tmp_path, monkeypatch, capsys)
     np.testing.assert_allclose(models[0].get_layer('style')(x), x.astype(np.float32) @ w + b, rtol=1e-5, atol=1e-6)
     visualize.main()                                            # the CLI form: build_or_load inside
     assert "Writing to out directory" in capsys.readouterr().out
+
+
+def test_engine_close_and_pending_census(gpu_device):
+    """An engine's finalizer does no HIP work (round 5: a finalizer may run inside somebody's graph capture): close() takes
+    the last fault census and releases the workspace; an engine that is simply dropped hands its workspace to
+    engine.drain_pending(), which takes the census at the next safe point -- Engine(), close(), the test fixture."""
+    import gc
+    import torch
+    from music_generator_amd import engine as E
+    from music_generator_amd.engine import DeepJConfig, Engine
+    cfg = DeepJConfig(num_notes=24, time_steps=4)
+    gc.collect()
+    E.drain_pending()
+    n0 = E.CENSUS["engines"]
+    eng = Engine(cfg, 2, 4, device=gpu_device)
+    assert eng in E._LIVE
+    eng.close()
+    eng.close()                                            # idempotent
+    assert E.CENSUS["engines"] == n0 + 1 and eng not in E._LIVE and eng.ws is None
+    eng2 = Engine(cfg, 2, 4, device=gpu_device)
+    ws_ptr = eng2.ws.data_ptr()
+    del eng2
+    gc.collect()
+    assert len(E._PENDING) == 1 and E._PENDING[0][2].data_ptr() == ws_ptr      # workspace parked, not read
+    assert E.CENSUS["engines"] == n0 + 1
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        x = torch.zeros(8, device=gpu_device)
+        with torch.cuda.graph(g, stream=s):
+            assert E.drain_pending() == 0                  # never inside a capture
+            x += 1
+    assert len(E._PENDING) == 1
+    assert E.drain_pending() == 1 and not E._PENDING and E.CENSUS["engines"] == n0 + 2
+    with Engine(cfg, 2, 4, device=gpu_device) as eng3:     # context manager = close()
+        assert eng3.cluster_faults() == 0
+    assert E.CENSUS["engines"] == n0 + 3
